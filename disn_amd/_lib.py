@@ -1,0 +1,107 @@
+"""ctypes binding of libdisn_amd.so (include/disn_amd.h).
+
+The HIP library is the product: there is NO CPU fallback.  ``lib()`` raises
+``DisnLibraryError`` when the shared object is missing or does not export the
+ABI this package was written against; every wrapper raises ``DisnError`` on a
+non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libdisn_amd.so")
+ABI_VERSION = 1
+
+c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+
+class DisnLibraryError(RuntimeError):
+    pass
+
+
+class DisnError(RuntimeError):
+    def __init__(self, fn: str, status: int):
+        kind = {-1: "invalid argument", -2: "unsupported shape", -3: "workspace too small"}.get(
+            status, "hipError_t %d" % status if status > 0 else "error")
+        super().__init__("%s failed: %s (status %d)" % (fn, kind, status))
+        self.status = status
+
+
+class VggWeights(C.Structure):  # disn_vgg_weights_t
+    _fields_ = [("conv_w", C.c_void_p * 13), ("conv_b", C.c_void_p * 13),
+                ("fc_w", C.c_void_p * 3), ("fc_b", C.c_void_p * 3), ("num_classes", C.c_int)]
+
+
+MLP_FIELDS = ("g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3", "g_w4_point", "g_w4_global", "g_b4",
+              "g_w5", "g_b5", "g_w6", "g_b6", "l_w1", "l_b1", "l_w2", "l_b2", "l_w3", "l_b3",
+              "l_w4", "l_b4", "l_w5", "l_b5", "l_w6", "l_b6")
+
+
+class MlpWeights(C.Structure):  # disn_mlp_weights_t
+    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS]
+
+
+# name -> (restype, argtypes); every symbol declared in include/disn_amd.h
+I, Z, P, F, L = C.c_int, C.c_size_t, C.c_void_p, C.c_float, C.c_int64
+SIGNATURES = {
+    "disn_abi_version": (I, []),
+    "disn_pack_kn": (I, [P, I, I, I, P, P]),
+    "disn_resize_bilinear": (I, [P, I, I, I, I, P, I, I, I, I, P]),
+    "disn_vgg16_workspace_bytes": (Z, [I]),
+    "disn_vgg16_forward": (I, [C.POINTER(VggWeights), P, I, P, C.POINTER(C.c_void_p * 5), P, P, Z, P]),
+    "disn_conv3x3_workspace_bytes": (Z, [I, I, I, I, I]),
+    "disn_conv3x3": (I, [P, I, I, I, I, P, P, I, I, P, P, Z, P]),
+    "disn_maxpool2x2": (I, [P, I, I, I, I, P, P]),
+    "disn_fc_workspace_bytes": (Z, [I, I, I]),
+    "disn_fc": (I, [P, I, I, P, P, I, I, P, P, Z, P]),
+    "disn_dense_workspace_bytes": (Z, [I, I, I]),
+    "disn_dense": (I, [P, I, I, P, I, I, I, P, P, I, I, P, P, Z, P]),
+    "disn_build_featmap": (I, [C.POINTER(C.c_void_p * 5), I, P, P]),
+    "disn_project": (I, [P, P, I, I, P, P]),
+    "disn_gather": (I, [P, P, I, I, P, P]),
+    "disn_sdf_mlp_workspace_bytes": (Z, [I, I]),
+    "disn_sdf_mlp": (I, [C.POINTER(MlpWeights), P, P, P, I, I, P, P, P, P, Z, P]),
+    "disn_query_workspace_bytes": (Z, [I, I]),
+    "disn_query": (I, [C.POINTER(MlpWeights), P, P, P, P, P, I, I, P, P, Z, P]),
+    "disn_grid_points": (I, [C.POINTER(C.c_double * 6), I, L, L, P, P]),
+    "disn_query_grid_workspace_bytes": (Z, [L]),
+    "disn_query_grid": (I, [C.POINTER(MlpWeights), P, P, P, C.POINTER(C.c_double * 6), I, L, L, F, P,
+                            P, Z, P]),
+}
+
+_LIB: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and type the shared library.  Fails loudly."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise DisnLibraryError(
+            "HIP extension %s is missing: build it with `python -m disn_amd.csrc.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)
+    try:
+        h = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise DisnLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise DisnLibraryError("%s does not export %s" % (LIB_PATH, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    v = h.disn_abi_version()
+    if v != ABI_VERSION:
+        raise DisnLibraryError("ABI mismatch: library %d, binding %d" % (v, ABI_VERSION))
+    _LIB = h
+    return h
+
+
+def check(fn: str, status: int) -> None:
+    if status != 0:
+        raise DisnError(fn, status)

@@ -1,0 +1,454 @@
+// extern "C" entry points of include/disn_amd.h: argument checking, workspace carving and
+// the launch sequences.  No allocation, no global mutable state, no host synchronisation.
+#include "../../include/disn_amd.h"
+
+#include "kernels.hpp"
+
+using namespace disn;
+
+#define DISN_TRY(expr)                    \
+  do {                                    \
+    hipError_t _e = (expr);               \
+    if (_e != hipSuccess) return (int)_e; \
+  } while (0)
+
+namespace {
+
+struct Bump {  // carve a caller-provided workspace; base == nullptr just measures
+  char* base;
+  size_t off;
+  explicit Bump(void* b) : base(static_cast<char*>(b)), off(0) {}
+  float* take(size_t bytes) {
+    off = (off + 255) & ~size_t(255);
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+// ---- VGG-16 -----------------------------------------------------------------
+struct VggLayer {
+  int cin, cout, hw, tap;  // tap index or -1
+};
+const VggLayer kVgg[13] = {
+    {3, 64, 224, -1},   {64, 64, 224, 0},    {64, 128, 112, -1},  {128, 128, 112, 1},
+    {128, 256, 56, -1}, {256, 256, 56, -1},  {256, 256, 56, 2},   {256, 512, 28, -1},
+    {512, 512, 28, -1}, {512, 512, 28, 3},   {512, 512, 14, -1},  {512, 512, 14, -1},
+    {512, 512, 14, 4}};
+const bool kPoolAfter[13] = {false, true, false, true, false, false, true,
+                             false, false, true, false, false, true};
+
+inline int conv_k(int cin) { return cin == 3 ? 32 : 9 * cin; }
+
+struct VggWs {
+  float *resized, *bufA, *bufB, *bufP, *gemm_ws, *fc_ws, *fc6, *fc7;
+  size_t total;
+};
+
+VggWs vgg_layout(void* ws, int B, int num_classes) {
+  Bump b(ws);
+  VggWs w;
+  const size_t big = (size_t)B * 224 * 224 * 64 * sizeof(float);
+  w.resized = b.take((size_t)B * 224 * 224 * 3 * sizeof(float));
+  w.bufA = b.take(big);
+  w.bufB = b.take(big / 4);  // only used from conv3 on (56x56x256 = big/4)
+  w.bufP = b.take(big / 4);
+  size_t gws = 0;
+  for (const VggLayer& L : kVgg) {
+    const GemmPlan pl = gemm_plan(B * L.hw * L.hw, L.cout, conv_k(L.cin));
+    if (pl.ws_bytes > gws) gws = pl.ws_bytes;
+  }
+  w.gemm_ws = b.take(gws);
+  size_t fws = gemv_ws_bytes(B, 25088, 4096);
+  const size_t f7 = gemv_ws_bytes(B, 4096, 4096), f8 = gemv_ws_bytes(B, 4096, num_classes);
+  if (f7 > fws) fws = f7;
+  if (f8 > fws) fws = f8;
+  w.fc_ws = b.take(fws);
+  w.fc6 = b.take((size_t)B * 4096 * sizeof(float));
+  w.fc7 = b.take((size_t)B * 4096 * sizeof(float));
+  w.total = (b.off + 255) & ~size_t(255);
+  return w;
+}
+
+int conv3x3_impl(const float* in, int B, int H, int W, int Cin, const float* w_packed,
+                 const float* bias, int Cout, int relu, float* out, float* ws, size_t ws_bytes,
+                 hipStream_t st) {
+  if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
+  if (!(Cin == 3 || Cin % 32 == 0) || Cout % 64 != 0 || H >= 32768 || W >= 32768)
+    return DISN_E_SHAPE;
+  GemmParams p{};
+  p.a1 = in;
+  p.H = H; p.W = W; p.Cin = Cin;
+  p.M = B * H * W; p.N = Cout; p.K = conv_k(Cin);
+  p.bp = w_packed; p.bias = bias; p.rows_per_bias = 0;
+  p.out = out; p.ldc = Cout; p.relu = relu;
+  const GemmPlan pl = gemm_plan(p.M, p.N, p.K);
+  if (pl.ws_bytes > ws_bytes || (pl.ws_bytes && !ws)) return DISN_E_WS;
+  DISN_TRY(gemm_launch(p, Cin == 3 ? GEMM_CONV3_C3 : GEMM_CONV3, pl, ws, st));
+  return 0;
+}
+
+// ---- point MLP ----------------------------------------------------------------
+const int kChunk = 65536;  // points per MLP pass inside disn_query / disn_sdf_mlp
+
+struct MlpWs {
+  float *e1g, *e1l, *h256, *h512a, *h512b, *g5, *l5, *gemm_ws;
+  size_t total;
+};
+
+size_t mlp_gemm_ws(int n) {
+  size_t m = 0;
+  const int shapes[5][2] = {{256, 64}, {512, 256}, {512, 512}, {512, 1984}, {256, 512}};
+  for (auto& s : shapes) {
+    const GemmPlan pl = gemm_plan(n, s[0], s[1]);
+    if (pl.ws_bytes > m) m = pl.ws_bytes;
+  }
+  return m;
+}
+
+MlpWs mlp_layout(Bump& b, int n) {
+  MlpWs w;
+  const size_t f = sizeof(float);
+  w.e1g = b.take((size_t)n * 64 * f);
+  w.e1l = b.take((size_t)n * 64 * f);
+  w.h256 = b.take((size_t)n * 256 * f);
+  w.h512a = b.take((size_t)n * 512 * f);
+  w.h512b = b.take((size_t)n * 512 * f);
+  w.g5 = b.take((size_t)n * 256 * f);
+  w.l5 = b.take((size_t)n * 256 * f);
+  w.gemm_ws = b.take(mlp_gemm_ws(n));
+  w.total = b.off;
+  return w;
+}
+
+bool mlp_weights_ok(const disn_mlp_weights_t* w) {
+  if (!w) return false;
+  const float* const* p = reinterpret_cast<const float* const*>(w);
+  for (size_t i = 0; i < sizeof(disn_mlp_weights_t) / sizeof(const float*); ++i)
+    if (!p[i]) return false;
+  return true;
+}
+
+int dense_layer(const float* a1, int lda1, int k1, const float* a2, int lda2, int K, int n,
+                const float* bp, const float* bias, int N, float* out, float* ws,
+                hipStream_t st) {
+  GemmParams p{};
+  p.a1 = a1; p.lda1 = lda1; p.k1 = k1; p.a2 = a2; p.lda2 = lda2;
+  p.M = n; p.N = N; p.K = K;
+  p.bp = bp; p.bias = bias; p.rows_per_bias = 0;
+  p.out = out; p.ldc = N; p.relu = 1;
+  const GemmPlan pl = gemm_plan(n, N, K);
+  DISN_TRY(gemm_launch(p, GEMM_DENSE, pl, ws, st));
+  return 0;
+}
+
+// both MLP streams for n points of ONE image (gbias = that image's folded bias row)
+int mlp_chunk(const disn_mlp_weights_t* w, const float* pts_rot, int n, const float* gbias,
+              const float* feat, float* sdf, float* sdf_g, float* sdf_l, float out_div,
+              const MlpWs& s, hipStream_t st) {
+  int rc;
+  DISN_TRY(pt_embed_launch(pts_rot, n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g, s.e1l, st));
+  // global stream  (models/sdfnet.py:71-88)
+  if ((rc = dense_layer(s.e1g, 64, 64, nullptr, 0, 64, n, w->g_w2, w->g_b2, 256, s.h256, s.gemm_ws, st))) return rc;
+  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->g_w3, w->g_b3, 512, s.h512a, s.gemm_ws, st))) return rc;
+  if ((rc = dense_layer(s.h512a, 512, 512, nullptr, 0, 512, n, w->g_w4_point, gbias, 512, s.h512b, s.gemm_ws, st))) return rc;
+  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->g_w5, w->g_b5, 256, s.g5, s.gemm_ws, st))) return rc;
+  // local stream  (models/sdfnet.py:173-186); fold2/conv1 reads [point512 | feat1472]
+  if ((rc = dense_layer(s.e1l, 64, 64, nullptr, 0, 64, n, w->l_w2, w->l_b2, 256, s.h256, s.gemm_ws, st))) return rc;
+  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->l_w3, w->l_b3, 512, s.h512a, s.gemm_ws, st))) return rc;
+  if ((rc = dense_layer(s.h512a, 512, 512, feat, DISN_FEAT_DIM, 512 + DISN_FEAT_DIM, n, w->l_w4, w->l_b4, 512, s.h512b, s.gemm_ws, st))) return rc;
+  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->l_w5, w->l_b5, 256, s.l5, s.gemm_ws, st))) return rc;
+  DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, sdf_g, sdf_l,
+                            out_div, st));
+  return 0;
+}
+
+struct QueryWs {
+  float *gbias, *gemv_ws, *feat, *pts;
+  MlpWs mlp;
+  size_t total;
+};
+
+QueryWs query_layout(void* ws, int B, int chunk, bool need_feat, bool need_pts) {
+  Bump b(ws);
+  QueryWs q;
+  q.gbias = b.take((size_t)B * 512 * sizeof(float));
+  q.gemv_ws = b.take(gemv_ws_bytes(B, DISN_EMBED_DIM, 512));
+  q.feat = need_feat ? b.take((size_t)chunk * DISN_FEAT_DIM * sizeof(float)) : nullptr;
+  q.pts = need_pts ? b.take((size_t)chunk * 3 * sizeof(float)) : nullptr;
+  q.mlp = mlp_layout(b, chunk);
+  q.total = (b.off + 255) & ~size_t(255);
+  return q;
+}
+
+inline int chunk_for(long n) { return (int)(n < kChunk ? (n > 0 ? n : 1) : kChunk); }
+
+bool grid_spec(const double* p, int R, GridSpec* g) {
+  if (!p || R < 1) return false;
+  g->res = R + 1;
+  for (int a = 0; a < 3; ++a) {
+    g->start[a] = p[a];
+    g->stop[a] = p[a + 3];
+    g->step[a] = (p[a + 3] - p[a]) / (double)R;  // numpy.linspace: delta / div
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int disn_abi_version(void) { return DISN_ABI_VERSION; }
+
+int disn_pack_kn(const float* w_kn, int K, int N, int Kpad, float* packed, void* stream) {
+  if (!w_kn || !packed || K <= 0 || N <= 0) return DISN_E_ARG;
+  if (N % 32 || Kpad % 32 || Kpad < K) return DISN_E_SHAPE;
+  DISN_TRY(pack_kn_launch(w_kn, K, N, Kpad, packed, (hipStream_t)stream));
+  return 0;
+}
+
+int disn_resize_bilinear(const float* in, int B, int Hin, int Win, int C, float* out, int Hout,
+                         int Wout, int out_cstride, int out_coff, void* stream) {
+  if (!in || !out || B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || Hout <= 0 || Wout <= 0)
+    return DISN_E_ARG;
+  if (out_coff < 0 || out_coff + C > out_cstride) return DISN_E_SHAPE;
+  DISN_TRY(resize_bilinear_launch(in, B, Hin, Win, C, out, Hout, Wout, out_cstride, out_coff,
+                                  (hipStream_t)stream));
+  return 0;
+}
+
+size_t disn_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  return gemm_plan(B * H * W, Cout, conv_k(Cin)).ws_bytes;
+}
+
+int disn_conv3x3(const float* in, int B, int H, int W, int Cin, const float* w_packed,
+                 const float* bias, int Cout, int relu, float* out, void* ws, size_t ws_bytes,
+                 void* stream) {
+  return conv3x3_impl(in, B, H, W, Cin, w_packed, bias, Cout, relu, out, (float*)ws, ws_bytes,
+                      (hipStream_t)stream);
+}
+
+int disn_maxpool2x2(const float* in, int B, int H, int W, int C, float* out, void* stream) {
+  if (!in || !out || B <= 0 || H < 2 || W < 2) return DISN_E_ARG;
+  if (C % 4) return DISN_E_SHAPE;
+  DISN_TRY(maxpool2x2_launch(in, B, H, W, C, out, (hipStream_t)stream));
+  return 0;
+}
+
+size_t disn_fc_workspace_bytes(int B, int K, int N) {
+  if (B <= 0 || K <= 0 || N <= 0 || N % 256) return 0;
+  return gemv_ws_bytes(B, K, N);
+}
+
+int disn_fc(const float* x, int B, int K, const float* w_kn, const float* bias, int N, int relu,
+            float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !w_kn || !bias || !out || !ws || B <= 0 || K <= 0) return DISN_E_ARG;
+  if (N <= 0 || N % 256) return DISN_E_SHAPE;
+  if (ws_bytes < gemv_ws_bytes(B, K, N)) return DISN_E_WS;
+  DISN_TRY(gemv_launch(x, B, K, w_kn, bias, N, relu, out, (float*)ws, (hipStream_t)stream));
+  return 0;
+}
+
+size_t disn_dense_workspace_bytes(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0 || K % 32 || N % 64) return 0;
+  return gemm_plan(M, N, K).ws_bytes;
+}
+
+int disn_dense(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, int M,
+               const float* w_packed, const float* bias, int N, int relu, float* out, void* ws,
+               size_t ws_bytes, void* stream) {
+  if (!a1 || !w_packed || !bias || !out || M <= 0 || k1 <= 0 || k2 < 0 || (k2 > 0 && !a2))
+    return DISN_E_ARG;
+  if (k1 % 32 || k2 % 32 || N <= 0 || N % 64 || lda1 < k1 || (k2 > 0 && lda2 < k2) || lda1 % 4 ||
+      (k2 > 0 && lda2 % 4))
+    return DISN_E_SHAPE;
+  GemmParams p{};
+  p.a1 = a1; p.lda1 = lda1; p.k1 = k1; p.a2 = a2; p.lda2 = lda2;
+  p.M = M; p.N = N; p.K = k1 + k2;
+  p.bp = w_packed; p.bias = bias; p.rows_per_bias = 0;
+  p.out = out; p.ldc = N; p.relu = relu;
+  const GemmPlan pl = gemm_plan(M, N, p.K);
+  if (pl.ws_bytes > ws_bytes || (pl.ws_bytes && !ws)) return DISN_E_WS;
+  DISN_TRY(gemm_launch(p, GEMM_DENSE, pl, (float*)ws, (hipStream_t)stream));
+  return 0;
+}
+
+size_t disn_vgg16_workspace_bytes(int B) {
+  if (B <= 0) return 0;
+  return vgg_layout(nullptr, B, DISN_EMBED_DIM).total;
+}
+
+int disn_vgg16_forward(const disn_vgg_weights_t* w, const float* img, int B, float* resized224,
+                       float* const taps[5], float* embedding, void* ws, size_t ws_bytes,
+                       void* stream) {
+  if (!w || !img || !taps || !embedding || !ws || B <= 0) return DISN_E_ARG;
+  for (int i = 0; i < 5; ++i)
+    if (!taps[i]) return DISN_E_ARG;
+  for (int i = 0; i < 13; ++i)
+    if (!w->conv_w[i] || !w->conv_b[i]) return DISN_E_ARG;
+  for (int i = 0; i < 3; ++i)
+    if (!w->fc_w[i] || !w->fc_b[i]) return DISN_E_ARG;
+  if (w->num_classes <= 0 || w->num_classes % 256) return DISN_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const VggWs s = vgg_layout(ws, B, w->num_classes);
+  if (s.total > ws_bytes) return DISN_E_WS;
+  float* resized = resized224 ? resized224 : s.resized;
+  // row A: 137 -> 224 legacy bilinear  (models/model_normalization.py:65-72)
+  DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, resized, DISN_VGG_SIZE,
+                                  DISN_VGG_SIZE, 3, 0, st));
+  // row B: conv stack  (models/CNN/vgg.py:187-196)
+  const float* x = resized;
+  bool toggle = false;
+  const size_t gws_cap = (size_t)((char*)s.fc_ws - (char*)s.gemm_ws);
+  for (int i = 0; i < 13; ++i) {
+    const VggLayer& L = kVgg[i];
+    float* out = L.tap >= 0 ? taps[L.tap] : (L.hw >= 112 ? s.bufA : (toggle ? s.bufB : s.bufA));
+    if (L.tap < 0 && L.hw < 112) toggle = !toggle;
+    const int rc = conv3x3_impl(x, B, L.hw, L.hw, L.cin, w->conv_w[i], w->conv_b[i], L.cout, 1,
+                                out, s.gemm_ws, gws_cap, st);
+    if (rc) return rc;
+    x = out;
+    if (kPoolAfter[i]) {
+      DISN_TRY(maxpool2x2_launch(x, B, L.hw, L.hw, L.cout, s.bufP, st));
+      x = s.bufP;
+      toggle = false;
+    }
+  }
+  // row C: fc6 (7x7 VALID == dense over the NHWC-flattened pool5), fc7, fc8
+  // (models/CNN/vgg.py:198-214; dropout inactive: is_training=False, model_normalization.py:76)
+  DISN_TRY(gemv_launch(x, B, 25088, w->fc_w[0], w->fc_b[0], 4096, 1, s.fc6, s.fc_ws, st));
+  DISN_TRY(gemv_launch(s.fc6, B, 4096, w->fc_w[1], w->fc_b[1], 4096, 1, s.fc7, s.fc_ws, st));
+  DISN_TRY(gemv_launch(s.fc7, B, 4096, w->fc_w[2], w->fc_b[2], w->num_classes, 0, embedding,
+                       s.fc_ws, st));
+  return 0;
+}
+
+int disn_build_featmap(const float* const taps[5], int B, float* featmap, void* stream) {
+  if (!taps || !featmap || B <= 0) return DISN_E_ARG;
+  const int hw[5] = {224, 112, 56, 28, 14}, ch[5] = {64, 128, 256, 512, 512};
+  int coff = 0;
+  for (int i = 0; i < 5; ++i) {
+    if (!taps[i]) return DISN_E_ARG;
+    DISN_TRY(resize_bilinear_launch(taps[i], B, hw[i], hw[i], ch[i], featmap, DISN_IMG_H,
+                                    DISN_IMG_W, DISN_FEAT_DIM, coff, (hipStream_t)stream));
+    coff += ch[i];
+  }
+  return 0;
+}
+
+int disn_project(const float* pts, const float* trans_mat, int B, int N, float* xy, void* stream) {
+  if (!pts || !trans_mat || !xy || B <= 0 || N <= 0) return DISN_E_ARG;
+  DISN_TRY(project_launch(pts, trans_mat, B, N, xy, (hipStream_t)stream));
+  return 0;
+}
+
+int disn_gather(const float* featmap, const float* xy, int B, int N, float* feat, void* stream) {
+  if (!featmap || !xy || !feat || B <= 0 || N <= 0) return DISN_E_ARG;
+  DISN_TRY(gather_launch(featmap, xy, B, N, feat, (hipStream_t)stream));
+  return 0;
+}
+
+size_t disn_sdf_mlp_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return query_layout(nullptr, B, chunk_for(N), false, false).total;
+}
+
+int disn_sdf_mlp(const disn_mlp_weights_t* w, const float* pts_rot, const float* embedding,
+                 const float* feat, int B, int N, float* sdf, float* sdf_global, float* sdf_local,
+                 void* ws, size_t ws_bytes, void* stream) {
+  if (!mlp_weights_ok(w) || !pts_rot || !embedding || !feat || !sdf || !ws || B <= 0 || N <= 0)
+    return DISN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunk = chunk_for(N);
+  const QueryWs q = query_layout(ws, B, chunk, false, false);
+  if (q.total > ws_bytes) return DISN_E_WS;
+  DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
+                       q.gemv_ws, st));
+  for (int b = 0; b < B; ++b)
+    for (int n0 = 0; n0 < N; n0 += chunk) {
+      const int n = (N - n0) < chunk ? (N - n0) : chunk;
+      const size_t o = (size_t)b * N + n0;
+      const int rc = mlp_chunk(w, pts_rot + o * 3, n, q.gbias + (size_t)b * 512,
+                               feat + o * DISN_FEAT_DIM, sdf + o, sdf_global ? sdf_global + o : nullptr,
+                               sdf_local ? sdf_local + o : nullptr, 1.0f, q.mlp, st);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+size_t disn_query_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return query_layout(nullptr, B, chunk_for(N), true, false).total;
+}
+
+int disn_query(const disn_mlp_weights_t* w, const float* featmap, const float* embedding,
+               const float* trans_mat, const float* pts, const float* pts_rot, int B, int N,
+               float* sdf, void* ws, size_t ws_bytes, void* stream) {
+  if (!mlp_weights_ok(w) || !featmap || !embedding || !trans_mat || !pts || !pts_rot || !sdf ||
+      !ws || B <= 0 || N <= 0)
+    return DISN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunk = chunk_for(N);
+  const QueryWs q = query_layout(ws, B, chunk, true, false);
+  if (q.total > ws_bytes) return DISN_E_WS;
+  DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
+                       q.gemv_ws, st));
+  const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
+  for (int b = 0; b < B; ++b)
+    for (int n0 = 0; n0 < N; n0 += chunk) {
+      const int n = (N - n0) < chunk ? (N - n0) : chunk;
+      const size_t o = (size_t)b * N + n0;
+      DISN_TRY(project_gather_launch(featmap + b * map_stride, trans_mat + (size_t)b * 12,
+                                     pts + o * 3, n, q.feat, st));
+      const int rc = mlp_chunk(w, pts_rot + o * 3, n, q.gbias + (size_t)b * 512, q.feat, sdf + o,
+                               nullptr, nullptr, 1.0f, q.mlp, st);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+int disn_grid_points(const double* sdf_params_host, int R, int64_t k0, int64_t k1, float* pts,
+                     void* stream) {
+  GridSpec g;
+  if (!pts || !grid_spec(sdf_params_host, R, &g)) return DISN_E_ARG;
+  const int64_t total = (int64_t)g.res * g.res * g.res;
+  if (k0 < 0 || k1 > total || k0 >= k1) return DISN_E_ARG;
+  DISN_TRY(grid_points_launch(g, k0, k1, pts, (hipStream_t)stream));
+  return 0;
+}
+
+size_t disn_query_grid_workspace_bytes(int64_t max_points) {
+  if (max_points <= 0) return 0;
+  return query_layout(nullptr, 1, chunk_for(max_points), true, true).total;
+}
+
+int disn_query_grid(const disn_mlp_weights_t* w, const float* featmap, const float* embedding,
+                    const float* trans_mat, const double* sdf_params_host, int R, int64_t k0,
+                    int64_t k1, float sdf_weight, float* out, void* ws, size_t ws_bytes,
+                    void* stream) {
+  GridSpec g;
+  if (!mlp_weights_ok(w) || !featmap || !embedding || !trans_mat || !out || !ws ||
+      !grid_spec(sdf_params_host, R, &g))
+    return DISN_E_ARG;
+  const int64_t total = (int64_t)g.res * g.res * g.res;
+  if (k0 < 0 || k1 > total || k0 >= k1 || sdf_weight == 0.0f) return DISN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunk = chunk_for(k1 - k0);
+  const QueryWs q = query_layout(ws, 1, chunk, true, true);
+  if (q.total > ws_bytes) return DISN_E_WS;
+  DISN_TRY(gemv_launch(embedding, 1, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
+                       q.gemv_ws, st));
+  for (int64_t k = k0; k < k1; k += chunk) {
+    const int n = (int)((k1 - k) < chunk ? (k1 - k) : chunk);
+    DISN_TRY(grid_points_launch(g, k, k + n, q.pts, st));
+    DISN_TRY(project_gather_launch(featmap, trans_mat, q.pts, n, q.feat, st));
+    // sample_pc == sample_pc_rot on this caller (test/create_sdf.py:268-269)
+    const int rc = mlp_chunk(w, q.pts, n, q.gbias, q.feat, out + (k - k0), nullptr, nullptr,
+                             sdf_weight, q.mlp, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

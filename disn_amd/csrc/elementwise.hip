@@ -1,0 +1,314 @@
+// Element-wise / gather rows of the path.  THIS FILE IS COMPILED WITH
+// -ffp-contract=off: every multiply and add is rounded separately, in the
+// operation order of the oracle (oracle/disn_oracle.py), so these kernels are
+// bit-exact with it.  All of them are HBM/L2-bandwidth bound; the rules that
+// matter are coalescing (16 B per lane, channel-contiguous NHWC) and enough
+// workgroups to fill 256 CUs.
+//
+//   resize_bilinear  -- tf.image.resize_bilinear legacy  (models/model_normalization.py:72,171-183)
+//   project          -- get_img_points                   (models/model_normalization.py:241-251)
+//   gather           -- 5 x contrib.resampler + concat   (models/model_normalization.py:172-190)
+//   maxpool2x2       -- slim.max_pool2d                  (models/CNN/vgg.py:188-196)
+//   grid_points      -- linspace/meshgrid grid           (test/create_sdf.py:246-256)
+#include "kernels.hpp"
+
+namespace disn {
+
+#define DISN_FEAT 1472
+#define DISN_FEAT4 368
+#define DISN_IMG 137
+
+// ---------------------------------------------------------------------------
+// legacy bilinear resize
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, int B, int Hin,
+                                                     int Win, int C, float* __restrict__ out,
+                                                     int Hout, int Wout, int out_cstride,
+                                                     int out_coff, float sy, float sx) {
+  const int cv = C / VEC;
+  const size_t total = (size_t)B * Hout * Wout * cv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    size_t pidx = i / cv;
+    const int ox = (int)(pidx % Wout);
+    pidx /= Wout;
+    const int oy = (int)(pidx % Hout);
+    const int b = (int)(pidx / Hout);
+    const float fy = (float)oy * sy, fx = (float)ox * sx;
+    const int ylo = (int)floorf(fy), xlo = (int)floorf(fx);
+    const int yhi = min(ylo + 1, Hin - 1), xhi = min(xlo + 1, Win - 1);
+    const float yl = fy - (float)ylo, xl = fx - (float)xlo;
+    const float* base = in + (size_t)b * Hin * Win * C + c;
+    const float* ptl = base + ((size_t)ylo * Win + xlo) * C;
+    const float* ptr = base + ((size_t)ylo * Win + xhi) * C;
+    const float* pbl = base + ((size_t)yhi * Win + xlo) * C;
+    const float* pbr = base + ((size_t)yhi * Win + xhi) * C;
+    float* po = out + ((size_t)(b * Hout + oy) * Wout + ox) * out_cstride + out_coff + c;
+    if (VEC == 4) {
+      const float4 tl = *reinterpret_cast<const float4*>(ptl);
+      const float4 tr = *reinterpret_cast<const float4*>(ptr);
+      const float4 bl = *reinterpret_cast<const float4*>(pbl);
+      const float4 br = *reinterpret_cast<const float4*>(pbr);
+      float4 o;
+#define DISN_LERP(f)                              \
+  {                                               \
+    const float top = tl.f + (tr.f - tl.f) * xl;  \
+    const float bot = bl.f + (br.f - bl.f) * xl;  \
+    o.f = top + (bot - top) * yl;                 \
+  }
+      DISN_LERP(x) DISN_LERP(y) DISN_LERP(z) DISN_LERP(w)
+#undef DISN_LERP
+      *reinterpret_cast<float4*>(po) = o;
+    } else {
+      const float top = *ptl + (*ptr - *ptl) * xl;
+      const float bot = *pbl + (*pbr - *pbl) * xl;
+      *po = top + (bot - top) * yl;
+    }
+  }
+}
+
+static inline int grid_for(size_t total, int cap = 8192) {
+  size_t b = (total + 255) / 256;
+  if (b > (size_t)cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+hipError_t resize_bilinear_launch(const float* in, int B, int Hin, int Win, int C, float* out,
+                                  int Hout, int Wout, int out_cstride, int out_coff,
+                                  hipStream_t st) {
+  const float sy = (float)Hin / (float)Hout;  // CalculateResizeScale, float32 division
+  const float sx = (float)Win / (float)Wout;
+  const bool vec = (C % 4 == 0) && (out_cstride % 4 == 0) && (out_coff % 4 == 0);
+  if (vec) {
+    const size_t total = (size_t)B * Hout * Wout * (C / 4);
+    hipLaunchKernelGGL((resize_kernel<4>), dim3(grid_for(total)), dim3(256), 0, st, in, B, Hin, Win,
+                       C, out, Hout, Wout, out_cstride, out_coff, sy, sx);
+  } else {
+    const size_t total = (size_t)B * Hout * Wout * C;
+    hipLaunchKernelGGL((resize_kernel<1>), dim3(grid_for(total)), dim3(256), 0, st, in, B, Hin, Win,
+                       C, out, Hout, Wout, out_cstride, out_coff, sy, sx);
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// 2x2 stride-2 VALID max pool, NHWC, C % 4 == 0
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in, int B, int H,
+                                                      int W, int C, float* __restrict__ out) {
+  const int Ho = H / 2, Wo = W / 2, c4n = C / 4;
+  const size_t total = (size_t)B * Ho * Wo * c4n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    size_t pidx = i / c4n;
+    const int ox = (int)(pidx % Wo);
+    pidx /= Wo;
+    const int oy = (int)(pidx % Ho);
+    const int b = (int)(pidx / Ho);
+    const float* p = in + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b2 = *reinterpret_cast<const float4*>(p + C);
+    const float4 c2 = *reinterpret_cast<const float4*>(p + (size_t)W * C);
+    const float4 d = *reinterpret_cast<const float4*>(p + (size_t)W * C + C);
+    float4 o;
+    o.x = fmaxf(fmaxf(a.x, b2.x), fmaxf(c2.x, d.x));
+    o.y = fmaxf(fmaxf(a.y, b2.y), fmaxf(c2.y, d.y));
+    o.z = fmaxf(fmaxf(a.z, b2.z), fmaxf(c2.z, d.z));
+    o.w = fmaxf(fmaxf(a.w, b2.w), fmaxf(c2.w, d.w));
+    *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Wo + ox) * C + c) = o;
+  }
+}
+
+hipError_t maxpool2x2_launch(const float* in, int B, int H, int W, int C, float* out,
+                             hipStream_t st) {
+  const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, B, H, W, C, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// projection  ((x*T0 + y*T1) + z*T2) + T3 ; xy / z ; clamp [0,136], NaN propagates
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float clamp_px(float v) {
+  return (v != v) ? v : fminf(136.0f, fmaxf(0.0f, v));
+}
+
+__device__ __forceinline__ void project_point(const float* __restrict__ T, float x, float y,
+                                              float z, float& px, float& py) {
+  float p[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float a = x * T[0 * 3 + j] + y * T[1 * 3 + j];
+    a = a + z * T[2 * 3 + j];
+    p[j] = a + T[3 * 3 + j];
+  }
+  px = clamp_px(p[0] / p[2]);
+  py = clamp_px(p[1] / p[2]);
+}
+
+__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ pts,
+                                                      const float* __restrict__ trans_mat, int B,
+                                                      int N, float* __restrict__ xy) {
+  const size_t total = (size_t)B * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / N);
+    float px, py;
+    project_point(trans_mat + (size_t)b * 12, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], px, py);
+    xy[i * 2] = px;
+    xy[i * 2 + 1] = py;
+  }
+}
+
+hipError_t project_launch(const float* pts, const float* trans_mat, int B, int N, float* xy,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(project_kernel, dim3(grid_for((size_t)B * N)), dim3(256), 0, st, pts, trans_mat,
+                     B, N, xy);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// gather: one thread per (point, float4 of the 1472 channels).  Consecutive lanes read
+// consecutive 16-byte pieces of the same pixel (5888 contiguous bytes per tap pixel) and
+// write consecutive 16-byte pieces of the output row: every access is a full-line stream.
+// The two x-taps (fx, fx+1) of a row are adjacent pixels = 11776 contiguous bytes.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float4 sample4(const float* __restrict__ map, float x, float y, int c) {
+  // TF-1.10 resampler functor: zero outside, weights from the ceil corner.
+  const bool ok = x > -1.0f && y > -1.0f && x < (float)DISN_IMG && y < (float)DISN_IMG;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!ok) return o;
+  const float fx = floorf(x), fy = floorf(y);
+  const float cx = fx + 1.0f, cy = fy + 1.0f;
+  const float dx = cx - x, dy = cy - y;
+  const int ifx = (int)fx, ify = (int)fy, icx = (int)cx, icy = (int)cy;
+  const float w_ff = dx * dy;
+  const float w_cc = (1.0f - dx) * (1.0f - dy);
+  const float w_fc = dx * (1.0f - dy);
+  const float w_cf = (1.0f - dx) * dy;
+  const bool xf = ifx >= 0 && ifx < DISN_IMG, xc = icx >= 0 && icx < DISN_IMG;
+  const bool yf = ify >= 0 && ify < DISN_IMG, yc = icy >= 0 && icy < DISN_IMG;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 v_ff = (xf && yf) ? *reinterpret_cast<const float4*>(
+                                       map + ((size_t)ify * DISN_IMG + ifx) * DISN_FEAT + c)
+                                 : z4;
+  const float4 v_cc = (xc && yc) ? *reinterpret_cast<const float4*>(
+                                       map + ((size_t)icy * DISN_IMG + icx) * DISN_FEAT + c)
+                                 : z4;
+  const float4 v_fc = (xf && yc) ? *reinterpret_cast<const float4*>(
+                                       map + ((size_t)icy * DISN_IMG + ifx) * DISN_FEAT + c)
+                                 : z4;
+  const float4 v_cf = (xc && yf) ? *reinterpret_cast<const float4*>(
+                                       map + ((size_t)ify * DISN_IMG + icx) * DISN_FEAT + c)
+                                 : z4;
+#define DISN_ACC(f)             \
+  {                             \
+    float v = w_ff * v_ff.f;    \
+    v = v + w_cc * v_cc.f;      \
+    v = v + w_fc * v_fc.f;      \
+    v = v + w_cf * v_cf.f;      \
+    o.f = v;                    \
+  }
+  DISN_ACC(x) DISN_ACC(y) DISN_ACC(z) DISN_ACC(w)
+#undef DISN_ACC
+  return o;
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ featmap,
+                                                     const float* __restrict__ xy, int B, int N,
+                                                     float* __restrict__ feat) {
+  const size_t total = (size_t)B * N * DISN_FEAT4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pt = i / DISN_FEAT4;
+    const int c = (int)(i - pt * DISN_FEAT4) * 4;
+    const int b = (int)(pt / N);
+    const float x = xy[pt * 2], y = xy[pt * 2 + 1];
+    const float4 o = sample4(featmap + (size_t)b * DISN_IMG * DISN_IMG * DISN_FEAT, x, y, c);
+    *reinterpret_cast<float4*>(feat + pt * DISN_FEAT + c) = o;
+  }
+}
+
+hipError_t gather_launch(const float* featmap, const float* xy, int B, int N, float* feat,
+                         hipStream_t st) {
+  const size_t total = (size_t)B * N * DISN_FEAT4;
+  hipLaunchKernelGGL(gather_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, featmap, xy, B,
+                     N, feat);
+  return hipGetLastError();
+}
+
+// project + gather fused (the xy of a point is recomputed by each of its 368 threads:
+// 12 multiplies, cheaper than a round trip of xy through memory)
+__global__ __launch_bounds__(256) void project_gather_kernel(const float* __restrict__ featmap_b,
+                                                             const float* __restrict__ trans_mat_b,
+                                                             const float* __restrict__ pts, int n,
+                                                             float* __restrict__ feat) {
+  const size_t total = (size_t)n * DISN_FEAT4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pt = i / DISN_FEAT4;
+    const int c = (int)(i - pt * DISN_FEAT4) * 4;
+    float px, py;
+    project_point(trans_mat_b, pts[pt * 3], pts[pt * 3 + 1], pts[pt * 3 + 2], px, py);
+    const float4 o = sample4(featmap_b, px, py, c);
+    *reinterpret_cast<float4*>(feat + pt * DISN_FEAT + c) = o;
+  }
+}
+
+hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_b, const float* pts,
+                                 int n, float* feat, hipStream_t st) {
+  const size_t total = (size_t)n * DISN_FEAT4;
+  hipLaunchKernelGGL(project_gather_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st,
+                     featmap_b, trans_mat_b, pts, n, feat);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// dense grid points: numpy.linspace in float64 (i*step + start, last = stop), cast float32
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grid_points_kernel(GridSpec g, int64_t k0, int64_t k1,
+                                                          float* __restrict__ pts) {
+  const int64_t n = k1 - k0;
+  const int64_t res = g.res;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = k0 + i;
+    const int ix = (int)(k % res);
+    const int iy = (int)((k / res) % res);
+    const int iz = (int)(k / (res * res));
+    const int idx[3] = {ix, iy, iz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double v = (double)idx[a] * g.step[a];
+      v = v + g.start[a];
+      if (idx[a] == g.res - 1 && g.res > 1) v = g.stop[a];
+      pts[i * 3 + a] = (float)v;
+    }
+  }
+}
+
+hipError_t grid_points_launch(const GridSpec& g, int64_t k0, int64_t k1, float* pts,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(grid_points_kernel, dim3(grid_for((size_t)(k1 - k0))), dim3(256), 0, st, g, k0,
+                     k1, pts);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void scale_div_kernel(const float* __restrict__ in, float divisor,
+                                                        int64_t n, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = in[i] / divisor;
+}
+
+hipError_t scale_div_launch(const float* in, float divisor, int64_t n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(scale_div_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, in, divisor, n,
+                     out);
+  return hipGetLastError();
+}
+
+}  // namespace disn

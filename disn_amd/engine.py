@@ -1,0 +1,152 @@
+"""Device-resident engine for the SDF query path: packed weights + encoder/decoder split.
+
+The reference re-runs the whole graph (resize, VGG-16, five 137x137 up-samples) on every
+chunk ``sess.run`` (test/create_sdf.py:262-276) although it also defines -- and never calls --
+an encoder/decoder split (``get_decoder`` / ``placeholder_features``,
+models/model_normalization.py:38-45,223-238).  Here that split is the primary structure:
+``encode()`` runs rows A, B, C, E once per image, ``query*()`` run rows D, F, G, H per point.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import MLP_FIELDS, MlpWeights, VggWeights
+from .weights import MLP_SCOPES, VGG_CONV_NAMES, WeightStore
+
+
+class DeviceWeights:
+    """Uploads a WeightStore and re-packs the GEMM-shaped layers for the MFMA kernels."""
+
+    def __init__(self, store: WeightStore, device: torch.device):
+        if not store.complete():
+            raise ValueError("WeightStore is incomplete")
+        self.device = device
+        self.num_classes = store.num_classes
+        self._keep: List[torch.Tensor] = []
+        dev = lambda a: self._hold(torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device))
+
+        # ---- VGG-16 --------------------------------------------------------------------
+        v = VggWeights()
+        for i, nm in enumerate(VGG_CONV_NAMES):
+            w = store[nm + "/weights"]                     # [3,3,Cin,Cout] HWIO
+            kh, kw, ci, co = w.shape
+            packed = self._hold(ops.pack_kn(dev(w.reshape(kh * kw * ci, co))))
+            v.conv_w[i] = packed.data_ptr()
+            v.conv_b[i] = dev(store[nm + "/biases"]).data_ptr()
+        for i, nm in enumerate(("fc6", "fc7", "fc8")):
+            w = store["vgg_16/%s/weights" % nm]
+            v.fc_w[i] = dev(w.reshape(-1, w.shape[3])).data_ptr()   # [K][N], K=(h,w,c) = NHWC flatten
+            v.fc_b[i] = dev(store["vgg_16/%s/biases" % nm]).data_ptr()
+        v.num_classes = store.num_classes
+        self.vgg = v
+
+        # ---- point MLPs ------------------------------------------------------------------
+        m = MlpWeights()
+        g, l = MLP_SCOPES
+
+        def W(scope, layer):
+            return store["%s/%s/weights" % (scope, layer)][0, 0]   # [Cin,Cout]
+
+        def Bv(scope, layer):
+            return store["%s/%s/biases" % (scope, layer)]
+
+        def pk(a):
+            return self._hold(ops.pack_kn(dev(a))).data_ptr()
+
+        for pre, scope in (("g", g), ("l", l)):
+            setattr(m, pre + "_w1", dev(W(scope, "fold1/conv1")).data_ptr())       # [3,64] as is
+            setattr(m, pre + "_b1", dev(Bv(scope, "fold1/conv1")).data_ptr())
+            setattr(m, pre + "_w2", pk(W(scope, "fold1/conv2")))
+            setattr(m, pre + "_b2", dev(Bv(scope, "fold1/conv2")).data_ptr())
+            setattr(m, pre + "_w3", pk(W(scope, "fold1/conv3")))
+            setattr(m, pre + "_b3", dev(Bv(scope, "fold1/conv3")).data_ptr())
+            setattr(m, pre + "_b4", dev(Bv(scope, "fold2/conv1")).data_ptr())
+            setattr(m, pre + "_w5", pk(W(scope, "fold2/conv2")))
+            setattr(m, pre + "_b5", dev(Bv(scope, "fold2/conv2")).data_ptr())
+            setattr(m, pre + "_w6", dev(W(scope, "fold2/conv5").reshape(-1)).data_ptr())   # [256]
+            setattr(m, pre + "_b6", dev(Bv(scope, "fold2/conv5")).data_ptr())
+        w4g = W(g, "fold2/conv1")                          # [512+1024, 512]: rows 0-511 point, rest global
+        m.g_w4_point = pk(w4g[:512])
+        m.g_w4_global = dev(w4g[512:]).data_ptr()          # folded into a per-image bias by the library
+        m.l_w4 = pk(W(l, "fold2/conv1"))                   # [512+1472, 512]
+        for f in MLP_FIELDS:
+            assert getattr(m, f), f
+        self.mlp = m
+        torch.cuda.current_stream(device).synchronize()
+
+    def _hold(self, t: torch.Tensor) -> torch.Tensor:
+        self._keep.append(t)
+        return t
+
+
+@dataclass
+class Encoded:
+    """Per-image state produced once by the encoder."""
+    resized: torch.Tensor          # [B,224,224,3]   'resized_ref_img'
+    taps: List[torch.Tensor]       # conv1_2, conv2_2, conv3_3, conv4_3, conv5_3 (native resolution)
+    embedding: torch.Tensor        # [B,1024]        'img_embedding'
+    featmap: torch.Tensor          # [B,137,137,1472] the five resized taps, channel-concatenated
+
+
+class SdfEngine:
+    def __init__(self, store: WeightStore, device: Optional[torch.device] = None):
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if not torch.cuda.is_available():
+            raise RuntimeError("disn_amd needs a HIP device: the product path has no CPU fallback")
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            self.weights = DeviceWeights(store, self.device)
+        self._ws: Dict[str, torch.Tensor] = {}
+
+    def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def _dev(self, a) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    # rows A, B, C, E
+    def encode(self, imgs) -> Encoded:
+        imgs = self._dev(imgs)
+        with torch.cuda.device(self.device):
+            from ._lib import lib
+            ws = self._workspace("vgg", lib().disn_vgg16_workspace_bytes(imgs.shape[0]))
+            resized, taps, emb = ops.vgg16_forward(self.weights.vgg, imgs, ws)
+            featmap = ops.build_featmap(taps)
+        return Encoded(resized, taps, emb, featmap)
+
+    # rows D, F, G, H
+    def query(self, enc: Encoded, pts, trans_mat, pts_rot=None) -> torch.Tensor:
+        """pts [B,N,3] -> pred_sdf [B,N] (un-divided, as models/model_normalization.py:204)."""
+        pts = self._dev(pts)
+        pts_rot = pts if pts_rot is None else self._dev(pts_rot)
+        trans_mat = self._dev(trans_mat)
+        with torch.cuda.device(self.device):
+            from ._lib import lib
+            ws = self._workspace("query", lib().disn_query_workspace_bytes(pts.shape[0], pts.shape[1]))
+            return ops.query(self.weights.mlp, enc.featmap, enc.embedding, trans_mat, pts, pts_rot, ws)
+
+    def query_grid(self, enc: Encoded, image_index: int, trans_mat, sdf_params, res: int,
+                   k0: int = 0, k1: Optional[int] = None, sdf_weight: float = 10.0,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """rows J + D..H + '/SDF_WEIGHT' for grid points k0..k1-1 of one image."""
+        total = (res + 1) ** 3
+        k1 = total if k1 is None else k1
+        tm = self._dev(trans_mat).reshape(-1, 4, 3)
+        tm = tm[image_index if tm.shape[0] > 1 else 0]
+        with torch.cuda.device(self.device):
+            from ._lib import lib
+            ws = self._workspace("grid", lib().disn_query_grid_workspace_bytes(k1 - k0))
+            return ops.query_grid(self.weights.mlp, enc.featmap[image_index], enc.embedding[image_index:image_index + 1],
+                                  tm.contiguous(), sdf_params, res, k0, k1, sdf_weight, ws, out)

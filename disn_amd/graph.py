@@ -1,0 +1,149 @@
+"""A minimal TF1-idiom shim: symbolic tensors, placeholders, ``Session.run(fetches, feed_dict)``.
+
+The reference drives the path through graph-mode TensorFlow: the scripts build the graph
+once with ``model.placeholder_inputs`` / ``model.get_model`` and then loop
+``sess.run(fetches, feed_dict)`` with numpy in / numpy out (test/create_sdf.py:262-276,
+train/train_sdf.py:371-387).  This module provides exactly that calling convention on top
+of the HIP engine so those loops run unchanged; it is host glue, not a tracing compiler:
+each symbolic tensor names one engine call, evaluated on demand with per-run memoisation.
+"""
+from __future__ import annotations
+
+import contextlib
+import hashlib
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_SCOPE: List[str] = []
+
+
+@contextlib.contextmanager
+def variable_scope(name: str):
+    """tf.variable_scope stand-in: only tracks the name prefix used to pick weights."""
+    _SCOPE.append(name)
+    try:
+        yield "/".join(s for s in _SCOPE if s)
+    finally:
+        _SCOPE.pop()
+
+
+def current_scope() -> str:
+    return "/".join(s for s in _SCOPE if s)
+
+
+class SymTensor:
+    """A node: ``fn(session, *evaluated_inputs) -> device tensor / python object``."""
+    _count = 0
+
+    def __init__(self, name: str, shape: Tuple[Optional[int], ...], fn: Optional[Callable] = None,
+                 inputs: Sequence["SymTensor"] = ()):
+        SymTensor._count += 1
+        self.name = "%s:%d" % (name, SymTensor._count)
+        self.shape = tuple(shape)
+        self.fn = fn
+        self.inputs = tuple(inputs)
+
+    def get_shape(self):
+        return self.shape
+
+    def __add__(self, other: "SymTensor") -> "SymTensor":
+        return SymTensor("add", self.shape, lambda sess, a, b: a + b, (self, other))
+
+    def __repr__(self):
+        return "<SymTensor %s %s>" % (self.name, self.shape)
+
+
+class Placeholder(SymTensor):
+    def __init__(self, name: str, shape, dtype=np.float32):
+        super().__init__(name, shape)
+        self.dtype = dtype
+
+
+def placeholder(dtype, shape=(), name: str = "Placeholder") -> Placeholder:
+    return Placeholder(name, tuple(shape), dtype)
+
+
+class Session:
+    """``sess.run(fetches, feed_dict)``.  Holds the device engine (packed weights).
+
+    ``cache_encoder`` (default True): the encoder state of a fed image batch is kept and
+    re-used while the same image bytes are fed again -- the encoder/decoder split the
+    reference defines but never uses (models/model_normalization.py:38-45,223-238).  Set it to
+    False to re-run VGG on every ``run`` exactly as the reference does.
+    """
+
+    def __init__(self, weights=None, device=None, cache_encoder: bool = True, seed: int = 0):
+        from .engine import SdfEngine
+        from .weights import WeightStore
+        if weights is None:
+            # what the reference runs on when no checkpoint restores (test/create_sdf.py:184-192);
+            # explicit here rather than a swallowed exception
+            weights = WeightStore.random_init(seed)
+        self.weights = weights
+        self.engine = SdfEngine(weights, device)
+        self.cache_encoder = cache_encoder
+        self._enc_key: Optional[bytes] = None
+        self._enc_val = None
+
+    # -- encoder cache ---------------------------------------------------------------------
+    def encoded(self, imgs_np: np.ndarray):
+        key = hashlib.blake2b(np.ascontiguousarray(imgs_np).view(np.uint8), digest_size=16).digest()
+        if self.cache_encoder and key == self._enc_key:
+            return self._enc_val
+        enc = self.engine.encode(imgs_np)
+        if self.cache_encoder:
+            self._enc_key, self._enc_val = key, enc
+        return enc
+
+    # -- evaluation --------------------------------------------------------------------------
+    def _eval(self, t: Any, feed: Dict[SymTensor, Any], memo: Dict[SymTensor, Any]):
+        if not isinstance(t, SymTensor):
+            return t
+        if t in memo:
+            return memo[t]
+        if isinstance(t, Placeholder):
+            if t not in feed:
+                raise KeyError("placeholder %s was not fed" % t.name)
+            v = feed[t]
+            if t.dtype in (np.float32, "float32"):
+                v = np.ascontiguousarray(v, dtype=np.float32)
+                want = t.shape
+                if len(want) == v.ndim and any(w is not None and w != s for w, s in zip(want, v.shape)):
+                    raise ValueError("feed for %s has shape %s, placeholder is %s" % (t.name, v.shape, want))
+        else:
+            if t.fn is None:
+                raise ValueError("%s has no value" % t.name)
+            v = t.fn(self, *[self._eval(i, feed, memo) for i in t.inputs])
+        memo[t] = v
+        return v
+
+    def run(self, fetches, feed_dict: Optional[Dict[SymTensor, Any]] = None):
+        import torch
+        feed = dict(feed_dict or {})
+        memo: Dict[SymTensor, Any] = {}
+        single = not isinstance(fetches, (list, tuple))
+        outs = []
+        for f in ([fetches] if single else fetches):
+            if isinstance(f, dict):
+                outs.append({k: self._to_numpy(self._eval(v, feed, memo)) for k, v in f.items()})
+            else:
+                outs.append(self._to_numpy(self._eval(f, feed, memo)))
+        torch.cuda.synchronize(self.engine.device)
+        return outs[0] if single else outs
+
+    @staticmethod
+    def _to_numpy(v):
+        import torch
+        if isinstance(v, torch.Tensor):
+            return v.detach().cpu().numpy()
+        return v
+
+    def close(self):
+        self._enc_key = self._enc_val = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -1,0 +1,223 @@
+"""Thin torch-tensor wrappers over the C ABI (include/disn_amd.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every
+computation is a hand-written HIP kernel behind ``libdisn_amd.so``.  All
+tensors are float32, contiguous, on a CUDA(=HIP) device; kernels are enqueued
+on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import MlpWeights, VggWeights, check, lib
+
+FEAT_DIM = 1472
+IMG = 137
+TAP_SHAPES = ((224, 64), (112, 128), (56, 256), (28, 512), (14, 512))
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise TypeError("%s must be a float32 CUDA tensor (the HIP path has no CPU fallback)" % name)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def pack_kn(w_kn: torch.Tensor, kpad: Optional[int] = None) -> torch.Tensor:
+    """[K,N] -> MFMA B-fragment order (disn_pack_kn)."""
+    w_kn = _chk(w_kn, "w_kn")
+    K, N = w_kn.shape
+    kpad = kpad or ((K + 31) // 32) * 32
+    out = torch.empty(kpad * N, dtype=torch.float32, device=w_kn.device)
+    check("disn_pack_kn", lib().disn_pack_kn(w_kn.data_ptr(), K, N, kpad, out.data_ptr(), _stream()))
+    return out
+
+
+def resize_bilinear(x: torch.Tensor, out_h: int, out_w: int, out: Optional[torch.Tensor] = None,
+                    out_coff: int = 0) -> torch.Tensor:
+    """tf.image.resize_bilinear (legacy) on NHWC."""
+    x = _chk(x, "x")
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((B, out_h, out_w, Cc), dtype=torch.float32, device=x.device)
+    cstride = out.shape[-1]
+    check("disn_resize_bilinear", lib().disn_resize_bilinear(
+        x.data_ptr(), B, H, W, Cc, out.data_ptr(), out_h, out_w, cstride, out_coff, _stream()))
+    return out
+
+
+def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool = True
+            ) -> torch.Tensor:
+    x = _chk(x, "x")
+    B, H, W, Cin = x.shape
+    out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    nb = lib().disn_conv3x3_workspace_bytes(B, H, W, Cin, cout)
+    ws = _ws(nb, x.device)
+    check("disn_conv3x3", lib().disn_conv3x3(x.data_ptr(), B, H, W, Cin, w_packed.data_ptr(),
+                                             bias.data_ptr(), cout, int(relu), out.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def maxpool2x2(x: torch.Tensor) -> torch.Tensor:
+    x = _chk(x, "x")
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, H // 2, W // 2, Cc), dtype=torch.float32, device=x.device)
+    check("disn_maxpool2x2", lib().disn_maxpool2x2(x.data_ptr(), B, H, W, Cc, out.data_ptr(), _stream()))
+    return out
+
+
+def fc(x: torch.Tensor, w_kn: torch.Tensor, bias: torch.Tensor, relu: bool) -> torch.Tensor:
+    x = _chk(x, "x")
+    B, K = x.shape
+    N = w_kn.shape[-1]
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().disn_fc_workspace_bytes(B, K, N), x.device)
+    check("disn_fc", lib().disn_fc(x.data_ptr(), B, K, w_kn.data_ptr(), bias.data_ptr(), N, int(relu),
+                                   out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def dense(a1: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, n_out: int, relu: bool = True,
+          a2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act([a1 | a2] @ W + b): the tf_util.conv2d [1,1] primitive on [M,K] rows."""
+    a1 = _chk(a1, "a1")
+    M, k1 = a1.shape
+    k2 = 0
+    if a2 is not None:
+        a2 = _chk(a2, "a2")
+        k2 = a2.shape[1]
+    out = torch.empty((M, n_out), dtype=torch.float32, device=a1.device)
+    ws = _ws(lib().disn_dense_workspace_bytes(M, k1 + k2, n_out), a1.device)
+    check("disn_dense", lib().disn_dense(
+        a1.data_ptr(), a1.stride(0), k1, a2.data_ptr() if a2 is not None else None,
+        a2.stride(0) if a2 is not None else 0, k2, M, w_packed.data_ptr(), bias.data_ptr(), n_out,
+        int(relu), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def vgg16_forward(w: VggWeights, img: torch.Tensor, ws: Optional[torch.Tensor] = None
+                  ) -> Tuple[torch.Tensor, List[torch.Tensor], torch.Tensor]:
+    """-> (resized224 [B,224,224,3], taps[5], embedding [B,num_classes])."""
+    img = _chk(img, "img")
+    B = img.shape[0]
+    if tuple(img.shape[1:]) != (IMG, IMG, 3):
+        raise ValueError("img must be [B,137,137,3] (models/model_normalization.py:249-250 hard-codes 137)")
+    dev = img.device
+    resized = torch.empty((B, 224, 224, 3), dtype=torch.float32, device=dev)
+    taps = [torch.empty((B, hw, hw, ch), dtype=torch.float32, device=dev) for hw, ch in TAP_SHAPES]
+    emb = torch.empty((B, w.num_classes), dtype=torch.float32, device=dev)
+    need = lib().disn_vgg16_workspace_bytes(B)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, dev)
+    tp = (C.c_void_p * 5)(*[t.data_ptr() for t in taps])
+    check("disn_vgg16_forward", lib().disn_vgg16_forward(
+        C.byref(w), img.data_ptr(), B, resized.data_ptr(), C.byref(tp), emb.data_ptr(), ws.data_ptr(),
+        ws.numel(), _stream()))
+    return resized, taps, emb
+
+
+def build_featmap(taps: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B = taps[0].shape[0]
+    if out is None:
+        out = torch.empty((B, IMG, IMG, FEAT_DIM), dtype=torch.float32, device=taps[0].device)
+    tp = (C.c_void_p * 5)(*[_chk(t, "tap").data_ptr() for t in taps])
+    check("disn_build_featmap", lib().disn_build_featmap(C.byref(tp), B, out.data_ptr(), _stream()))
+    return out
+
+
+def project(pts: torch.Tensor, trans_mat: torch.Tensor) -> torch.Tensor:
+    pts, trans_mat = _chk(pts, "pts"), _chk(trans_mat, "trans_mat")
+    B, N, _ = pts.shape
+    xy = torch.empty((B, N, 2), dtype=torch.float32, device=pts.device)
+    check("disn_project", lib().disn_project(pts.data_ptr(), trans_mat.data_ptr(), B, N, xy.data_ptr(),
+                                             _stream()))
+    return xy
+
+
+def gather(featmap: torch.Tensor, xy: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    featmap, xy = _chk(featmap, "featmap"), _chk(xy, "xy")
+    B, N, _ = xy.shape
+    if out is None:
+        out = torch.empty((B, N, FEAT_DIM), dtype=torch.float32, device=xy.device)
+    check("disn_gather", lib().disn_gather(featmap.data_ptr(), xy.data_ptr(), B, N, out.data_ptr(),
+                                           _stream()))
+    return out
+
+
+def sdf_mlp(w: MlpWeights, pts_rot: torch.Tensor, embedding: torch.Tensor, feat: torch.Tensor,
+            want_streams: bool = False):
+    pts_rot, embedding, feat = _chk(pts_rot, "pts_rot"), _chk(embedding, "embedding"), _chk(feat, "feat")
+    B, N, _ = pts_rot.shape
+    dev = pts_rot.device
+    sdf = torch.empty((B, N), dtype=torch.float32, device=dev)
+    g = torch.empty((B, N), dtype=torch.float32, device=dev) if want_streams else None
+    l = torch.empty((B, N), dtype=torch.float32, device=dev) if want_streams else None
+    ws = _ws(lib().disn_sdf_mlp_workspace_bytes(B, N), dev)
+    check("disn_sdf_mlp", lib().disn_sdf_mlp(
+        C.byref(w), pts_rot.data_ptr(), embedding.data_ptr(), feat.data_ptr(), B, N, sdf.data_ptr(),
+        g.data_ptr() if want_streams else None, l.data_ptr() if want_streams else None, ws.data_ptr(),
+        ws.numel(), _stream()))
+    return (sdf, g, l) if want_streams else sdf
+
+
+def query(w: MlpWeights, featmap: torch.Tensor, embedding: torch.Tensor, trans_mat: torch.Tensor,
+          pts: torch.Tensor, pts_rot: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    pts = _chk(pts, "pts")
+    pts_rot = pts if pts_rot is None else _chk(pts_rot, "pts_rot")
+    B, N, _ = pts.shape
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=pts.device)
+    need = lib().disn_query_workspace_bytes(B, N)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, pts.device)
+    check("disn_query", lib().disn_query(
+        C.byref(w), _chk(featmap, "featmap").data_ptr(), _chk(embedding, "embedding").data_ptr(),
+        _chk(trans_mat, "trans_mat").data_ptr(), pts.data_ptr(), pts_rot.data_ptr(), B, N,
+        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def _params6(sdf_params) -> C.Array:
+    vals = [float(v) for v in sdf_params]
+    if len(vals) != 6:
+        raise ValueError("sdf_params must have 6 entries")
+    return (C.c_double * 6)(*vals)
+
+
+def grid_points(sdf_params, res: int, k0: int, k1: int, device) -> torch.Tensor:
+    pts = torch.empty((k1 - k0, 3), dtype=torch.float32, device=device)
+    p6 = _params6(sdf_params)
+    with torch.cuda.device(pts.device):
+        check("disn_grid_points", lib().disn_grid_points(C.byref(p6), res, k0, k1, pts.data_ptr(), _stream()))
+    return pts
+
+
+def query_grid(w: MlpWeights, featmap: torch.Tensor, embedding: torch.Tensor, trans_mat: torch.Tensor,
+               sdf_params, res: int, k0: int, k1: int, sdf_weight: float = 10.0,
+               ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """SDF of grid points k0..k1-1 of ONE image (featmap [137,137,1472] or [1,...])."""
+    dev = featmap.device
+    if out is None:
+        out = torch.empty((k1 - k0,), dtype=torch.float32, device=dev)
+    need = lib().disn_query_grid_workspace_bytes(k1 - k0)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, dev)
+    p6 = _params6(sdf_params)
+    check("disn_query_grid", lib().disn_query_grid(
+        C.byref(w), _chk(featmap, "featmap").data_ptr(), _chk(embedding, "embedding").data_ptr(),
+        _chk(trans_mat, "trans_mat").data_ptr(), C.byref(p6), res, k0, k1, float(sdf_weight),
+        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return out

@@ -1,0 +1,188 @@
+/*
+ * disn_amd.h -- C ABI of the MI355X (gfx950) DISN SDF-query hot path.
+ *
+ * The reference (laughtervv/DISN) has NO C/FFI boundary on this path: the
+ * boundary is the Python module API of models/model_normalization.py /
+ * models/sdfnet.py executed by TensorFlow.  This header is therefore the
+ * boundary a binding for that module API would use; each entry point cites the
+ * reference graph fragment (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - all tensors are float32, row-major, NHWC; sizes are plain ints;
+ *   - the caller owns every buffer (the library never allocates); scratch is
+ *     sized by the *_workspace_bytes() queries and passed in;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return value: 0 ok; <0 invalid argument (DISN_E_*); >0 a hipError_t.
+ *     Nothing throws or aborts.  Entry points are re-entrant per stream and keep
+ *     no global mutable state.
+ */
+#ifndef DISN_AMD_H
+#define DISN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DISN_IMG_H 137
+#define DISN_IMG_W 137
+#define DISN_VGG_SIZE 224
+#define DISN_FEAT_DIM 1472 /* 64+128+256+512+512, models/model_normalization.py:41 */
+#define DISN_EMBED_DIM 1024
+
+#define DISN_E_ARG (-1)   /* null pointer / non-positive size */
+#define DISN_E_SHAPE (-2) /* unsupported shape (channel multiple, image size ...) */
+#define DISN_E_WS (-3)    /* workspace too small */
+
+/* ABI version of this header; disn_abi_version() returns the library's. */
+#define DISN_ABI_VERSION 1
+int disn_abi_version(void);
+
+/* ---------------------------------------------------------------------- *
+ * Weight packing.  GEMM-shaped layers read their [K][N] weight matrix      *
+ * (TF HWIO flattened: K = kh*kw*Cin, N = Cout) in MFMA B-fragment order:   *
+ * packed[((k/8)*(N/32) + n/32)*256 + lane*4 + t] =                         *
+ *     W[8*(k/8) + 4*(lane>>5) + t][32*(n/32) + (lane&31)].                 *
+ * K is zero-padded up to Kpad (multiple of 32); N must be a multiple of 32.*
+ * `packed` holds Kpad*N floats.                                            *
+ * ---------------------------------------------------------------------- */
+int disn_pack_kn(const float* w_kn, int K, int N, int Kpad, float* packed, void* stream);
+
+/* ---------------------------------------------------------------------- *
+ * Row A / E: tf.image.resize_bilinear, TF1 legacy (align_corners=False,    *
+ * no half-pixel) -- models/model_normalization.py:72 and :171-183.         *
+ * Writes channels [out_coff, out_coff+C) of an output whose pixel stride is*
+ * out_cstride floats (out_cstride==C, out_coff==0 for a plain resize).     *
+ * Bit-exact with the oracle (FMA contraction off).                         *
+ * ---------------------------------------------------------------------- */
+int disn_resize_bilinear(const float* in, int B, int Hin, int Win, int C, float* out, int Hout,
+                         int Wout, int out_cstride, int out_coff, void* stream);
+
+/* ---------------------------------------------------------------------- *
+ * Rows B + C: slim vgg_16(num_classes, is_training=False,                  *
+ * spatial_squeeze=False) -- call models/model_normalization.py:74-78,      *
+ * architecture models/CNN/vgg.py:187-214.                                  *
+ * conv_w[i]: disn_pack_kn of 'vgg_16/convX/convX_Y/weights' ([3,3,Cin,Cout]*
+ *   -> K=9*Cin; conv1_1 K=27 padded to 32).  fc_w[i]: the TF tensor as is  *
+ *   ([7,7,512,4096], [1,1,4096,4096], [1,1,4096,num_classes]) = [K][N].    *
+ * ---------------------------------------------------------------------- */
+typedef struct disn_vgg_weights {
+  const float* conv_w[13]; /* packed, order conv1_1 .. conv5_3 */
+  const float* conv_b[13];
+  const float* fc_w[3]; /* fc6, fc7, fc8 : [K][N] row-major */
+  const float* fc_b[3];
+  int num_classes; /* 1024 on this path */
+} disn_vgg_weights_t;
+
+size_t disn_vgg16_workspace_bytes(int B);
+
+/* img: [B,137,137,3] BGR in [0,1] (demo/demo.py:263-264).  Outputs:
+ * resized224 [B,224,224,3] ('resized_ref_img'); taps[0..4] = conv1_2
+ * [B,224,224,64], conv2_2 [B,112,112,128], conv3_3 [B,56,56,256], conv4_3
+ * [B,28,28,512], conv5_3 [B,14,14,512]; embedding [B,num_classes]. */
+int disn_vgg16_forward(const disn_vgg_weights_t* w, const float* img, int B, float* resized224,
+                       float* const taps[5], float* embedding, void* ws, size_t ws_bytes,
+                       void* stream);
+
+/* Single layers of the above (unit-test / composition surface).
+ * disn_conv3x3: SAME 3x3 stride-1 conv + bias + optional ReLU, NHWC, Cin in {3} or a
+ *   multiple of 32, Cout a multiple of 64; ws >= disn_conv3x3_workspace_bytes. */
+size_t disn_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int disn_conv3x3(const float* in, int B, int H, int W, int Cin, const float* w_packed,
+                 const float* bias, int Cout, int relu, float* out, void* ws, size_t ws_bytes,
+                 void* stream);
+int disn_maxpool2x2(const float* in, int B, int H, int W, int C, float* out, void* stream);
+/* out[b][n] = act(sum_k x[b][k] W[k][n] + bias[n]); ws >= disn_fc_workspace_bytes */
+size_t disn_fc_workspace_bytes(int B, int K, int N);
+int disn_fc(const float* x, int B, int K, const float* w_kn, const float* bias, int N, int relu,
+            float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* Row G3: tf_util.conv2d with a [1,1] kernel (utils/tf_util.py:119-184) == per-row
+ * out[m][n] = act(sum_k A[m][k] W[k][n] + bias[n]) where A = [a1 (k1 cols) | a2 (k2 cols)]
+ * (the tf.concat(axis=3) of models/sdfnet.py:82,180 is read in place, never materialised).
+ * k1, k2 multiples of 32 (k2 may be 0 with a2 NULL), N a multiple of 64,
+ * w_packed = disn_pack_kn of W [k1+k2][N].  fp32 MFMA. */
+size_t disn_dense_workspace_bytes(int M, int K, int N);
+int disn_dense(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, int M,
+               const float* w_packed, const float* bias, int N, int relu, float* out, void* ws,
+               size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------- *
+ * Row E: the five resize_bilinear(tap,(137,137)) of                        *
+ * models/model_normalization.py:171-183, written channel-concatenated (in  *
+ * the reference's concat order, :187-189) into one map                     *
+ * featmap [B,137,137,1472] so that one pixel is 5888 contiguous bytes.     *
+ * ---------------------------------------------------------------------- */
+int disn_build_featmap(const float* const taps[5], int B, float* featmap, void* stream);
+
+/* Row D: get_img_points -- models/model_normalization.py:241-251.
+ * pts [B,N,3], trans_mat [B,4,3] -> xy [B,N,2], clamped to [0,136]. */
+int disn_project(const float* pts, const float* trans_mat, int B, int N, float* xy, void* stream);
+
+/* Row F: 5 x tf.contrib.resampler.resampler + concat --
+ * models/model_normalization.py:172-190.  featmap [B,137,137,1472],
+ * xy [B,N,2] -> feat [B,N,1472] ('point_img_feat').  Bit-exact with the oracle. */
+int disn_gather(const float* featmap, const float* xy, int B, int N, float* feat, void* stream);
+
+/* ---------------------------------------------------------------------- *
+ * Rows G + H: the two point MLPs and their sum --                          *
+ * models/sdfnet.py:69-92 (scope 'sdfprediction'), :171-190 (scope          *
+ * 'sdfprediction_imgfeat'), sum models/model_normalization.py:204.         *
+ * g_* = global stream, l_* = local stream.  w2,w3,w5 and l_w4 are          *
+ * disn_pack_kn of fold1/conv2, fold1/conv3, fold2/conv2 and the local      *
+ * fold2/conv1 [1984][512].  g_w4_point = disn_pack_kn of rows 0..511 of the*
+ * global fold2/conv1 [1536][512]; g_w4_global = its rows 512..1535 as is   *
+ * ([1024][512] row-major): that block multiplies a per-image constant and  *
+ * is folded into a per-image bias (changes summation order only).          *
+ * w1 [3][64], w6 [256] are the TF tensors as is.                           *
+ * ---------------------------------------------------------------------- */
+typedef struct disn_mlp_weights {
+  const float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3;
+  const float *g_w4_point, *g_w4_global, *g_b4, *g_w5, *g_b5, *g_w6, *g_b6;
+  const float *l_w1, *l_b1, *l_w2, *l_b2, *l_w3, *l_b3;
+  const float *l_w4, *l_b4, *l_w5, *l_b5, *l_w6, *l_b6;
+} disn_mlp_weights_t;
+
+/* scratch for one launch over B images x N points (N per image) */
+size_t disn_sdf_mlp_workspace_bytes(int B, int N);
+
+/* pts_rot [B,N,3] ('sample_pc_rot'), embedding [B,1024], feat [B,N,1472]
+ * -> sdf [B,N] = global + local; sdf_global / sdf_local optional (NULL ok). */
+int disn_sdf_mlp(const disn_mlp_weights_t* w, const float* pts_rot, const float* embedding,
+                 const float* feat, int B, int N, float* sdf, float* sdf_global, float* sdf_local,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* Rows D..H in one call: project pts, gather from featmap, run both MLPs.
+ * Same result as disn_project + disn_gather + disn_sdf_mlp; the 1472-wide
+ * feature only ever exists chunk-wise inside `ws`.
+ * pts [B,N,3] is projected; pts_rot [B,N,3] feeds the MLPs (may alias pts). */
+size_t disn_query_workspace_bytes(int B, int N);
+int disn_query(const disn_mlp_weights_t* w, const float* featmap, const float* embedding,
+               const float* trans_mat, const float* pts, const float* pts_rot, int B, int N,
+               float* sdf, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------- *
+ * Row J: dense grid -- test/create_sdf.py:246-256.  Flat index             *
+ * k=(iz*(R+1)+iy)*(R+1)+ix -> (x_[ix], y_[iy], z_[iz]) with                *
+ * x_=linspace(p0,p3,R+1) etc. evaluated in float64 then cast to float32    *
+ * (bit-exact with numpy).  Writes points k0..k1-1 to pts [(k1-k0),3].      *
+ * ---------------------------------------------------------------------- */
+int disn_grid_points(const double* sdf_params_host, int R, int64_t k0, int64_t k1, float* pts,
+                     void* stream);
+
+/* Row J + D..H + the host '/ SDF_WEIGHT' (test/create_sdf.py:285): SDF of
+ * grid points k0..k1-1 of ONE image, out[k-k0] = pred_sdf / sdf_weight
+ * (IEEE float32 division; pass 1.0f for the un-divided value). */
+size_t disn_query_grid_workspace_bytes(int64_t max_points);
+int disn_query_grid(const disn_mlp_weights_t* w, const float* featmap, const float* embedding,
+                    const float* trans_mat, const double* sdf_params_host, int R, int64_t k0,
+                    int64_t k1, float sdf_weight, float* out, void* ws, size_t ws_bytes,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISN_AMD_H */
