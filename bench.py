@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Benchmark of the DISN SDF-query hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): SDF point queries / s on a 137x137 image with a 2048-point batch.
+One STEP = one pass of the whole hot path over one batch of synthetic input, nothing cached:
+resize 137->224, VGG-16, five tap up-samples, projection, gather, both point MLPs and their sum
+for 2048 random query points (BASELINE config 2: "1xMI355X: VGG-16 encode + 2048 random query
+points, img_feat_twostream, fp32, random-init weights").  Inputs are resident in HBM before the
+timed region.  With N>1 every rank runs the same per-GPU workload on its own image / points
+(replicas: the 2048-point step has no exchange step), value = N*2048*K / max-over-ranks time.
+
+Besides the contract line's fields the JSON carries
+  roofline      -- the dominant kernel family (implicit-GEMM 3x3 conv, fp32 MFMA): algorithmic
+                   FLOP of the 13 conv launches of one step / their summed duration measured with
+                   events on the launch stream, against the 157.3 TFLOP/s fp32-MFMA peak;
+  roofline_gather / roofline_mlp -- the same for the gather (HBM-bound, 29 440 B/point) and the
+                   point MLP (fp32 MFMA, 3.67 MFLOP/point with the global block folded);
+  query_only    -- encoder amortised (the >=1e7 pts/s target of north_star applies here);
+  grid256       -- wall-clock of a full 257^3 dense-grid evaluation on this GPU (config 3, no MC);
+  cpu_baseline  -- the oracle (numpy/torch-CPU restatement of the reference's algorithm as
+                   written) timed on this box's host cores on the same workload (rank 0, N=1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+GATHER_BYTES_PER_PT = 29440        # 4 taps x 1472 ch x 4 B read + 1472 x 4 B write
+MLP_FLOP_PER_PT = 2 * 1835904      # 3.67 MFLOP/pt, global 1024x512 block folded per image
+VGG_LAYERS = [(3, 64, 224), (64, 64, 224), (64, 128, 112), (128, 128, 112), (128, 256, 56), (256, 256, 56),
+              (256, 256, 56), (256, 512, 28), (512, 512, 28), (512, 512, 28), (512, 512, 14), (512, 512, 14),
+              (512, 512, 14)]
+N_POINTS = 2048
+
+
+def ev_time_ms(fn, reps, torch):
+    """average duration of fn() in ms, events recorded on the stream the kernels run on"""
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / grid / cpu legs")
+    ap.add_argument("--cpu-runs", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; reporting n_gpus=%d" % (args.gpus, world, world), file=sys.stderr)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from disn_amd import ops
+    from disn_amd.engine import SdfEngine
+    from disn_amd.weights import WeightStore
+
+    store = WeightStore.random_init(0, mode="xavier")          # "random-init weights" (create_sdf.py:184-192)
+    eng = SdfEngine(store, dev)
+    rng = np.random.default_rng(1000 + rank)
+    img = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32)).to(dev)
+    pts = torch.from_numpy((rng.random((1, N_POINTS, 3), dtype=np.float32) * 2 - 1).astype(np.float32)).to(dev)
+    tm = torch.tensor([[[-68.453156, 5.5086656, -0.37556022], [-17.138561, -84.685486, -0.250198],
+                        [-47.284092, -3.6569588, 0.2493176], [101.133705, 101.34268, 1.4305686]]],
+                      dtype=torch.float32, device=dev)       # demo/demo.py:272-276
+
+    def step():
+        enc = eng.encode(img)                                  # rows A, B, C, E -- every step
+        return eng.query(enc, pts, tm)                         # rows D, F, G, H
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(out).all())
+    value = world * N_POINTS * args.steps / dt
+    line = {
+        "metric": "SDF point queries/sec (137x137 img, 2048-pt batch, VGG-16 encode + two-stream query per batch)",
+        "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: VGG-16 encode + 2048 random query points, img_feat_twostream, "
+                               "fp32, random-init (xavier) weights, nothing cached between steps",
+                   "images_per_step_per_gpu": 1, "points_per_step_per_gpu": N_POINTS,
+                   "parallelism": "replicas x%d (no data-path collective)" % world},
+    }
+
+    if rank == 0 and not args.no_extras:
+        # ---- roofline of the dominant kernel family: the 13 implicit-GEMM conv launches ----------
+        layers, tot_ms, tot_flop = [], 0.0, 0.0
+        for cin, cout, hw in VGG_LAYERS:
+            x = torch.rand((1, hw, hw, cin), device=dev)
+            w = ops.pack_kn(torch.randn((9 * cin, cout), device=dev) * (2.0 / (9 * cin)) ** 0.5)
+            b = torch.zeros(cout, device=dev)
+            ms = ev_time_ms(lambda: ops.conv3x3(x, w, b, cout, True), 20, torch)
+            fl = 2.0 * hw * hw * cout * 9 * cin
+            layers.append({"cin": cin, "cout": cout, "hw": hw, "ms": round(ms, 5), "tflops": round(fl / ms / 1e9, 2)})
+            tot_ms += ms
+            tot_flop += fl
+        ach = tot_flop / tot_ms / 1e9
+        line["roofline"] = {"kernel": "gemm_f32_mfma<*,*,CONV3> (13 conv launches of one VGG-16 forward, B=1)",
+                            "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                            "flop_per_step": tot_flop, "ms_per_step": tot_ms, "layers": layers}
+        # ---- gather (HBM bound) -----------------------------------------------------------------
+        enc = eng.encode(img)
+        g = {}
+        for n in (N_POINTS, 262144):
+            p = torch.rand((1, n, 3), device=dev) * 2 - 1
+            xy = ops.project(p, tm)
+            feat = torch.empty((1, n, 1472), device=dev)
+            ms = ev_time_ms(lambda: ops.gather(enc.featmap, xy, feat), 20, torch)
+            gbs = n * GATHER_BYTES_PER_PT / ms / 1e6
+            g["n%d" % n] = {"ms": ms, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS}
+        line["roofline_gather"] = {"kernel": "gather_kernel", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "bytes_per_point": GATHER_BYTES_PER_PT, **g}
+        # ---- point MLP + query-only (encoder amortised) ------------------------------------------
+        q = {}
+        for n in (N_POINTS, 65536, 262144):
+            p = torch.rand((1, n, 3), device=dev) * 2 - 1
+            ms = ev_time_ms(lambda: eng.query(enc, p, tm), 10, torch)
+            q["n%d" % n] = {"ms": ms, "points_per_s": n / ms * 1e3,
+                            "mlp_tflops_lower_bound": n * MLP_FLOP_PER_PT / ms / 1e9}
+        line["query_only"] = q
+        best = max(v["mlp_tflops_lower_bound"] for v in q.values())
+        line["roofline_mlp"] = {"kernel": "gemm_f32_mfma<*,*,DENSE> x8 (+gather, embed, final) per chunk",
+                                "bound": "mfma", "achieved": best, "peak": PEAK_FP32_MFMA_TFLOPS,
+                                "unit": "TFLOP/s", "frac": best / PEAK_FP32_MFMA_TFLOPS,
+                                "flop_per_point": MLP_FLOP_PER_PT}
+        # ---- config 3: full 257^3 grid on one GPU (no marching cubes yet) -----------------------
+        from disn_amd import create_sdf as cs
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enc3 = eng.encode(img)
+        full = cs.dense_grid_sdf(eng, enc3, 0, tm, [-1, -1, -1, 1, 1, 1], 256)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter() - t0
+        line["grid256"] = {"points": 257 ** 3, "seconds": t1, "points_per_s": 257 ** 3 / t1,
+                           "includes": "encode + all chunks + /10, single GPU, no marching cubes"}
+        del full
+        # ---- CPU baseline: the oracle on the same workload, host cores -----------------------------
+        from oracle import disn_oracle as O
+        Wn = store.arrays
+        feed = {"imgs": img.cpu().numpy(), "sample_pc": pts.cpu().numpy(), "sample_pc_rot": pts.cpu().numpy(),
+                "trans_mat": tm.cpu().numpy()}
+        O.get_model(feed, Wn)
+        ts = []
+        for _ in range(max(1, args.cpu_runs)):
+            t0 = time.perf_counter()
+            O.get_model(feed, Wn)
+            ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        cpu_name = ""
+        try:
+            cpu_name = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            pass
+        line["cpu_baseline"] = {"value": N_POINTS / med, "unit": "points/s", "cores": torch.get_num_threads(),
+                                "kind": "port", "seconds_per_step": med,
+                                "sample": "%d full steps (encode + 2048 points) of the numpy/torch-CPU oracle, "
+                                          "median; nproc=%d; %s" % (len(ts), os.cpu_count(), cpu_name)}
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+"""CPU tests of the host logic and the C-ABI surface (no GPU compute).  (-m "not gpu")"""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build():
+    from disn_amd.csrc import build
+    return build.build()
+
+
+def test_library_exports_every_declared_symbol():
+    """the C-ABI library loads and exports exactly what include/disn_amd.h declares"""
+    path = _build()
+    hdr = open(os.path.join(ROOT, "include", "disn_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(disn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    h = ctypes.CDLL(path)
+    for name in sorted(declared):
+        assert hasattr(h, name), "library does not export %s" % name
+    from disn_amd import _lib
+    assert set(_lib.SIGNATURES) == declared, (set(_lib.SIGNATURES) ^ declared)
+    assert _lib.lib().disn_abi_version() == 1
+
+
+def test_code_object_targets_gfx950():
+    path = _build()
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", path], capture_output=True, text=True)
+    blob = open(path, "rb").read()
+    assert b"gfx950" in blob
+    assert b"gfx942" not in blob and b"sm_" not in blob[:0]   # single-arch build
+
+
+def test_argument_validation_without_gpu():
+    """error convention: <0 for invalid arguments, never a crash; checked before any launch"""
+    from disn_amd import _lib
+    h = _lib.lib()
+    assert h.disn_pack_kn(None, 32, 64, 32, None, None) == -1
+    assert h.disn_pack_kn(1, 32, 48, 32, 1, None) == -2            # N % 32
+    assert h.disn_resize_bilinear(None, 1, 2, 2, 3, None, 4, 4, 3, 0, None) == -1
+    assert h.disn_resize_bilinear(1, 1, 2, 2, 3, 1, 4, 4, 2, 0, None) == -2   # coff + C > cstride
+    assert h.disn_conv3x3(1, 1, 8, 8, 5, 1, 1, 64, 1, 1, None, 0, None) == -2  # Cin not 3 / %32
+    assert h.disn_conv3x3(1, 1, 8, 8, 32, 1, 1, 48, 1, 1, None, 0, None) == -2  # Cout % 64
+    assert h.disn_fc(1, 1, 64, 1, 1, 100, 0, 1, 1, 1 << 20, None) == -2         # N % 256
+    assert h.disn_dense(1, 64, 48, None, 0, 0, 8, 1, 1, 64, 1, 1, None, 0, None) == -2
+    assert h.disn_project(None, None, 1, 1, None, None) == -1
+    assert h.disn_gather(1, 1, 0, 4, 1, None) == -1
+    assert h.disn_vgg16_forward(None, None, 1, None, None, None, None, 0, None) == -1
+    p6 = (ctypes.c_double * 6)(-1, -1, -1, 1, 1, 1)
+    assert h.disn_grid_points(ctypes.byref(p6), 4, 0, 126, 1, None) == -1      # k1 > 5^3
+    assert h.disn_grid_points(ctypes.byref(p6), 0, 0, 1, 1, None) == -1
+    # workspace queries are pure host arithmetic
+    assert h.disn_vgg16_workspace_bytes(1) > 12 * 2**20
+    assert h.disn_vgg16_workspace_bytes(8) > h.disn_vgg16_workspace_bytes(1)
+    assert h.disn_query_workspace_bytes(1, 2048) > 2048 * 1472 * 4
+    assert h.disn_query_workspace_bytes(0, 5) == 0
+    with pytest.raises(_lib.DisnError):
+        _lib.check("x", -3)
+
+
+def test_product_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):
+    import torch
+    from disn_amd import _lib, ops
+    with pytest.raises(TypeError):          # CPU tensors are refused: no CPU fallback
+        ops.project(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))
+    if not torch.cuda.is_available():
+        from disn_amd.engine import SdfEngine
+        from disn_amd.weights import WeightStore
+        with pytest.raises((RuntimeError, AssertionError)):
+            SdfEngine(WeightStore(num_classes=1024))
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(_lib.DisnLibraryError):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    """only tests/, smoke() and bench.py's cpu_baseline may touch oracle/"""
+    pkg = os.path.join(ROOT, "disn_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                if f.endswith(".py"):
+                    assert not re.search(r"^\s*(from|import)\s+(\.+)?oracle\b", src, flags=re.M), (dp, f)
+                    assert not re.search(r"import_module\(|__import__\(|exec\(|dlopen|CDLL\([^)]*oracle", src), (dp, f)
+                    code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
+                    assert "disn_oracle" not in re.sub(r'""".*?"""', "", code, flags=re.S), (dp, f)
+                else:
+                    assert not re.search(r"#include\s+[\"<][^\">]*oracle", src), (dp, f)
+
+
+def test_weight_store_namespace_and_restore_semantics(tmp_path):
+    from disn_amd.weights import WeightStore, variable_shapes
+    from oracle import disn_oracle as O
+    assert variable_shapes() == O.variable_shapes()
+    ws = WeightStore.random_init(0)
+    assert ws.complete() and ws.n_params() == 140819266
+    ref = O.init_weights(0, "xavier")
+    for k in ref:
+        assert np.array_equal(ws[k], ref[k]), k           # same generator order as the oracle's init
+    he = WeightStore.random_init(0, mode="he")
+    assert np.array_equal(he["vgg_16/fc8/biases"], O.init_weights(0, "he")["vgg_16/fc8/biases"])
+    # biases zero (utils/tf_util.py:173 constant_initializer(0.0))
+    assert not ws["sdfprediction/fold1/conv1/biases"].any()
+    # restore: prefix + exact shape match, others skipped (train/train_sdf.py:196-205)
+    other = WeightStore(num_classes=1024)
+    n = other.assign({"vgg_16/conv1/conv1_1/weights": ws["vgg_16/conv1/conv1_1/weights"],
+                      "vgg_16/fc8/weights": np.zeros((1, 1, 4096, 1000), np.float32),   # shape mismatch
+                      "unrelated/var": np.zeros(3, np.float32)}, prefix="vgg_16")
+    assert n == 1 and not other.complete()
+    with pytest.raises(ValueError):
+        other.assign({"vgg_16/fc8/weights": np.zeros((1, 1, 4096, 1000), np.float32)}, strict=True)
+    small = {k: v for k, v in ws.items() if k.startswith("sdfprediction")}
+    p = str(tmp_path / "dec.npz")
+    np.savez(p, **small)
+    with pytest.raises(KeyError):
+        WeightStore.load(p)                                 # incomplete checkpoint is an error when strict
+    part = WeightStore.load(p, strict=False)
+    assert len(list(part.keys())) == len(small)
+
+
+def test_graph_surface_matches_reference_signatures():
+    import inspect
+    import disn_amd.model_normalization as model
+    import disn_amd.sdfnet as sdfnet
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(model.placeholder_inputs) == ["batch_size", "num_points", "img_size", "num_sample_pc", "scope", "FLAGS"]
+    assert sig(model.get_model) == ["ref_dict", "num_point", "is_training", "bn", "bn_decay", "img_size", "wd", "FLAGS"]
+    assert sig(model.get_loss) == ["end_points", "sdf_weight", "regularization", "mask_weight",
+                                   "num_sample_points", "FLAGS", "batch_size"]
+    assert sig(model.get_decoder) == ["num_point", "input_pls", "feature_pls", "bn", "bn_decay", "wd"]
+    assert sig(model.get_img_points) == ["sample_pc", "trans_mat_right"]
+    assert sig(model.placeholder_features) == ["batch_size", "num_sample_pc", "scope"]
+    assert sig(sdfnet.get_sdf_basic2) == ["src_pc", "globalfeats", "is_training", "batch_size", "num_point",
+                                          "bn", "bn_decay", "wd"]
+    assert sig(sdfnet.get_sdf_basic2_imgfeat_twostream) == ["src_pc", "point_feat", "is_training", "batch_size",
+                                                             "num_point", "bn", "bn_decay", "wd"]
+    pls = model.placeholder_inputs(2, 1, (137, 137), num_sample_pc=100)
+    assert set(pls) == {"pc", "sample_pc", "sample_pc_rot", "imgs", "sdf", "sdf_params", "trans_mat"}
+    assert pls["imgs"].get_shape() == (2, 137, 137, 3) and pls["trans_mat"].get_shape() == (2, 4, 3)
+    ep = model.get_model(pls, 1, None, bn=False)
+    loss, ep = model.get_loss(ep, num_sample_points=100, batch_size=2)
+    for k in ("pred_sdf", "ref_img", "sample_img_points", "ref_sdf", "ref_pc", "resized_ref_img", "img_embedding",
+              "pred_sdf_value_global", "pred_sdf_value_local", "ref_feats_embedding_cnn", "point_img_feat",
+              "weighed_mask"):
+        assert k in ep, k
+    assert set(ep["losses"]) == {"accuracy", "sdf_loss_realvalue", "sdf_loss", "regularization", "overall_loss"}
+    assert ep["ref_img"] is pls["imgs"]                     # the UN-resized input (model_normalization.py:62)
+    assert ep["pred_sdf"].get_shape() == (2, 100, 1)
+    assert ep["point_img_feat"].get_shape() == (2, 100, 1, 1472)
+
+    class F:
+        binary = True
+    with pytest.raises(NotImplementedError):
+        model.get_model(pls, 1, None, FLAGS=F)
+    with pytest.raises(NotImplementedError):
+        model.get_model(pls, 1, None, bn=True)
+
+
+def test_create_sdf_host_helpers(pins, tmp_path):
+    from disn_amd import create_sdf as cs
+    for r, total, split, nsp in pins["split_plans"]:
+        assert cs.split_plan(int(r))[:3] == (total, split, nsp)
+    for tag in ("a", "b"):
+        assert np.array_equal(cs.grid_points_host(pins["grid_%s_params" % tag], int(pins["grid_%s_res" % tag])),
+                              pins["grid_%s_pts" % tag])
+    p = str(tmp_path / "x.dist")
+    cs.to_binary(int(pins["dist_res"]), pins["dist_pos"], pins["dist_vals"], p)
+    assert np.array_equal(np.frombuffer(open(p, "rb").read(), np.uint8), pins["dist_bytes"])
+    res, pos, vals = cs.read_dist(p)
+    assert res == 4 and np.array_equal(pos, pins["dist_pos"]) and np.array_equal(vals.ravel(), pins["dist_vals"])
+
+
+def test_bench_and_entry_contract_static():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ("--gpus", "--steps", "--warmup", '"roofline"', '"cpu_baseline"', '"vs_baseline"', "ms_per_step"):
+        assert key in src, key
+    ent = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "def build(" in ent and "def smoke(" in ent

@@ -1,0 +1,163 @@
+"""CPU tests of the oracle: against the reference-executed pins, the survey KATs, the committed
+oracle KATs, and independent torch ops.  (-m "not gpu")"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import disn_oracle as O
+
+
+# ---- pinned by the reference's own code (tests/golden/make_golden.py:reference_pins) ---------
+def test_to_binary_matches_reference_bytes(pins):
+    blob = O.to_binary(int(pins["dist_res"]), pins["dist_pos"], pins["dist_vals"])
+    assert np.array_equal(np.frombuffer(blob, np.uint8), pins["dist_bytes"])
+
+
+def test_split_plan_matches_reference(pins):
+    for r, total, split, nsp in pins["split_plans"]:
+        t, s, n, pad = O.split_plan(int(r))
+        assert (t, s, n) == (total, split, nsp)
+        assert pad == s * n - t and 0 <= pad < s
+    # SURVEY §8c chunking KAT
+    assert O.split_plan(64) == (274625, 2, 137313, 1)
+    assert O.split_plan(256) == (16974593, 80, 212183, 47)
+
+
+def test_grid_points_match_reference(pins):
+    for tag in ("a", "b"):
+        pts = O.grid_points(pins["grid_%s_params" % tag], int(pins["grid_%s_res" % tag]))
+        assert pts.dtype == np.float32
+        assert np.array_equal(pts, pins["grid_%s_pts" % tag])
+
+
+def test_blender_proj_matches_reference(pins):
+    for (az, el, d), K, RT in zip(pins["cam_params"], pins["cam_K"], pins["cam_RT"]):
+        k, rt = O.blender_proj(az, el, d)
+        assert np.allclose(k, K, rtol=0, atol=1e-12)
+        assert np.allclose(rt, RT, rtol=0, atol=1e-12)
+    # intrinsics identity (preprocessing/create_img_h5.py:30-34)
+    assert pins["cam_K"][0][0, 0] == 35.0 * 137 / 32 and pins["cam_K"][0][0, 2] == 68.5
+
+
+def test_synth_trans_mat_projects_in_front_of_camera():
+    tm = O.synth_trans_mat(30.0, 25.0, 0.8)
+    assert tm.shape == (4, 3) and tm.dtype == np.float32
+    pts = np.random.default_rng(0).uniform(-0.5, 0.5, (1, 256, 3)).astype(np.float32)
+    homo = np.concatenate([pts[0], np.ones((256, 1), np.float32)], 1) @ tm
+    assert (homo[:, 2] > 0).all()          # positive depth for an object-sized cloud
+    xy = O.get_img_points(pts, tm[None])
+    assert ((xy >= 0) & (xy <= 136)).all()
+
+
+# ---- survey / committed KATs -------------------------------------------------------------------
+def test_projection_kat(kat):
+    xy = O.get_img_points(kat["proj_pts"], O.DEMO_TRANS_MAT)
+    assert np.array_equal(xy, kat["proj_xy"])
+    assert np.allclose(xy[0], kat["proj_xy_survey"], rtol=0, atol=2e-5)   # values quoted in SURVEY §8c
+    grid = O.grid_points([-1, -1, -1, 1, 1, 1], 64)
+    gxy = O.get_img_points(grid[None], O.DEMO_TRANS_MAT)[0]
+    clamp = ((gxy == 0) | (gxy == 136)).any(1).mean()
+    assert abs(clamp - 0.0539) < 5e-4                                     # "5.39 % of points hit the clamp"
+
+
+def test_projection_nan_policy():
+    tm = np.zeros((1, 4, 3), np.float32)      # p = 0 -> 0/0
+    xy = O.get_img_points(np.ones((1, 2, 3), np.float32), tm)
+    assert np.isnan(xy).all()
+    out = O.resampler(np.ones((1, 137, 137, 4), np.float32), xy)
+    assert (out == 0).all()                  # documented choice: NaN -> outside -> zero features
+
+
+def test_resize_kat_and_index_facts(kat):
+    for hin, hout in ((14, 137), (224, 137), (137, 224), (28, 137)):
+        out = O.resize_bilinear_legacy(kat["resize_%d_%d_in" % (hin, hout)], hout, hout)
+        assert np.array_equal(out, kat["resize_%d_%d_out" % (hin, hout)])
+    # Appendix A.3: rows with hi == lo (clamped at the last source row)
+    for size, n_clamped in ((224, 0), (112, 1), (56, 2), (28, 4), (14, 9)):
+        lo, hi, _ = O.resize_index_table(size, 137)
+        assert int((lo == hi).sum()) == n_clamped
+    lo, hi, _ = O.resize_index_table(224, 137)
+    assert lo.max() == 222 and hi.max() == 223
+
+
+def test_resize_against_independent_bilinear():
+    rng = np.random.default_rng(3)
+    for hin, hout in ((14, 137), (224, 137), (137, 224), (56, 137)):
+        a = rng.random((2, hin, hin, 3), dtype=np.float32)
+        o = O.resize_bilinear_legacy(a, hout, hout)
+        src = np.minimum(np.arange(hout, dtype=np.float32) * (np.float32(hin) / np.float32(hout)), hin - 1)
+        gy, gx = np.meshgrid(src, src, indexing="ij")
+        grid = np.stack([2 * gx / (hin - 1) - 1, 2 * gy / (hin - 1) - 1], -1)[None].repeat(2, 0).astype(np.float32)
+        t = F.grid_sample(torch.from_numpy(a).permute(0, 3, 1, 2), torch.from_numpy(grid), mode="bilinear",
+                          padding_mode="border", align_corners=True).permute(0, 2, 3, 1).numpy()
+        assert np.abs(o - t).max() < 2e-5
+
+
+def test_resampler_kat_and_grid_sample(kat):
+    out = O.resampler(kat["resampler_data"], kat["resampler_warp"])
+    assert np.array_equal(out, kat["resampler_out"])
+    d, w = kat["resampler_data"], kat["resampler_warp"]
+    # edge cases: (0,0) exact pixel; (136,136) cx=137 out of range with weight 0; outside -> 0
+    assert np.array_equal(out[0, 0], d[0, 0, 0]) and np.array_equal(out[0, 1], d[0, 136, 136])
+    assert np.array_equal(out[0, 2], d[0, 0, 136]) and (out[0, 4] != 0).any()   # x=136.5 < W: half weight
+    gx = 2 * w / (137 - 1) - 1
+    t = F.grid_sample(torch.from_numpy(d).permute(0, 3, 1, 2), torch.from_numpy(gx)[:, None], mode="bilinear",
+                      padding_mode="zeros", align_corners=True)[0, :, 0].T.numpy()
+    assert np.abs(out[0] - t).max() < 2e-5
+
+
+def test_conv_and_pool_against_numpy():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 9, 7, 5)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 5, 6)).astype(np.float32)
+    b = rng.standard_normal(6).astype(np.float32)
+    assert np.abs(O.conv2d(x, w, b) - O.conv2d_numpy(x, w, b, "SAME", True)).max() < 2e-5
+    w7 = rng.standard_normal((7, 7, 5, 4)).astype(np.float32)
+    x7 = rng.standard_normal((1, 7, 7, 5)).astype(np.float32)
+    assert np.abs(O.conv2d(x7, w7, b[:4], "VALID", False) - O.conv2d_numpy(x7, w7, b[:4], "VALID", False)).max() < 5e-5
+    p = O.max_pool_2x2(x[:, :8, :6])
+    assert p.shape == (2, 4, 3, 5) and p[0, 0, 0, 0] == x[0, :2, :2, 0].max()
+
+
+def test_variable_namespace():
+    shp = O.variable_shapes()
+    assert shp["vgg_16/conv1/conv1_1/weights"] == (3, 3, 3, 64)
+    assert shp["vgg_16/fc6/weights"] == (7, 7, 512, 4096)
+    assert shp["sdfprediction/fold2/conv1/weights"] == (1, 1, 1536, 512)
+    assert shp["sdfprediction_imgfeat/fold2/conv1/weights"] == (1, 1, 1984, 512)
+    n = sum(int(np.prod(s)) for s in shp.values())
+    assert n == 138455872 + 2363394 - 0 or n == 140819266     # VGG 138 455 872 + decoder 2 363 394
+
+
+def test_mlp_small_known_answer():
+    # hand-checkable: zero weights except biases -> pred = b6 for both streams
+    W = {k: np.zeros(s, np.float32) for k, s in O.variable_shapes().items()}
+    W["sdfprediction/fold2/conv5/biases"][:] = 0.25
+    W["sdfprediction_imgfeat/fold2/conv5/biases"][:] = -1.5
+    pts = np.zeros((1, 3, 3), np.float32)
+    g = O.get_sdf_basic2(pts, np.zeros((1, 1024), np.float32), W)
+    l = O.get_sdf_basic2_imgfeat_twostream(pts, np.zeros((1, 3, 1, 1472), np.float32), W)
+    assert g.shape == (1, 3, 1) and (g == 0.25).all() and (l == -1.5).all()
+
+
+@pytest.mark.timeout(600)
+def test_full_model_kat(kat):
+    """cfg2 (seed 0, 2048 pts) reproduces the committed fp32 prediction and stays within the
+    fp32 noise floor of the fp64 shadow."""
+    W = O.init_weights(0, "he")
+    ep = O.get_model(O.synth_inputs(0, 1, 2048), W)
+    assert np.array_equal(ep["sample_img_points"], kat["cfg2_he_xy"])
+    assert np.abs(ep["pred_sdf"] - kat["cfg2_he_pred"]).max() < 5e-5      # BLAS thread-count dependent order
+    assert np.abs(ep["pred_sdf"] - kat["cfg2_he_pred64"]).max() < 5e-5
+    assert np.abs(kat["cfg2_he_pred"]).mean() > 0.1                       # He weights keep activations O(1)
+
+
+def test_loss_formula():
+    pred = np.array([[[1.0], [-2.0], [0.5]]], np.float32)
+    gt = np.array([[[0.2], [-0.1], [0.005]]], np.float32)
+    L = O.get_loss(pred, gt)
+    assert L["accuracy"] == 1.0
+    # |10*gt - pred| * mask, mask = 4 where gt <= 0.01
+    expect = np.mean([abs(2.0 - 1.0) * 1, abs(-1.0 + 2.0) * 4, abs(0.05 - 0.5) * 4]) * 1000
+    assert abs(L["sdf_loss"] - expect) < 1e-3

@@ -1,0 +1,78 @@
+"""world_size-2 gloo tests of the sharded dense-grid path (CPU).  (-m "not gpu")
+
+The per-shard compute is injected: here it is a deterministic function of the flat grid
+index (and, in one test, the oracle's MLP on a tiny grid), so that what is tested is the
+partition, the padding, the all_gather and the reassembly into ``.dist`` order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from disn_amd import parallel as par
+
+
+def test_shard_range_properties():
+    for total in (1, 7, 125, 274625, 16974593):
+        for world in (1, 2, 3, 8):
+            edges = [par.shard_range(total, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            for (a0, a1), (b0, b1) in zip(edges, edges[1:]):
+                assert a1 == b0 and a1 >= a0
+            sizes = par.shard_sizes(total, world)
+            assert sum(sizes) == total and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        par.shard_range(10, 2, 2)
+
+
+def _worker(rank, world, port, total, n_images, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def query_fn(b, k0, k1):
+            calls.append((b, k0, k1))
+            k = torch.arange(k0, k1, dtype=torch.float64)
+            return (torch.sin(k * 0.37 + b) * 3.0).to(torch.float32)
+
+        out = par.sharded_grid(query_fn, n_images, total, torch.device("cpu"))
+        q.put((rank, out.numpy(), calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("total,n_images", [(125, 1), (4913, 3)])
+def test_sharded_grid_gloo_world2(total, n_images):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + total) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, n_images, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    k = np.arange(total, dtype=np.float64)
+    expect = np.stack([(np.sin(k * 0.37 + b) * 3.0).astype(np.float32) for b in range(n_images)])
+    for rank, out, calls in results:
+        assert out.shape == (n_images, total)
+        assert np.array_equal(out, expect), "rank %d: sharded result differs from the single-rank order" % rank
+        k0, k1 = par.shard_range(total, world, rank)
+        assert calls == [(b, k0, k1) for b in range(n_images)]   # every rank touched only its slice
+
+
+def test_single_process_equals_unsharded():
+    total = 343
+
+    def query_fn(b, k0, k1):
+        return torch.arange(k0, k1, dtype=torch.float32) + 1000 * b
+
+    out = par.sharded_grid(query_fn, 2, total, torch.device("cpu"))
+    assert torch.equal(out[1], torch.arange(total, dtype=torch.float32) + 1000)
