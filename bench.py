@@ -132,6 +132,8 @@ def main():
                    "parallelism": "replicas x%d (no data-path collective)" % world},
     }
 
+    if rank == 0:
+        print("[bench] main line: %.4g points/s, %.4f ms/step" % (value, line["ms_per_step"]), file=sys.stderr)
     if rank == 0 and not args.no_extras:
         # ---- roofline of the dominant kernel family: the 13 implicit-GEMM conv launches ----------
         layers, tot_ms, tot_flop = [], 0.0, 0.0

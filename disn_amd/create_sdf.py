@@ -36,7 +36,7 @@ def grid_points_host(sdf_params: Sequence[float], sdf_res: int) -> np.ndarray:
     """Host grid as the reference builds it (test/create_sdf.py:246-256) -- for callers that
     still feed points through placeholders.  The device path never materialises this."""
     res = sdf_res + 1
-    p = np.asarray(sdf_params)
+    p = np.asarray(sdf_params, dtype=np.float64)   # numpy-1.x semantics of the reference (float64 linspace)
     x_ = np.linspace(p[0], p[3], num=res)
     y_ = np.linspace(p[1], p[4], num=res)
     z_ = np.linspace(p[2], p[5], num=res)

@@ -82,8 +82,7 @@ int conv3x3_impl(const float* in, int B, int H, int W, int Cin, const float* w_p
   p.M = B * H * W; p.N = Cout; p.K = conv_k(Cin);
   p.bp = w_packed; p.bias = bias; p.rows_per_bias = 0;
   p.out = out; p.ldc = Cout; p.relu = relu;
-  const GemmPlan pl = gemm_plan(p.M, p.N, p.K);
-  if (pl.ws_bytes > ws_bytes || (pl.ws_bytes && !ws)) return DISN_E_WS;
+  const GemmPlan pl = gemm_plan(p.M, p.N, p.K, ws ? ws_bytes : 0);
   DISN_TRY(gemm_launch(p, Cin == 3 ? GEMM_CONV3_C3 : GEMM_CONV3, pl, ws, st));
   return 0;
 }
@@ -93,15 +92,22 @@ const int kChunk = 65536;  // points per MLP pass inside disn_query / disn_sdf_m
 
 struct MlpWs {
   float *e1g, *e1l, *h256, *h512a, *h512b, *g5, *l5, *gemm_ws;
-  size_t total;
+  size_t gemm_ws_bytes, total;
 };
 
 size_t mlp_gemm_ws(int n) {
+  // the split-K plan depends on the row count; a ragged last chunk may want slabs although the
+  // full chunk does not, so size for every power-of-two row count up to n (and n itself).
+  // mlp_chunk() additionally plans WITHIN this capacity, so the size is only a speed matter.
   size_t m = 0;
   const int shapes[5][2] = {{256, 64}, {512, 256}, {512, 512}, {512, 1984}, {256, 512}};
-  for (auto& s : shapes) {
-    const GemmPlan pl = gemm_plan(n, s[0], s[1]);
-    if (pl.ws_bytes > m) m = pl.ws_bytes;
+  for (int rows = 1;; rows *= 2) {
+    const int r = rows < n ? rows : n;
+    for (auto& s : shapes) {
+      const GemmPlan pl = gemm_plan(r, s[0], s[1]);
+      if (pl.ws_bytes > m) m = pl.ws_bytes;
+    }
+    if (rows >= n) break;
   }
   return m;
 }
@@ -116,7 +122,8 @@ MlpWs mlp_layout(Bump& b, int n) {
   w.h512b = b.take((size_t)n * 512 * f);
   w.g5 = b.take((size_t)n * 256 * f);
   w.l5 = b.take((size_t)n * 256 * f);
-  w.gemm_ws = b.take(mlp_gemm_ws(n));
+  w.gemm_ws_bytes = mlp_gemm_ws(n);
+  w.gemm_ws = b.take(w.gemm_ws_bytes);
   w.total = b.off;
   return w;
 }
@@ -130,14 +137,14 @@ bool mlp_weights_ok(const disn_mlp_weights_t* w) {
 }
 
 int dense_layer(const float* a1, int lda1, int k1, const float* a2, int lda2, int K, int n,
-                const float* bp, const float* bias, int N, float* out, float* ws,
+                const float* bp, const float* bias, int N, float* out, float* ws, size_t ws_bytes,
                 hipStream_t st) {
   GemmParams p{};
   p.a1 = a1; p.lda1 = lda1; p.k1 = k1; p.a2 = a2; p.lda2 = lda2;
   p.M = n; p.N = N; p.K = K;
   p.bp = bp; p.bias = bias; p.rows_per_bias = 0;
   p.out = out; p.ldc = N; p.relu = 1;
-  const GemmPlan pl = gemm_plan(n, N, K);
+  const GemmPlan pl = gemm_plan(n, N, K, ws ? ws_bytes : 0);
   DISN_TRY(gemm_launch(p, GEMM_DENSE, pl, ws, st));
   return 0;
 }
@@ -149,15 +156,15 @@ int mlp_chunk(const disn_mlp_weights_t* w, const float* pts_rot, int n, const fl
   int rc;
   DISN_TRY(pt_embed_launch(pts_rot, n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g, s.e1l, st));
   // global stream  (models/sdfnet.py:71-88)
-  if ((rc = dense_layer(s.e1g, 64, 64, nullptr, 0, 64, n, w->g_w2, w->g_b2, 256, s.h256, s.gemm_ws, st))) return rc;
-  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->g_w3, w->g_b3, 512, s.h512a, s.gemm_ws, st))) return rc;
-  if ((rc = dense_layer(s.h512a, 512, 512, nullptr, 0, 512, n, w->g_w4_point, gbias, 512, s.h512b, s.gemm_ws, st))) return rc;
-  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->g_w5, w->g_b5, 256, s.g5, s.gemm_ws, st))) return rc;
+  if ((rc = dense_layer(s.e1g, 64, 64, nullptr, 0, 64, n, w->g_w2, w->g_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->g_w3, w->g_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h512a, 512, 512, nullptr, 0, 512, n, w->g_w4_point, gbias, 512, s.h512b, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->g_w5, w->g_b5, 256, s.g5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
   // local stream  (models/sdfnet.py:173-186); fold2/conv1 reads [point512 | feat1472]
-  if ((rc = dense_layer(s.e1l, 64, 64, nullptr, 0, 64, n, w->l_w2, w->l_b2, 256, s.h256, s.gemm_ws, st))) return rc;
-  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->l_w3, w->l_b3, 512, s.h512a, s.gemm_ws, st))) return rc;
-  if ((rc = dense_layer(s.h512a, 512, 512, feat, DISN_FEAT_DIM, 512 + DISN_FEAT_DIM, n, w->l_w4, w->l_b4, 512, s.h512b, s.gemm_ws, st))) return rc;
-  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->l_w5, w->l_b5, 256, s.l5, s.gemm_ws, st))) return rc;
+  if ((rc = dense_layer(s.e1l, 64, 64, nullptr, 0, 64, n, w->l_w2, w->l_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->l_w3, w->l_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h512a, 512, 512, feat, DISN_FEAT_DIM, 512 + DISN_FEAT_DIM, n, w->l_w4, w->l_b4, 512, s.h512b, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->l_w5, w->l_b5, 256, s.l5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
   DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, sdf_g, sdf_l,
                             out_div, st));
   return 0;
@@ -268,8 +275,7 @@ int disn_dense(const float* a1, int lda1, int k1, const float* a2, int lda2, int
   p.M = M; p.N = N; p.K = k1 + k2;
   p.bp = w_packed; p.bias = bias; p.rows_per_bias = 0;
   p.out = out; p.ldc = N; p.relu = relu;
-  const GemmPlan pl = gemm_plan(M, N, p.K);
-  if (pl.ws_bytes > ws_bytes || (pl.ws_bytes && !ws)) return DISN_E_WS;
+  const GemmPlan pl = gemm_plan(M, N, p.K, ws ? ws_bytes : 0);
   DISN_TRY(gemm_launch(p, GEMM_DENSE, pl, (float*)ws, (hipStream_t)stream));
   return 0;
 }

@@ -296,7 +296,7 @@ static bool parse_force(int* bm, int* bn, int* s) {
   return std::sscanf(e, "%d,%d,%d", bm, bn, s) == 3;
 }
 
-GemmPlan gemm_plan(int M, int N, int K) {
+GemmPlan gemm_plan(int M, int N, int K, size_t max_ws) {
   const int ksteps = K / 32;
   const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
   const int svals[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 36};
@@ -309,6 +309,8 @@ GemmPlan gemm_plan(int M, int N, int K) {
     const int tiles = (bm / 64) * (bn / 64);
     for (int s : svals) {
       if (s > 1 && (ksteps % s || ksteps / s < 4)) continue;
+      // split-K needs S partial slabs: never plan beyond the caller's workspace
+      if (s > 1 && (size_t)s * M * N * sizeof(float) > max_ws) continue;
       // cost model (cycles): CU rounds x per-WG time (+ split-K reduce pass).
       // Co-residency: small tiles fit 3 WGs per CU, 128x128 fits 2.
       const int per_cu = tiles >= 4 ? 2 : 3;
@@ -325,7 +327,8 @@ GemmPlan gemm_plan(int M, int N, int K) {
   }
   int fbm, fbn, fs;
   if (parse_force(&fbm, &fbn, &fs) && (fbm == 64 || fbm == 128) && (fbn == 64 || fbn == 128) &&
-      N % fbn == 0 && fs >= 1 && fs <= ksteps) {
+      N % fbn == 0 && fs >= 1 && fs <= ksteps &&
+      (fs == 1 || (size_t)fs * M * N * sizeof(float) <= max_ws)) {
     plan.bm = fbm; plan.bn = fbn; plan.splitk = fs;
   }
   plan.ws_bytes = plan.splitk > 1 ? (size_t)plan.splitk * M * N * sizeof(float) : 0;

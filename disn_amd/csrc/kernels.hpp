@@ -32,7 +32,8 @@ struct GemmPlan {
   size_t ws_bytes;  // split-K partial slabs (0 when splitk == 1)
 };
 
-GemmPlan gemm_plan(int M, int N, int K);
+// max_ws bounds the split-K partial slabs the plan may use (the plan is a pure speed choice)
+GemmPlan gemm_plan(int M, int N, int K, size_t max_ws = ~size_t(0));
 hipError_t gemm_launch(const GemmParams& p, GemmMode mode, const GemmPlan& plan, float* ws,
                        hipStream_t st);
 hipError_t pack_kn_launch(const float* w, int K, int N, int Kpad, float* packed, hipStream_t st);

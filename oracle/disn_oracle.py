@@ -449,7 +449,10 @@ def grid_points(sdf_params: Sequence[float], sdf_res: int) -> np.ndarray:
     """[(R+1)^3, 3] float32 in the flat (iz,iy,ix) order -- test/create_sdf.py:246-256:
     linspace in float64, meshgrid(z_,y_,x_,'ij'), concat (x,y,z), cast float32."""
     res = sdf_res + 1
-    p = np.asarray(sdf_params)
+    # float64 explicitly: in the reference's numpy-1.x environment linspace of float32 / int
+    # scalars computes in float64 (demo/demo.py:278 even passes ints); numpy>=2 (NEP 50) would
+    # silently compute float32 for float32 inputs, which is NOT the reference's arithmetic
+    p = np.asarray(sdf_params, dtype=np.float64)
     x_ = np.linspace(p[0], p[3], num=res)
     y_ = np.linspace(p[1], p[4], num=res)
     z_ = np.linspace(p[2], p[5], num=res)

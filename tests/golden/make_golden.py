@@ -102,7 +102,11 @@ def reference_pins():
     code = statements(os.path.join(REF, "test/create_sdf.py"), 247, 255)
     for tag, sp, r in (("a", np.array([-1, -1, -1, 1, 1, 1], np.float32), 8),
                        ("b", np.array([-0.83, -0.41, -0.27, 0.79, 0.55, 0.31], np.float32), 5)):
-        env = {"np": np, "sdf_params": sp, "RESOLUTION": r + 1}
+        # NOTE: fed as float64.  The reference ran on numpy 1.x, where np.linspace of float32
+        # scalars computes in float64; under this container's numpy 2.x (NEP 50) float32 inputs
+        # would make the very same statements compute in float32.  Feeding the (exactly
+        # representable) values as float64 reproduces the reference environment's arithmetic.
+        env = {"np": np, "sdf_params": sp.astype(np.float64), "RESOLUTION": r + 1}
         exec(code, env)
         out["grid_%s_params" % tag] = sp
         out["grid_%s_res" % tag] = np.int64(r)
