@@ -1,0 +1,31 @@
+"""Small, bounded workload for rocprofv3 passes (kernel trace or one PMC counter at a time):
+2 full steps (encode + 2048-point query), one standalone gather at 2048 and 262144 points,
+one 65536-point query."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from disn_amd import ops
+from disn_amd.engine import SdfEngine
+from disn_amd.weights import WeightStore
+
+torch.cuda.set_device(0)
+eng = SdfEngine(WeightStore.random_init(0))
+rng = np.random.default_rng(0)
+img = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32)).cuda()
+tm = torch.tensor([[[-68.453156, 5.5086656, -0.37556022], [-17.138561, -84.685486, -0.250198],
+                    [-47.284092, -3.6569588, 0.2493176], [101.133705, 101.34268, 1.4305686]]], device="cuda")
+pts = torch.rand((1, 2048, 3), device="cuda") * 2 - 1
+for _ in range(int(os.environ.get("PROF_STEPS", "3"))):
+    enc = eng.encode(img)
+    out = eng.query(enc, pts, tm)
+for n in (2048, 262144):
+    p = torch.rand((1, n, 3), device="cuda") * 2 - 1
+    xy = ops.project(p, tm)
+    for _ in range(3):
+        f = ops.gather(enc.featmap, xy)
+p = torch.rand((1, 65536, 3), device="cuda") * 2 - 1
+for _ in range(2):
+    eng.query(enc, p, tm)
+torch.cuda.synchronize()
+print("done")
