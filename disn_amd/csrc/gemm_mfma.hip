@@ -38,95 +38,130 @@ __device__ __forceinline__ float4 mask4(float4 v, bool keep) {
 
 struct GemmDev {
   GemmParams p;
-  float* ws;
+  float* ws;   // stream-K partial slabs [2*W][BM*BN] (tile-local row-major)
   int ksteps, mtiles, ntiles;
+  int W;       // workgroups = gridDim.x
+  long units;  // mtiles * ntiles * ksteps
+  long long* dbg;  // profiling only (ABL & 16): per-workgroup phase timestamps; null in the product
 };
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmDev d) {
+// Stream-K decomposition.  The work is the list of (tile, k-step) units, tile-major; workgroup w
+// owns the contiguous range [U*w/W, U*(w+1)/W).  A range is cut into SEGMENTS at tile borders:
+// a segment that covers a whole tile [0,KS) is finished in place (bias + ReLU fused); a partial
+// one goes to slab 2w (the workgroup's first segment) or 2w+1 (its last) and streamk_fixup sums
+// the slabs of every cut tile in workgroup order (deterministic).  With W = tiles*S this is
+// classic split-K, with W = tiles plain data-parallel; W = 256*G balances any shape over the 256
+// CUs, which matters because one VGG layer at batch 1 is only 50-400 tiles (measured: 196 / 392
+// / 784 equal workgroups take 1 / 2 / 4 rounds, tools/ubench/mfma_ubench.hip).
+__device__ __forceinline__ long unit_begin(long U, int W, int w) { return (U * w) / W; }
+
+// ABL: profiling ablation mask, 0 in every product instantiation (tools/ubench/gemm_ablate.hip
+// instantiates the others): 1 = no A-tile global loads in the loop, 2 = no B loads in the loop,
+// 4 = no LDS store + barrier, 8 = no A-fragment ds_reads.  Results are garbage when != 0.
+template <int BM, int BN, int MODE, int ABL = 0>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1)  // 128x128 must fit two waves per SIMD
+void gemm_f32_mfma(const GemmDev d) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int LDA = 36;
   constexpr int APASS = BM / 32;
   __shared__ __attribute__((aligned(16))) float lds[2 * BM * LDA];
 
   const GemmParams& p = d.p;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of
-  // tile ids (neighbouring tiles share A rows / B columns in that XCD's L2).
-  int bid = blockIdx.x;
+  // XCD-aware order: block b runs on XCD b%8; give each XCD a contiguous run of logical
+  // workgroup ids, i.e. of tiles (neighbouring tiles share A rows / B columns in that XCD's L2).
+  int w = blockIdx.x;
   {
-    const int nwg = d.mtiles * d.ntiles;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int q = d.W >> 3, r = d.W & 7, xcd = w & 7, idx = w >> 3;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int mt = bid / d.ntiles, nt = bid - mt * d.ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int S = gridDim.y, z = blockIdx.y;
-  const int s_begin = (int)(((long)d.ksteps * z) / S);
-  const int s_end = (int)(((long)d.ksteps * (z + 1)) / S);
+  const int KS = d.ksteps;
+  const long u0 = unit_begin(d.units, d.W, w), u1 = unit_begin(d.units, d.W, w + 1);
 
-  // ---- per-thread A-loader state: rows (tid>>3)+32*pass, 16-byte column c4 -------
+  int dbg_n = 0;
+  if ((ABL & 16) && threadIdx.x == 0) d.dbg[(size_t)blockIdx.x * 16 + dbg_n++] = __builtin_readcyclecounter();
+  for (long u = u0; u < u1;) {
+  // The thread id is made opaque per segment: otherwise LICM hoists every lane-dependent address
+  // (LDS offsets, row pointers, epilogue indices) out of this loop and keeps ~100 extra VGPRs live
+  // across the K loop -- one wave per SIMD instead of two.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
   const int c4 = tid & 7;
   const int arow = tid >> 3;
-  int pix[APASS];  // CONV: flat pixel index (b*H+y)*W+x, -1 when the row is past M
-  int yx[APASS];   // CONV: (y<<16)|x ; DENSE: unused
+  const int tile = (int)(u / KS);
+  const int s_begin = (int)(u - (long)tile * KS);
+  const long rest = u1 - (long)tile * KS;
+  const int s_end = rest < KS ? (int)rest : KS;
+  const bool complete = s_begin == 0 && s_end == KS;
+  const int slot = (u == u0) ? 2 * w : 2 * w + 1;
+  u += s_end - s_begin;
+  const int mt = tile / d.ntiles, nt = tile - mt * d.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-thread A-loader state: rows (tid>>3)+32*pass, 16-byte column c4 ---------------
+  // Everything per-row is precomputed ONCE: a base pointer and, for the convolution, a 9-bit
+  // validity mask of the 3x3 taps.  Per k-step only a wave-uniform offset (SALU) is added.
+  const float* pa1[APASS];
+  const float* pa2[APASS];
+  unsigned vmask[APASS];
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
     const int m = m0 + arow + 32 * i;
+    const bool valid = m < p.M;
+    const size_t mm = valid ? (size_t)m : 0;
     if (MODE == GEMM_DENSE) {
-      pix[i] = (m < p.M) ? m : -1;
-      yx[i] = 0;
+      pa1[i] = p.a1 + mm * p.lda1 + c4 * 4;
+      pa2[i] = p.a2 ? p.a2 + mm * p.lda2 + c4 * 4 : p.a1;
+      vmask[i] = valid ? 0x1ffu : 0u;
     } else {
-      if (m < p.M) {
-        const int hw = p.H * p.W;
-        const int b = m / hw, rem = m - b * hw;
-        const int y = rem / p.W, x = rem - y * p.W;
-        pix[i] = m;
-        yx[i] = (y << 16) | x;
-      } else {
-        pix[i] = -1;
-        yx[i] = 0;
+      const int hw = p.H * p.W;
+      const int rem = (int)(mm % hw);
+      const int y = rem / p.W, x = rem - y * p.W;
+      pa1[i] = p.a1 + mm * p.Cin + (MODE == GEMM_CONV3 ? c4 * 4 : 0);
+      pa2[i] = p.a1;
+      unsigned vm = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (valid && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) vm |= 1u << t;
       }
+      vmask[i] = vm;
     }
   }
 
-  float4 areg[APASS];
-  unsigned aok = 0;  // bit i: pass i of the in-flight A tile is inside the image / matrix
-  auto load_a = [&](int s) {
+  // A cursor: wave-uniform position of the NEXT A tile to request.  It advances by one k-step
+  // per load_a() and sticks at the last step (the tail re-requests valid data; result unused),
+  // all with selects -- the K loop stays one basic block.
+  int a_step = s_begin;
+  int a_kyx = 0, a_ci0 = 0;
+  if (MODE == GEMM_CONV3) {
+    const int cblocks = p.Cin >> 5;
+    a_kyx = s_begin / cblocks;
+    a_ci0 = (s_begin - a_kyx * cblocks) << 5;
+  }
+  auto load_a = [&](float4 (&areg)[APASS], unsigned& aok) {
+    aok = 0;
     if (MODE == GEMM_DENSE) {
-      const int k0 = s * 32;
-      const float* base;
-      int ld;
-      if (k0 < p.k1) {
-        base = p.a1 + k0;
-        ld = p.lda1;
-      } else {
-        base = p.a2 + (k0 - p.k1);
-        ld = p.lda2;
-      }
+      const int k0 = a_step * 32;
+      const bool first = k0 < p.k1;
+      const long off = first ? k0 : k0 - p.k1;
 #pragma unroll
       for (int i = 0; i < APASS; ++i) {
-        const bool ok = pix[i] >= 0;
-        areg[i] = *reinterpret_cast<const float4*>(base + (size_t)(ok ? pix[i] : 0) * ld + c4 * 4);
-        aok = ok ? (aok | (1u << i)) : (aok & ~(1u << i));
+        areg[i] = *reinterpret_cast<const float4*>((first ? pa1[i] : pa2[i]) + off);
+        aok |= (vmask[i] & 1u) << i;
       }
     } else if (MODE == GEMM_CONV3) {
-      const int cblocks = p.Cin >> 5;
-      const int kyx = s / cblocks, ci0 = (s - kyx * cblocks) << 5;
-      const int dy = kyx / 3 - 1, dx = kyx - (kyx / 3) * 3 - 1;
+      const int dy = a_kyx / 3 - 1, dx = a_kyx - (a_kyx / 3) * 3 - 1;
+      const long delta = (long)(dy * p.W + dx) * p.Cin + a_ci0;
 #pragma unroll
       for (int i = 0; i < APASS; ++i) {
-        const int yy = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
-        const bool ok = pix[i] >= 0 && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-        // branch-free: out-of-image taps read pixel 0 and are zeroed by the select, so the
-        // K loop stays one basic block and the compiler's vmcnt bookkeeping stays exact
-        areg[i] = *reinterpret_cast<const float4*>(
-            p.a1 + (size_t)(ok ? pix[i] + dy * p.W + dx : 0) * p.Cin + ci0 + c4 * 4);
-        aok = ok ? (aok | (1u << i)) : (aok & ~(1u << i));
+        const unsigned ok = (vmask[i] >> a_kyx) & 1u;
+        // out-of-image taps read the (always valid) tensor base and are zeroed at store time
+        areg[i] = *reinterpret_cast<const float4*>(ok ? pa1[i] + delta : p.a1);
+        aok |= ok << i;
       }
     } else {  // GEMM_CONV3_C3: Cin == 3, K = 27 padded to 32, a single k-step
 #pragma unroll
@@ -137,16 +172,23 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmDev d) {
           const int k = c4 * 4 + j;
           const int kyx = k / 3, ci = k - kyx * 3;
           const int dy = kyx / 3 - 1, dx = kyx - (kyx / 3) * 3 - 1;
-          const int yy = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
-          const bool ok = k < 27 && pix[i] >= 0 && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-          v[j] = ok ? p.a1[(size_t)(pix[i] + dy * p.W + dx) * 3 + ci] : 0.f;
+          const bool ok = k < 27 && ((vmask[i] >> kyx) & 1u);
+          v[j] = ok ? pa1[i][(dy * p.W + dx) * 3 + ci] : 0.f;
         }
         areg[i] = make_float4(v[0], v[1], v[2], v[3]);
         aok |= 1u << i;
       }
     }
+    const int adv = (a_step + 1 < s_end) ? 1 : 0;
+    a_step += adv;
+    if (MODE == GEMM_CONV3) {
+      a_ci0 += 32 * adv;
+      const int wrap = (a_ci0 == p.Cin) ? 1 : 0;
+      a_ci0 = wrap ? 0 : a_ci0;
+      a_kyx += wrap;
+    }
   };
-  auto store_a = [&](int buf) {
+  auto store_a = [&](int buf, const float4 (&areg)[APASS], unsigned aok) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i)
       *reinterpret_cast<float4*>(&lds[buf * BM * LDA + (arow + 32 * i) * LDA + c4 * 4]) =
@@ -161,114 +203,238 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmDev d) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (s_begin < s_end) {
-    load_a(s_begin);
-    store_a(0);
-  }
-  __syncthreads();
-
   const int nb32 = p.N >> 5;
   const int frag_row = wm * (BM / 2) + (lane & 31);
   const int frag_k = (lane >> 5) * 4;
-  const int colblk0 = (n0 >> 5) + wn * TN;
-  // B fragments are software-pipelined one 8-k block ahead (carried across the step
-  // boundary) so their L2 latency hides under the 16*TM*TN/4 MFMAs of the current block.
-  auto load_b = [&](int s, int kb, float4 (&b)[TN]) {
-    const float* bp = p.bp + (((size_t)s * 4 + kb) * nb32 + colblk0) * 256 + lane * 4;
+  // B cursor: per-lane pointer to this wave's first fragment of the next step to request
+  const size_t b_stride = (size_t)4 * nb32 * 256;
+  const float* bptr = p.bp + ((size_t)s_begin * 4 * nb32 + (n0 >> 5) + wn * TN) * 256 + lane * 4;
+  int b_step = s_begin;
+  auto load_b = [&](float4 (&b)[4][TN]) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(bp + (size_t)j * 256);
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[kb][j] = *reinterpret_cast<const float4*>(bptr + ((size_t)kb * nb32 + j) * 256);
+    const int adv = (b_step + 1 < s_end) ? 1 : 0;
+    b_step += adv;
+    bptr += adv ? b_stride : 0;
   };
-  float4 bcur[TN], bnext[TN];
-  if (s_begin < s_end) load_b(s_begin, 0, bcur);
+
+  // Software pipeline, one step = 32 k = 16*TM*TN MFMAs per wave:
+  //   * the B fragments of step s+1 and the A tile of step s+2 are requested DURING the MFMAs
+  //     of step s, one VMEM instruction every Q MFMAs (sched_group_barrier): a 16-byte global
+  //     load costs ~60 cycles of in-order issue, which hides under a 64-cycle fp32 MFMA but
+  //     stalls the matrix pipe when ten of them are issued back to back (measured: 13-17 us of
+  //     a 55 us layer, tools/ubench/gemm_ablate.hip);
+  //   * the loop is unrolled by two with NAMED register sets (b0/b1, ra0/ra1): no register
+  //     copies, which would force a wait on the prefetch;
+  //   * end of step: A tile s+1 -> other LDS buffer, one barrier.
+  constexpr int NMFMA = 16 * TM * TN;
+  constexpr int NLOAD = 4 * TN + APASS;
+  constexpr int Q = NMFMA / NLOAD > 0 ? NMFMA / NLOAD : 1;
   int cur = 0;
-  for (int s = s_begin; s < s_end; ++s) {
-    // the last iteration re-fetches its own tile / B block (clamped index) instead of
-    // branching: harmless, and the loop body stays branch-free
-    const int sn = (s + 1 < s_end) ? s + 1 : s;
+  float4 af[4][TM];
+  auto step = [&](const float4 (&bc)[4][TN], float4 (&bn)[4][TN], const float4 (&a_st)[APASS],
+                  unsigned ok_st, float4 (&a_ld)[APASS], unsigned& ok_ld) {
     const float* la = &lds[cur * BM * LDA + frag_row * LDA + frag_k];
+    if (!(ABL & 8)) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[kb][i] = *reinterpret_cast<const float4*>(la + i * 32 * LDA + kb * 8);
+    }
+    if (!(ABL & 2)) load_b(bn);
+    if (!(ABL & 1)) load_a(a_ld, ok_ld);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      if (kb < 3) load_b(s, kb + 1, bnext);
-      else load_b(sn, 0, bnext);
-      float4 a[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const float4*>(la + i * 32 * LDA + kb * 8);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, bcur[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, bcur[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, bcur[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, bcur[j].w, acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kb][i].x, bc[kb][j].x, acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bcur[j] = bnext[j];
-      if (kb == 0) {
-        // next A tile: issued behind the first MFMA block so that block's operands are not
-        // queued behind it; it lands under the remaining three blocks
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(sn);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kb][i].y, bc[kb][j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kb][i].z, bc[kb][j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kb][i].w, bc[kb][j].w, acc[i][j], 0, 0, 0);
     }
-    store_a(cur ^ 1);
-    __syncthreads();
+    // issue order: all A-fragment reads, then {Q MFMAs, 1 global load} x NLOAD, then the rest
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * TM, 0);
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - Q * NLOAD > 0 ? NMFMA - Q * NLOAD : 0, 0);
+    if (!(ABL & 4)) {
+      store_a(cur ^ 1, a_st, ok_st);     // tile of step s+1, requested one full step ago
+      // the LDS stores stay behind the last MFMA: hoisted into the block they would need their
+      // operands early and drain the in-flight prefetches (vmcnt(0)) mid-step
+      __builtin_amdgcn_sched_group_barrier(0x200, APASS, 0);
+      __syncthreads();
+    }
     cur ^= 1;
+  };
+  float4 b0[4][TN], b1[4][TN];
+  float4 ra0[APASS], ra1[APASS];
+  unsigned ok0 = 0, ok1 = 0;
+  if (s_begin < s_end) {
+    load_a(ra0, ok0);          // tile s_begin
+    load_b(b0);                // B of s_begin
+    store_a(0, ra0, ok0);
+    load_a(ra0, ok0);          // tile s_begin+1 (in flight while step s_begin computes)
+    if (ABL) {                 // give every register set a defined value for the ablated variants
+      ra1[0] = ra0[0];
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) ra1[i] = ra0[i];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b1[kb][j] = b0[kb][j];
+    }
   }
+  __syncthreads();
+  if ((ABL & 16) && threadIdx.x == 0 && dbg_n < 15) d.dbg[(size_t)blockIdx.x * 16 + dbg_n++] = __builtin_readcyclecounter();
+  if (ABL & 8) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[kb][i] = *reinterpret_cast<const float4*>(&lds[frag_row * LDA + frag_k + i * 32 * LDA + kb * 8]);
+  }
+  int s = s_begin;
+  for (; s + 1 < s_end; s += 2) {
+    step(b0, b1, ra0, ok0, ra1, ok1);
+    step(b1, b0, ra1, ok1, ra0, ok0);
+  }
+  if (s < s_end) step(b0, b1, ra0, ok0, ra1, ok1);
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31,
-  //      row = (r&3) + 8*(r>>2) + 4*(lane>>5)  (cdna_hip_programming.md §3) ----------
+  //      row = (r&3) + 8*(r>>2) + 4*(lane>>5)  (cdna_hip_programming.md section 3) -------------
+  if ((ABL & 16) && threadIdx.x == 0 && dbg_n < 15) d.dbg[(size_t)blockIdx.x * 16 + dbg_n++] = __builtin_readcyclecounter();
+  // (the lane id is made opaque here: otherwise LICM hoists all of this lane-dependent address
+  //  arithmetic out of the segment loop and keeps ~100 VGPRs live across the K loop)
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-    const float bv = (S == 1) ? p.bias[col] : 0.f;
+    const int lcol = wn * (BN / 2) + j * 32 + (lane_e & 31);
+    const float bv = complete ? p.bias[n0 + lcol] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < p.M) {
-          float v = acc[i][j][r];
-          if (S == 1) {
+        const int lrow = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane_e >> 5);
+        float v = acc[i][j][r];
+        if (complete) {
+          if (m0 + lrow < p.M) {
             v += bv;
             if (p.relu) v = fmaxf(v, 0.f);
-            p.out[(size_t)row * p.ldc + col] = v;
-          } else {
-            d.ws[((size_t)z * p.M + row) * p.N + col] = v;
+            p.out[(size_t)(m0 + lrow) * p.ldc + n0 + lcol] = v;
           }
+        } else {
+          d.ws[((size_t)slot * BM + lrow) * BN + lcol] = v;
         }
       }
     }
   }
+  if ((ABL & 16) && threadIdx.x == 0 && dbg_n < 15) d.dbg[(size_t)blockIdx.x * 16 + dbg_n++] = __builtin_readcyclecounter();
+  }  // segment loop
+  if ((ABL & 16) && threadIdx.x == 0) d.dbg[(size_t)blockIdx.x * 16 + 15] = dbg_n;
 }
 
-// out[m][n] = act(sum_s ws[s][m][n] + bias[row(m)][n]);  float4 per thread
+// Sum the partial slabs of every tile that stream-K cut, in workgroup order; + bias, ReLU.
+// grid = (tiles, BM*BN/1024); a tile finished in place by one workgroup returns immediately.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void streamk_fixup(const GemmDev d) {
+  const GemmParams& p = d.p;
+  const int tile = blockIdx.x;
+  const long KS = d.ksteps, tb = (long)tile * KS, te = tb + KS;
+  int w = (int)((tb * d.W) / d.units);
+  while (w + 1 < d.W && unit_begin(d.units, d.W, w + 1) <= tb) ++w;
+  while (w > 0 && unit_begin(d.units, d.W, w) > tb) --w;
+  if (unit_begin(d.units, d.W, w) <= tb && unit_begin(d.units, d.W, w + 1) >= te) return;
+  const int idx4 = blockIdx.y * 256 + threadIdx.x;
+  const int lrow = idx4 / (BN / 4), lcol = (idx4 - lrow * (BN / 4)) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (; w < d.W; ++w) {
+    const long wb = unit_begin(d.units, d.W, w), we = unit_begin(d.units, d.W, w + 1);
+    if (wb >= te) break;
+    if (we <= wb) continue;  // empty range (W > units)
+    const int slot = (wb >= tb) ? 2 * w : 2 * w + 1;  // segment starts the workgroup's range?
+    const float4 u = *reinterpret_cast<const float4*>(d.ws + ((size_t)slot * BM + lrow) * BN + lcol);
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  const int mt = tile / d.ntiles, nt = tile - mt * d.ntiles;
+  const int row = mt * BM + lrow, col = nt * BN + lcol;
+  if (row >= p.M) return;
+  const float4 bv = *reinterpret_cast<const float4*>(p.bias + col);
+  v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+  if (p.relu) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  }
+  *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + col) = v;
+}
+
+// out[m][n] = act(sum_s ws[s][m][n] + bias[row(m)][n]).  One float4 column group per CG
+// threads; the S partial slabs are split over SL "s-lanes" of the block (independent loads in
+// flight instead of one latency-serial chain) and combined through LDS in a fixed order, so the
+// result is deterministic.  SL is chosen by the launcher from the amount of parallelism M*N/4.
+template <int SL>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S,
                                                             int M, int N,
                                                             const float* __restrict__ bias,
                                                             int rows_per_bias, int relu,
                                                             float* __restrict__ out, int ldc) {
+  constexpr int CG = 256 / SL;
+  __shared__ float4 red[SL > 1 ? SL : 1][CG];
+  const int sl = threadIdx.x / CG, cg = threadIdx.x - sl * CG;
   const size_t n4 = (size_t)N >> 2;
   const size_t total = (size_t)M * n4;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const size_t m = i / n4;
-    const int c = (int)(i - m * n4) * 4;
-    float4 v = *reinterpret_cast<const float4*>(ws + m * N + c);
-    for (int s = 1; s < S; ++s) {
-      const float4 u = *reinterpret_cast<const float4*>(ws + ((size_t)s * M + m) * N + c);
+  const size_t i = (size_t)blockIdx.x * CG + cg;
+  const bool live = i < total;
+  const size_t m = live ? i / n4 : 0;
+  const int c = live ? (int)(i - m * n4) * 4 : 0;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const float* p = ws + m * N + c;
+    const size_t slab = (size_t)M * N;
+#pragma unroll 4
+    for (int s = sl; s < S; s += SL) {
+      const float4 u = *reinterpret_cast<const float4*>(p + (size_t)s * slab);
       v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
-    const size_t brow = rows_per_bias ? m / rows_per_bias : 0;
-    const float4 bv = *reinterpret_cast<const float4*>(bias + brow * N + c);
-    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-    if (relu) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
-    *reinterpret_cast<float4*>(out + m * ldc + c) = v;
   }
+  if (SL > 1) {
+    red[sl][cg] = v;
+    __syncthreads();
+    if (sl != 0) return;
+#pragma unroll
+    for (int k = 1; k < SL; ++k) {
+      const float4 u = red[k][cg];
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+  }
+  if (!live) return;
+  const size_t brow = rows_per_bias ? m / rows_per_bias : 0;
+  const float4 bv = *reinterpret_cast<const float4*>(bias + brow * N + c);
+  v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+  if (relu) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  }
+  *reinterpret_cast<float4*>(out + m * ldc + c) = v;
 }
 
 // packed[((k/8)*(N/32) + n/32)*256 + lane*4 + t] = W[8*(k/8) + 4*(lane>>5) + t][32*(n/32)+(lane&31)]
@@ -290,53 +456,75 @@ __global__ __launch_bounds__(256) void pack_kn_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static bool parse_force(int* bm, int* bn, int* s) {
-  const char* e = std::getenv("DISN_GEMM_FORCE");  // "BM,BN,S" -- tuning/debug only
+static bool parse_force(int* bm, int* bn, int* w) {
+  const char* e = std::getenv("DISN_GEMM_FORCE");  // "BM,BN,W" -- tuning/debug only
   if (!e) return false;
-  return std::sscanf(e, "%d,%d,%d", bm, bn, s) == 3;
+  return std::sscanf(e, "%d,%d,%d", bm, bn, w) == 3;
+}
+
+static size_t slab_bytes(int bm, int bn, int W) { return (size_t)2 * W * bm * bn * sizeof(float); }
+
+static bool needs_fixup(long tiles, int ksteps, int W) {
+  const long U = tiles * ksteps;
+  return !(U % W == 0 && (U / W) % ksteps == 0);
 }
 
 GemmPlan gemm_plan(int M, int N, int K, size_t max_ws) {
   const int ksteps = K / 32;
   const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-  const int svals[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 36};
   double best = 1e300;
   GemmPlan plan{64, 64, 1, 0};
   for (auto& c : cand) {
     const int bm = c[0], bn = c[1];
     if (N % bn) continue;
-    const long wgs = (long)((M + bm - 1) / bm) * (N / bn);
-    const int tiles = (bm / 64) * (bn / 64);
-    for (int s : svals) {
-      if (s > 1 && (ksteps % s || ksteps / s < 4)) continue;
-      // split-K needs S partial slabs: never plan beyond the caller's workspace
-      if (s > 1 && (size_t)s * M * N * sizeof(float) > max_ws) continue;
-      // cost model (cycles): CU rounds x per-WG time (+ split-K reduce pass).
-      // Co-residency: small tiles fit 3 WGs per CU, 128x128 fits 2.
-      const int per_cu = tiles >= 4 ? 2 : 3;
-      const double rounds = (double)((wgs * s + 256L * per_cu - 1) / (256L * per_cu));
-      const double step = tiles * 16.0 * 64.0 + 500.0;  // MFMA issue + per-step overhead
-      const double wg = (ksteps / s) * step * per_cu + 4000.0;
-      double cost = rounds * wg;
-      if (s > 1) cost += 6000.0 + (double)s * M * N * 8.0 / 2000.0;  // ~4.8 TB/s at 2.4 GHz
+    const long tiles = (long)((M + bm - 1) / bm) * (N / bn);
+    const long U = tiles * ksteps;
+    const int tq = (bm / 64) * (bn / 64);           // 32x32 MFMA tiles per wave
+    const double unit = tq * 16.0 * 64.0;            // MFMA cycles of one k-step per wave
+    const int occ = tq >= 4 ? 2 : (tq == 2 ? 3 : 5); // co-resident workgroups per CU (VGPR bound)
+    // candidate workgroup counts: data-parallel (one tile each) and stream-K over 256*G
+    long wlist[4] = {tiles, 256, 512, 768};
+    for (long W : wlist) {
+      if (W > U) W = U;
+      if (W < 1) continue;
+      const bool fix = needs_fixup(tiles, ksteps, (int)W);
+      if (fix && slab_bytes(bm, bn, (int)W) > max_ws) continue;
+      const long per_wg = (U + W - 1) / W;          // k-steps of the busiest workgroup
+      const long resident = W < 256L * occ ? (W + 255) / 256 : occ;   // per CU at a time
+      const double rounds = (double)((W + 256L * resident - 1) / (256L * resident));
+      // a wave alone on its SIMD loses ~20 % to the per-step LDS/barrier bubble; two hide it
+      const double eff = resident >= 2 ? 0.93 : 0.80;
+      double cost = rounds * per_wg * unit * resident / eff + 6000.0;
+      cost += 600.0 * ((W + 255) / 256);            // prologue/epilogue per workgroup round
+      if (fix) {
+        const double segs = (double)W + (double)(tiles < W ? tiles : W);
+        cost += 7000.0 + segs * bm * bn * 8.0 / 1500.0;  // slab write + read at ~3.3 TB/s
+      }
       if (cost < best) {
         best = cost;
-        plan.bm = bm; plan.bn = bn; plan.splitk = s;
+        plan.bm = bm; plan.bn = bn; plan.wgs = (int)W;
       }
     }
   }
-  int fbm, fbn, fs;
-  if (parse_force(&fbm, &fbn, &fs) && (fbm == 64 || fbm == 128) && (fbn == 64 || fbn == 128) &&
-      N % fbn == 0 && fs >= 1 && fs <= ksteps &&
-      (fs == 1 || (size_t)fs * M * N * sizeof(float) <= max_ws)) {
-    plan.bm = fbm; plan.bn = fbn; plan.splitk = fs;
+  int fbm, fbn, fw;
+  if (parse_force(&fbm, &fbn, &fw) && (fbm == 64 || fbm == 128) && (fbn == 64 || fbn == 128) &&
+      N % fbn == 0 && fw >= 1) {
+    const long tiles = (long)((M + fbm - 1) / fbm) * (N / fbn);
+    if (fw > tiles * ksteps) fw = (int)(tiles * ksteps);
+    if (!needs_fixup(tiles, ksteps, fw) || slab_bytes(fbm, fbn, fw) <= max_ws) {
+      plan.bm = fbm; plan.bn = fbn; plan.wgs = fw;
+    }
   }
-  plan.ws_bytes = plan.splitk > 1 ? (size_t)plan.splitk * M * N * sizeof(float) : 0;
+  {
+    const long tiles = (long)((M + plan.bm - 1) / plan.bm) * (N / plan.bn);
+    plan.ws_bytes = needs_fixup(tiles, ksteps, plan.wgs) ? slab_bytes(plan.bm, plan.bn, plan.wgs) : 0;
+  }
   return plan;
 }
 
 template <int BM, int BN>
-static hipError_t launch_mode(const GemmDev& d, GemmMode mode, dim3 grid, hipStream_t st) {
+static hipError_t launch_mode(const GemmDev& d, GemmMode mode, bool fix, hipStream_t st) {
+  const dim3 grid(d.W);
   switch (mode) {
     case GEMM_DENSE:
       hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, GEMM_DENSE>), grid, dim3(256), 0, st, d);
@@ -348,6 +536,10 @@ static hipError_t launch_mode(const GemmDev& d, GemmMode mode, dim3 grid, hipStr
       hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, GEMM_CONV3_C3>), grid, dim3(256), 0, st, d);
       break;
   }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !fix) return e;
+  hipLaunchKernelGGL((streamk_fixup<BM, BN>), dim3(d.mtiles * d.ntiles, BM * BN / 1024), dim3(256), 0,
+                     st, d);
   return hipGetLastError();
 }
 
@@ -359,27 +551,37 @@ hipError_t gemm_launch(const GemmParams& p, GemmMode mode, const GemmPlan& plan,
   d.ksteps = p.K / 32;
   d.mtiles = (p.M + plan.bm - 1) / plan.bm;
   d.ntiles = p.N / plan.bn;
-  dim3 grid(d.mtiles * d.ntiles, plan.splitk);
-  hipError_t e;
-  if (plan.bm == 128 && plan.bn == 128) e = launch_mode<128, 128>(d, mode, grid, st);
-  else if (plan.bm == 128) e = launch_mode<128, 64>(d, mode, grid, st);
-  else if (plan.bn == 128) e = launch_mode<64, 128>(d, mode, grid, st);
-  else e = launch_mode<64, 64>(d, mode, grid, st);
-  if (e != hipSuccess) return e;
-  if (plan.splitk > 1)
-    return splitk_reduce_launch(ws, plan.splitk, p.M, p.N, p.bias, p.rows_per_bias, p.relu, p.out,
-                                p.ldc, st);
-  return hipSuccess;
+  d.W = plan.wgs;
+  d.units = (long)d.mtiles * d.ntiles * d.ksteps;
+  d.dbg = nullptr;
+  const bool fix = plan.ws_bytes != 0;
+  if (plan.bm == 128 && plan.bn == 128) return launch_mode<128, 128>(d, mode, fix, st);
+  if (plan.bm == 128) return launch_mode<128, 64>(d, mode, fix, st);
+  if (plan.bn == 128) return launch_mode<64, 128>(d, mode, fix, st);
+  return launch_mode<64, 64>(d, mode, fix, st);
 }
 
 hipError_t splitk_reduce_launch(const float* ws, int S, int M, int N, const float* bias,
                                 int rows_per_bias, int relu, float* out, int ldc, hipStream_t st) {
   const size_t total = (size_t)M * (N / 4);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, S, M, N, bias,
-                     rows_per_bias, relu, out, ldc);
+  // enough column groups to fill the chip -> 1 s-lane; otherwise spread S over 4 or 16 lanes
+  const int sl = (total >= 131072 || S < 4) ? 1 : ((total >= 16384 || S < 16) ? 4 : 16);
+  const int cg = 256 / sl;
+  const unsigned blocks = (unsigned)((total + cg - 1) / cg);
+  switch (sl) {
+    case 1:
+      hipLaunchKernelGGL((splitk_reduce_kernel<1>), dim3(blocks), dim3(256), 0, st, ws, S, M, N, bias,
+                         rows_per_bias, relu, out, ldc);
+      break;
+    case 4:
+      hipLaunchKernelGGL((splitk_reduce_kernel<4>), dim3(blocks), dim3(256), 0, st, ws, S, M, N, bias,
+                         rows_per_bias, relu, out, ldc);
+      break;
+    default:
+      hipLaunchKernelGGL((splitk_reduce_kernel<16>), dim3(blocks), dim3(256), 0, st, ws, S, M, N,
+                         bias, rows_per_bias, relu, out, ldc);
+      break;
+  }
   return hipGetLastError();
 }
 

@@ -28,11 +28,11 @@ struct GemmParams {
 };
 
 struct GemmPlan {
-  int bm, bn, splitk;
-  size_t ws_bytes;  // split-K partial slabs (0 when splitk == 1)
+  int bm, bn, wgs;  // tile shape and number of (stream-K) workgroups
+  size_t ws_bytes;  // stream-K partial slabs (0 when every workgroup owns whole tiles)
 };
 
-// max_ws bounds the split-K partial slabs the plan may use (the plan is a pure speed choice)
+// max_ws bounds the stream-K partial slabs the plan may use (the plan is a pure speed choice)
 GemmPlan gemm_plan(int M, int N, int K, size_t max_ws = ~size_t(0));
 hipError_t gemm_launch(const GemmParams& p, GemmMode mode, const GemmPlan& plan, float* ws,
                        hipStream_t st);

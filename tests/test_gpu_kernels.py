@@ -165,9 +165,12 @@ def test_conv3x3_vs_oracle(ops, B, H, W, Cin, Cout):
     report_close("conv3x3 %s" % ((B, H, W, Cin, Cout),), got, ref, atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("force", ["128,128,1", "128,64,1", "64,128,1", "64,64,1", "64,64,4", "128,128,3", "64,128,9"])
+@pytest.mark.parametrize("force", ["128,128,6", "128,64,12", "64,128,12", "64,64,24",   # data-parallel (W = tiles)
+                                   "64,64,96", "128,128,18",                              # split-K (W = tiles*S)
+                                   "128,128,7", "64,128,256", "64,64,500", "128,64,1", "64,64,864"])  # stream-K
 def test_conv3x3_every_tile_config_and_splitk(ops, force, monkeypatch):
-    """every tile shape and the split-K path give the same answer (tile choice is a pure speed knob)"""
+    """every tile shape and every stream-K workgroup count (BM,BN,W) gives the same answer: the
+    plan is a pure speed knob.  M = 380 rows, N = 256, 36 k-steps."""
     monkeypatch.setenv("DISN_GEMM_FORCE", force)
     rng = np.random.default_rng(11)
     B, H, W, Cin, Cout = 1, 20, 19, 128, 256          # M = 380 (ragged), ksteps = 36
