@@ -98,8 +98,8 @@ def main():
                       dtype=torch.float32, device=dev)       # demo/demo.py:272-276
 
     def step():
-        enc = eng.encode(img)                                  # rows A, B, C, E -- every step
-        return eng.query(enc, pts, tm)                         # rows D, F, G, H
+        # rows A..H, every step, through the single overlapped entry (disn_encode_query)
+        return eng.encode_query(img, pts, tm)[1]
 
     for _ in range(args.warmup):
         out = step()

@@ -66,6 +66,13 @@ SIGNATURES = {
     "disn_sdf_mlp": (I, [C.POINTER(MlpWeights), P, P, P, I, I, P, P, P, P, Z, P]),
     "disn_query_workspace_bytes": (Z, [I, I]),
     "disn_query": (I, [C.POINTER(MlpWeights), P, P, P, P, P, I, I, P, P, Z, P]),
+    "disn_ctx_create": (I, [C.POINTER(C.c_void_p)]),
+    "disn_ctx_destroy": (I, [P]),
+    "disn_encode_workspace_bytes": (Z, [I]),
+    "disn_encode": (I, [P, C.POINTER(VggWeights), P, I, P, C.POINTER(C.c_void_p * 5), P, P, P, Z, P]),
+    "disn_encode_query_workspace_bytes": (Z, [I, I]),
+    "disn_encode_query": (I, [P, C.POINTER(VggWeights), C.POINTER(MlpWeights), P, P, P, P, I, I, P,
+                              C.POINTER(C.c_void_p * 5), P, P, P, P, Z, P]),
     "disn_grid_points": (I, [C.POINTER(C.c_double * 6), I, L, L, P, P]),
     "disn_query_grid_workspace_bytes": (Z, [L]),
     "disn_query_grid": (I, [C.POINTER(MlpWeights), P, P, P, C.POINTER(C.c_double * 6), I, L, L, F, P,

@@ -4,6 +4,8 @@
 
 #include "kernels.hpp"
 
+#include <new>
+
 using namespace disn;
 
 #define DISN_TRY(expr)                    \
@@ -285,25 +287,35 @@ size_t disn_vgg16_workspace_bytes(int B) {
   return vgg_layout(nullptr, B, DISN_EMBED_DIM).total;
 }
 
-int disn_vgg16_forward(const disn_vgg_weights_t* w, const float* img, int B, float* resized224,
-                       float* const taps[5], float* embedding, void* ws, size_t ws_bytes,
-                       void* stream) {
-  if (!w || !img || !taps || !embedding || !ws || B <= 0) return DISN_E_ARG;
-  for (int i = 0; i < 5; ++i)
-    if (!taps[i]) return DISN_E_ARG;
+}  // extern "C"
+
+struct disn_ctx {
+  hipStream_t aux;
+  hipEvent_t ev[8];  // 0: fork, 1..5: tap ready, 6: aux done, 7: spare
+};
+
+namespace {
+
+const int kTapHw[5] = {224, 112, 56, 28, 14}, kTapCh[5] = {64, 128, 256, 512, 512};
+const int kTapOff[5] = {0, 64, 192, 448, 960};
+
+bool vgg_weights_ok(const disn_vgg_weights_t* w) {
+  if (!w) return false;
   for (int i = 0; i < 13; ++i)
-    if (!w->conv_w[i] || !w->conv_b[i]) return DISN_E_ARG;
+    if (!w->conv_w[i] || !w->conv_b[i]) return false;
   for (int i = 0; i < 3; ++i)
-    if (!w->fc_w[i] || !w->fc_b[i]) return DISN_E_ARG;
-  if (w->num_classes <= 0 || w->num_classes % 256) return DISN_E_SHAPE;
-  hipStream_t st = (hipStream_t)stream;
-  const VggWs s = vgg_layout(ws, B, w->num_classes);
-  if (s.total > ws_bytes) return DISN_E_WS;
-  float* resized = resized224 ? resized224 : s.resized;
-  // row A: 137 -> 224 legacy bilinear  (models/model_normalization.py:65-72)
+    if (!w->fc_w[i] || !w->fc_b[i]) return false;
+  return true;
+}
+
+// rows A, B (+E when featmap != nullptr): resize, conv stack, pools.  With a context the five
+// tap up-samples (HBM-write bound, 110 MB) run on ctx->aux as soon as their tap is final, under
+// the MFMA-bound convolutions that follow on `st`.  Returns pool5 in *pool5.
+int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, int B, float* resized,
+                 float* const taps[5], float* featmap, const VggWs& s, const float** pool5,
+                 hipStream_t st) {
   DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, resized, DISN_VGG_SIZE,
                                   DISN_VGG_SIZE, 3, 0, st));
-  // row B: conv stack  (models/CNN/vgg.py:187-196)
   const float* x = resized;
   bool toggle = false;
   const size_t gws_cap = (size_t)((char*)s.fc_ws - (char*)s.gemm_ws);
@@ -315,19 +327,202 @@ int disn_vgg16_forward(const disn_vgg_weights_t* w, const float* img, int B, flo
                                 out, s.gemm_ws, gws_cap, st);
     if (rc) return rc;
     x = out;
+    if (L.tap >= 0 && featmap) {
+      hipStream_t rs = st;
+      if (ctx) {
+        DISN_TRY(hipEventRecord(ctx->ev[1 + L.tap], st));
+        DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[1 + L.tap], 0));
+        rs = ctx->aux;
+      }
+      DISN_TRY(resize_bilinear_launch(taps[L.tap], B, kTapHw[L.tap], kTapHw[L.tap], kTapCh[L.tap],
+                                      featmap, DISN_IMG_H, DISN_IMG_W, DISN_FEAT_DIM,
+                                      kTapOff[L.tap], rs));
+    }
     if (kPoolAfter[i]) {
       DISN_TRY(maxpool2x2_launch(x, B, L.hw, L.hw, L.cout, s.bufP, st));
       x = s.bufP;
       toggle = false;
     }
   }
-  // row C: fc6 (7x7 VALID == dense over the NHWC-flattened pool5), fc7, fc8
-  // (models/CNN/vgg.py:198-214; dropout inactive: is_training=False, model_normalization.py:76)
-  DISN_TRY(gemv_launch(x, B, 25088, w->fc_w[0], w->fc_b[0], 4096, 1, s.fc6, s.fc_ws, st));
+  *pool5 = x;
+  return 0;
+}
+
+// row C: fc6 (7x7 VALID == dense over the NHWC-flattened pool5), fc7, fc8
+// (models/CNN/vgg.py:198-214; dropout inactive: is_training=False, model_normalization.py:76)
+int vgg_head(const disn_vgg_weights_t* w, const float* pool5, int B, float* embedding,
+             const VggWs& s, hipStream_t st) {
+  DISN_TRY(gemv_launch(pool5, B, 25088, w->fc_w[0], w->fc_b[0], 4096, 1, s.fc6, s.fc_ws, st));
   DISN_TRY(gemv_launch(s.fc6, B, 4096, w->fc_w[1], w->fc_b[1], 4096, 1, s.fc7, s.fc_ws, st));
   DISN_TRY(gemv_launch(s.fc7, B, 4096, w->fc_w[2], w->fc_b[2], w->num_classes, 0, embedding,
                        s.fc_ws, st));
   return 0;
+}
+
+// MLP phase 1: everything that does not need the image embedding -- the whole local stream
+// (models/sdfnet.py:173-186) and the global stream up to fold1/conv3 (models/sdfnet.py:71-76).
+// Leaves l5 in s.l5 and the global fold1 output in s.h512a.
+int mlp_phase1(const disn_mlp_weights_t* w, const float* pts_rot, int n, const float* feat,
+               const MlpWs& s, hipStream_t st) {
+  int rc;
+  DISN_TRY(pt_embed_launch(pts_rot, n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g, s.e1l, st));
+  if ((rc = dense_layer(s.e1l, 64, 64, nullptr, 0, 64, n, w->l_w2, w->l_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->l_w3, w->l_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h512a, 512, 512, feat, DISN_FEAT_DIM, 512 + DISN_FEAT_DIM, n, w->l_w4, w->l_b4, 512, s.h512b, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->l_w5, w->l_b5, 256, s.l5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.e1g, 64, 64, nullptr, 0, 64, n, w->g_w2, w->g_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->g_w3, w->g_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  return 0;
+}
+
+// MLP phase 2: the part behind the embedding -- global fold2 (per-image folded bias) and the sum.
+int mlp_phase2(const disn_mlp_weights_t* w, int B, int N, const float* gbias, float* sdf,
+               const MlpWs& s, hipStream_t st) {
+  int rc;
+  for (int b = 0; b < B; ++b) {
+    const size_t o = (size_t)b * N;
+    if ((rc = dense_layer(s.h512a + o * 512, 512, 512, nullptr, 0, 512, N, w->g_w4_point,
+                          gbias + (size_t)b * 512, 512, s.h512b + o * 512, s.gemm_ws,
+                          s.gemm_ws_bytes, st)))
+      return rc;
+  }
+  const int n = B * N;
+  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->g_w5, w->g_b5, 256, s.g5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, nullptr, nullptr,
+                            1.0f, st));
+  return 0;
+}
+
+struct EncQueryWs {
+  VggWs vgg;
+  QueryWs q;
+  size_t total;
+};
+
+EncQueryWs encq_layout(void* ws, int B, int N, int num_classes) {
+  EncQueryWs e;
+  e.vgg = vgg_layout(ws, B, num_classes);
+  char* base = ws ? static_cast<char*>(ws) + e.vgg.total : nullptr;
+  e.q = query_layout(base, B, B * N, true, false);
+  e.total = e.vgg.total + e.q.total;
+  return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int disn_ctx_create(disn_ctx_t** out) {
+  if (!out) return DISN_E_ARG;
+  disn_ctx* c = new (std::nothrow) disn_ctx();
+  if (!c) return DISN_E_ARG;
+  hipError_t e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+  for (int i = 0; i < 8 && e == hipSuccess; ++i)
+    e = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
+  if (e != hipSuccess) {
+    delete c;
+    return (int)e;
+  }
+  *out = c;
+  return 0;
+}
+
+int disn_ctx_destroy(disn_ctx_t* c) {
+  if (!c) return DISN_E_ARG;
+  (void)hipStreamSynchronize(c->aux);
+  for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->ev[i]);
+  (void)hipStreamDestroy(c->aux);
+  delete c;
+  return 0;
+}
+
+int disn_vgg16_forward(const disn_vgg_weights_t* w, const float* img, int B, float* resized224,
+                       float* const taps[5], float* embedding, void* ws, size_t ws_bytes,
+                       void* stream) {
+  if (!vgg_weights_ok(w) || !img || !taps || !embedding || !ws || B <= 0) return DISN_E_ARG;
+  for (int i = 0; i < 5; ++i)
+    if (!taps[i]) return DISN_E_ARG;
+  if (w->num_classes <= 0 || w->num_classes % 256) return DISN_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const VggWs s = vgg_layout(ws, B, w->num_classes);
+  if (s.total > ws_bytes) return DISN_E_WS;
+  const float* pool5 = nullptr;
+  int rc = vgg_features(nullptr, w, img, B, resized224 ? resized224 : s.resized, taps, nullptr, s,
+                        &pool5, st);
+  if (rc) return rc;
+  return vgg_head(w, pool5, B, embedding, s, st);
+}
+
+size_t disn_encode_workspace_bytes(int B) { return disn_vgg16_workspace_bytes(B); }
+
+int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, int B,
+                float* resized224, float* const taps[5], float* embedding, float* featmap, void* ws,
+                size_t ws_bytes, void* stream) {
+  if (!vgg_weights_ok(w) || !img || !taps || !embedding || !featmap || !ws || B <= 0)
+    return DISN_E_ARG;
+  for (int i = 0; i < 5; ++i)
+    if (!taps[i]) return DISN_E_ARG;
+  if (w->num_classes <= 0 || w->num_classes % 256) return DISN_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const VggWs s = vgg_layout(ws, B, w->num_classes);
+  if (s.total > ws_bytes) return DISN_E_WS;
+  if (ctx) {  // fork: the aux stream starts behind everything already queued on `st`
+    DISN_TRY(hipEventRecord(ctx->ev[0], st));
+    DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
+  }
+  const float* pool5 = nullptr;
+  int rc = vgg_features(ctx, w, img, B, resized224 ? resized224 : s.resized, taps, featmap, s, &pool5, st);
+  if (rc) return rc;
+  if ((rc = vgg_head(w, pool5, B, embedding, s, st))) return rc;
+  if (ctx) {  // join
+    DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
+    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
+  }
+  return 0;
+}
+
+size_t disn_encode_query_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0 || (long)B * N > kChunk) return 0;
+  return encq_layout(nullptr, B, N, DISN_EMBED_DIM).total;
+}
+
+int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_mlp_weights_t* mw,
+                      const float* img, const float* trans_mat, const float* pts,
+                      const float* pts_rot, int B, int N, float* resized224, float* const taps[5],
+                      float* embedding, float* featmap, float* sdf, void* ws, size_t ws_bytes,
+                      void* stream) {
+  if (!ctx || !vgg_weights_ok(vw) || !mlp_weights_ok(mw) || !img || !trans_mat || !pts || !pts_rot ||
+      !taps || !embedding || !featmap || !sdf || !ws || B <= 0 || N <= 0)
+    return DISN_E_ARG;
+  for (int i = 0; i < 5; ++i)
+    if (!taps[i]) return DISN_E_ARG;
+  if ((long)B * N > kChunk || vw->num_classes != DISN_EMBED_DIM) return DISN_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const EncQueryWs e = encq_layout(ws, B, N, vw->num_classes);
+  if (e.total > ws_bytes) return DISN_E_WS;
+  // fork
+  DISN_TRY(hipEventRecord(ctx->ev[0], st));
+  DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
+  // main: conv stack; aux: tap up-samples as the taps become final
+  const float* pool5 = nullptr;
+  int rc = vgg_features(ctx, vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap,
+                        e.vgg, &pool5, st);
+  if (rc) return rc;
+  // aux (MFMA bound): gather + every MLP layer that does not need the embedding ...
+  const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
+  for (int b = 0; b < B; ++b)
+    DISN_TRY(project_gather_launch(featmap + b * map_stride, trans_mat + (size_t)b * 12,
+                                   pts + (size_t)b * N * 3, N,
+                                   e.q.feat + (size_t)b * N * DISN_FEAT_DIM, ctx->aux));
+  if ((rc = mlp_phase1(mw, pts_rot, B * N, e.q.feat, e.q.mlp, ctx->aux))) return rc;
+  DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
+  // ... while main streams the 495 MB of fc6/fc7/fc8 weights (HBM bound) and folds the bias
+  if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
+  DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, mw->g_w4_global, mw->g_b4, 512, 0, e.q.gbias,
+                       e.q.gemv_ws, st));
+  // join, then the short tail behind the embedding
+  DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
+  return mlp_phase2(mw, B, N, e.q.gbias, sdf, e.q.mlp, st);
 }
 
 int disn_build_featmap(const float* const taps[5], int B, float* featmap, void* stream) {

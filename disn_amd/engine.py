@@ -91,6 +91,7 @@ class Encoded:
     taps: List[torch.Tensor]       # conv1_2, conv2_2, conv3_3, conv4_3, conv5_3 (native resolution)
     embedding: torch.Tensor        # [B,1024]        'img_embedding'
     featmap: torch.Tensor          # [B,137,137,1472] the five resized taps, channel-concatenated
+    pred: Optional[torch.Tensor] = None   # pred_sdf of the run that produced this state (encode_query)
 
 
 class SdfEngine:
@@ -102,7 +103,17 @@ class SdfEngine:
         self.device = torch.device(device)
         with torch.cuda.device(self.device):
             self.weights = DeviceWeights(store, self.device)
+            self._ctx = ops.ctx_create()      # aux HIP stream + events for the overlapped encoder
         self._ws: Dict[str, torch.Tensor] = {}
+
+    def __del__(self):
+        try:
+            ctx, self._ctx = getattr(self, "_ctx", None), None
+            if ctx:
+                with torch.cuda.device(self.device):
+                    ops.ctx_destroy(ctx)
+        except Exception:  # interpreter shutdown
+            pass
 
     def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
         t = self._ws.get(key)
@@ -121,10 +132,22 @@ class SdfEngine:
         imgs = self._dev(imgs)
         with torch.cuda.device(self.device):
             from ._lib import lib
-            ws = self._workspace("vgg", lib().disn_vgg16_workspace_bytes(imgs.shape[0]))
-            resized, taps, emb = ops.vgg16_forward(self.weights.vgg, imgs, ws)
-            featmap = ops.build_featmap(taps)
+            ws = self._workspace("vgg", lib().disn_encode_workspace_bytes(imgs.shape[0]))
+            resized, taps, emb, featmap = ops.encode(self._ctx, self.weights.vgg, imgs, ws)
         return Encoded(resized, taps, emb, featmap)
+
+    # rows A..H in one call: what ONE sess.run([pred_sdf]) of the reference executes
+    def encode_query(self, imgs, pts, trans_mat, pts_rot=None):
+        """-> (Encoded, pred_sdf [B,N]).  Nothing cached; B*N <= 65536.  The HBM-bound pieces
+        (feature-map write, fc weight stream) overlap the MFMA-bound ones on a second stream."""
+        imgs, pts, trans_mat = self._dev(imgs), self._dev(pts), self._dev(trans_mat)
+        pts_rot = pts if pts_rot is None else self._dev(pts_rot)
+        with torch.cuda.device(self.device):
+            from ._lib import lib
+            ws = self._workspace("encq", lib().disn_encode_query_workspace_bytes(pts.shape[0], pts.shape[1]))
+            resized, taps, emb, featmap, sdf = ops.encode_query(self._ctx, self.weights.vgg, self.weights.mlp,
+                                                                imgs, trans_mat, pts, pts_rot, ws)
+        return Encoded(resized, taps, emb, featmap), sdf
 
     # rows D, F, G, H
     def query(self, enc: Encoded, pts, trans_mat, pts_rot=None) -> torch.Tensor:

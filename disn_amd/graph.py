@@ -87,11 +87,20 @@ class Session:
         self._enc_val = None
 
     # -- encoder cache ---------------------------------------------------------------------
-    def encoded(self, imgs_np: np.ndarray):
+    def encoded(self, imgs_np: np.ndarray, pc=None, pc_rot=None, tm=None):
+        """Encoder state for the fed images.  When the state is not cached and the fed points fit
+        one launch sequence, encode and query run as ONE overlapped call (disn_encode_query) and
+        the prediction rides along as ``enc.pred`` for the pred_sdf node of the same run."""
         key = hashlib.blake2b(np.ascontiguousarray(imgs_np).view(np.uint8), digest_size=16).digest()
         if self.cache_encoder and key == self._enc_key:
+            self._enc_val.pred = None
             return self._enc_val
-        enc = self.engine.encode(imgs_np)
+        if pc is not None and pc.shape[0] * pc.shape[1] <= 65536:
+            enc, pred = self.engine.encode_query(imgs_np, pc, tm, pc_rot)
+            enc.pred = pred
+        else:
+            enc = self.engine.encode(imgs_np)
+            enc.pred = None
         if self.cache_encoder:
             self._enc_key, self._enc_val = key, enc
         return enc

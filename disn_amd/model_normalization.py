@@ -101,7 +101,10 @@ def get_model(ref_dict, num_point, is_training, bn=False, bn_decay=None, img_siz
     end_points['ref_img'] = ref_img                       # :62 -- the UN-resized input
 
     # rows A, B, C, E: resize 137->224 (:65-72), slim vgg_16 (:74-78), 5 up-sampled taps (:171-183)
-    enc = SymTensor('encoder', (), lambda sess, imgs: sess.encoded(imgs), (ref_img,))
+    # On an encoder-cache miss with a batch that fits one launch sequence the whole graph
+    # (encode + query) goes through the overlapped single entry disn_encode_query.
+    enc = SymTensor('encoder', (), lambda sess, imgs, pc, pc_rot, tm: sess.encoded(imgs, pc, pc_rot, tm),
+                    (ref_img, ref_sample_pc, ref_sample_pc_rot, ref_trans_mat))
     end_points['resized_ref_img'] = SymTensor('resized_ref_img', (B, 224, 224, 3),
                                               lambda sess, e: e.resized, (enc,))
     emb = SymTensor('img_embedding', (B, 1024), lambda sess, e: e.embedding, (enc,))
@@ -128,7 +131,7 @@ def get_model(ref_dict, num_point, is_training, bn=False, bn_decay=None, img_siz
     # row H (:204): pred_sdf = global + local.  The fetch every caller uses; it runs the fused
     # project -> gather -> two MLPs -> sum entry (disn_query) instead of the three separate nodes.
     def pred_fn(sess, e, pc, pc_rot, tm):
-        out = sess.engine.query(e, pc, tm, pc_rot)
+        out = e.pred if getattr(e, "pred", None) is not None else sess.engine.query(e, pc, tm, pc_rot)
         if F.tanh:                                         # :214-215 (off by default)
             import torch
             out = torch.tanh(out)

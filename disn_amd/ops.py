@@ -128,6 +128,65 @@ def vgg16_forward(w: VggWeights, img: torch.Tensor, ws: Optional[torch.Tensor] =
     return resized, taps, emb
 
 
+def ctx_create() -> int:
+    """Concurrency context (aux HIP stream + events) on the current device."""
+    h = C.c_void_p()
+    check("disn_ctx_create", lib().disn_ctx_create(C.byref(h)))
+    return h.value
+
+
+def ctx_destroy(ctx: int) -> None:
+    if ctx:
+        check("disn_ctx_destroy", lib().disn_ctx_destroy(ctx))
+
+
+def _alloc_encoder_outputs(B: int, num_classes: int, dev):
+    resized = torch.empty((B, 224, 224, 3), dtype=torch.float32, device=dev)
+    taps = [torch.empty((B, hw, hw, ch), dtype=torch.float32, device=dev) for hw, ch in TAP_SHAPES]
+    emb = torch.empty((B, num_classes), dtype=torch.float32, device=dev)
+    featmap = torch.empty((B, IMG, IMG, FEAT_DIM), dtype=torch.float32, device=dev)
+    return resized, taps, emb, featmap
+
+
+def encode(ctx: Optional[int], w: VggWeights, img: torch.Tensor, ws: Optional[torch.Tensor] = None):
+    """rows A, B, C, E -> (resized224, taps[5], embedding, featmap); the tap up-samples overlap the
+    convolutions on the context's auxiliary stream."""
+    img = _chk(img, "img")
+    B = img.shape[0]
+    if tuple(img.shape[1:]) != (IMG, IMG, 3):
+        raise ValueError("img must be [B,137,137,3] (models/model_normalization.py:249-250 hard-codes 137)")
+    resized, taps, emb, featmap = _alloc_encoder_outputs(B, w.num_classes, img.device)
+    need = lib().disn_encode_workspace_bytes(B)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, img.device)
+    tp = (C.c_void_p * 5)(*[t.data_ptr() for t in taps])
+    check("disn_encode", lib().disn_encode(ctx, C.byref(w), img.data_ptr(), B, resized.data_ptr(), C.byref(tp),
+                                           emb.data_ptr(), featmap.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return resized, taps, emb, featmap
+
+
+def encode_query(ctx: int, vw: VggWeights, mw: MlpWeights, img: torch.Tensor, trans_mat: torch.Tensor,
+                 pts: torch.Tensor, pts_rot: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
+    """One full evaluation of the graph for pred_sdf (what one sess.run executes), B*N <= 65536.
+    -> (resized224, taps, embedding, featmap, sdf [B,N])"""
+    img, pts, trans_mat = _chk(img, "img"), _chk(pts, "pts"), _chk(trans_mat, "trans_mat")
+    pts_rot = pts if pts_rot is None else _chk(pts_rot, "pts_rot")
+    B, N = pts.shape[0], pts.shape[1]
+    resized, taps, emb, featmap = _alloc_encoder_outputs(B, vw.num_classes, img.device)
+    sdf = torch.empty((B, N), dtype=torch.float32, device=img.device)
+    need = lib().disn_encode_query_workspace_bytes(B, N)
+    if need == 0:
+        raise ValueError("encode_query needs B*N <= 65536")
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, img.device)
+    tp = (C.c_void_p * 5)(*[t.data_ptr() for t in taps])
+    check("disn_encode_query", lib().disn_encode_query(
+        ctx, C.byref(vw), C.byref(mw), img.data_ptr(), trans_mat.data_ptr(), pts.data_ptr(), pts_rot.data_ptr(),
+        B, N, resized.data_ptr(), C.byref(tp), emb.data_ptr(), featmap.data_ptr(), sdf.data_ptr(),
+        ws.data_ptr(), ws.numel(), _stream()))
+    return resized, taps, emb, featmap, sdf
+
+
 def build_featmap(taps: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B = taps[0].shape[0]
     if out is None:

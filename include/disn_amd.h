@@ -165,6 +165,38 @@ int disn_query(const disn_mlp_weights_t* w, const float* featmap, const float* e
                float* sdf, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------- *
+ * Concurrency context.  The path mixes MFMA-bound launches (convolutions,  *
+ * MLP GEMMs) with HBM-bound ones (the 110 MB feature-map write, the 495 MB *
+ * fc6-fc8 weight stream) that do not depend on each other; disn_encode /   *
+ * disn_encode_query run the latter on the context's auxiliary HIP stream,  *
+ * forked from and joined back into the caller's `stream` with events, so   *
+ * the caller still sees ONE asynchronous operation on `stream`.            *
+ * A context owns one non-blocking stream and eight events; use one context *
+ * per caller stream (not thread-safe).  ctx may be NULL for disn_encode    *
+ * (everything then runs on `stream`).                                      *
+ * ---------------------------------------------------------------------- */
+typedef struct disn_ctx disn_ctx_t;
+int disn_ctx_create(disn_ctx_t** out);
+int disn_ctx_destroy(disn_ctx_t* ctx);
+
+/* Rows A, B, C, E for a batch of images: disn_vgg16_forward + disn_build_featmap
+ * (models/model_normalization.py:65-78 and :171-183).  featmap [B,137,137,1472]. */
+size_t disn_encode_workspace_bytes(int B);
+int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, int B,
+                float* resized224, float* const taps[5], float* embedding, float* featmap, void* ws,
+                size_t ws_bytes, void* stream);
+
+/* One full evaluation of the reference graph for pred_sdf, i.e. what ONE
+ * sess.run([pred_sdf]) executes (test/create_sdf.py:275): rows A..H, nothing cached.
+ * B*N <= 65536.  Outputs as disn_encode plus sdf [B,N]. */
+size_t disn_encode_query_workspace_bytes(int B, int N);
+int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw,
+                      const disn_mlp_weights_t* mw, const float* img, const float* trans_mat,
+                      const float* pts, const float* pts_rot, int B, int N, float* resized224,
+                      float* const taps[5], float* embedding, float* featmap, float* sdf, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------- *
  * Row J: dense grid -- test/create_sdf.py:246-256.  Flat index             *
  * k=(iz*(R+1)+iy)*(R+1)+ix -> (x_[ix], y_[iy], z_[iz]) with                *
  * x_=linspace(p0,p3,R+1) etc. evaluated in float64 then cast to float32    *

@@ -221,3 +221,30 @@ def test_encoder_cache_and_rerun_flag():
     assert a._enc_val is not e1                                  # different image bytes -> re-encode
     b = Session(WeightStore.random_init(0, mode="he"), cache_encoder=False)
     assert np.array_equal(b.run(ep["pred_sdf"], _feed(pls, feed)), p1) and b._enc_val is None
+
+
+@pytest.mark.parametrize("B,N", [(1, 2048), (2, 700), (3, 64)])
+def test_encode_query_equals_encode_plus_query(B, N):
+    """disn_encode_query (two streams, fork/join with events) == disn_encode + disn_query,
+    bit for bit, on every repetition: a missing dependency between the streams would show up as
+    a mismatch on some run."""
+    from disn_amd.engine import SdfEngine
+    from disn_amd.weights import WeightStore
+    eng = SdfEngine(WeightStore.random_init(0, mode="he"))
+    rng = np.random.default_rng(B * 100 + N)
+    tms = np.stack([O.DEMO_TRANS_MAT[0], O.synth_trans_mat(30, 25, 0.8), O.synth_trans_mat(201.5, 30, 0.65)])[:B]
+    for rep in range(6):
+        imgs = rng.random((B, 137, 137, 3), dtype=np.float32)
+        pts = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+        enc_a, sdf_a = eng.encode_query(imgs, pts, tms)
+        enc_b = eng.encode(imgs)
+        sdf_b = eng.query(enc_b, pts, tms)
+        torch.cuda.synchronize()
+        assert torch.equal(enc_a.embedding, enc_b.embedding), "embedding differs (rep %d)" % rep
+        assert torch.equal(enc_a.featmap, enc_b.featmap), "featmap differs (rep %d)" % rep
+        for ta, tb in zip(enc_a.taps, enc_b.taps):
+            assert torch.equal(ta, tb)
+        assert torch.equal(sdf_a, sdf_b), "pred_sdf differs (rep %d): max %g" % (rep, float((sdf_a - sdf_b).abs().max()))
+    ref = O.get_model({"imgs": imgs, "sample_pc": pts, "sample_pc_rot": pts, "trans_mat": tms},
+                      eng.weights and WeightStore.random_init(0, mode="he").arrays, dtype=np.float64)
+    report_close("encode_query vs oracle", sdf_a.cpu().numpy(), ref["pred_sdf"][..., 0], ATOL, RTOL)
