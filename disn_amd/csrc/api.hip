@@ -4,6 +4,7 @@
 
 #include "kernels.hpp"
 
+#include <cstdlib>
 #include <new>
 
 using namespace disn;
@@ -299,6 +300,22 @@ namespace {
 const int kTapHw[5] = {224, 112, 56, 28, 14}, kTapCh[5] = {64, 128, 256, 512, 512};
 const int kTapOff[5] = {0, 64, 192, 448, 960};
 
+// Which overlaps disn_encode / disn_encode_query use: bit 0 = tap up-samples on the aux stream
+// under the convolutions, bit 1 = MLP phase 1 on the aux stream under the fc head.
+// DISN_OVERLAP / DISN_RESIZE_BG_BLOCKS override the defaults (tuning / debugging only).
+int overlap_mask() {
+  // Measured on MI355X (tools/overlap_sweep.py, cfg2 step): none 0.886 ms; bit 1 only 0.797 ms;
+  // bit 0 only 0.892-0.979 ms at every throttle; both 0.863 ms.  The streamed 110 MB of
+  // up-sample writes disturb the latency-sensitive convolution loads more than they hide, so
+  // the default keeps them on the caller's stream and overlaps only the fc head.
+  const char* e = std::getenv("DISN_OVERLAP");
+  return e ? std::atoi(e) : 2;
+}
+int resize_bg_blocks() {
+  const char* e = std::getenv("DISN_RESIZE_BG_BLOCKS");
+  return e ? std::atoi(e) : 256;
+}
+
 bool vgg_weights_ok(const disn_vgg_weights_t* w) {
   if (!w) return false;
   for (int i = 0; i < 13; ++i)
@@ -329,14 +346,16 @@ int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, i
     x = out;
     if (L.tap >= 0 && featmap) {
       hipStream_t rs = st;
-      if (ctx) {
+      int cap = 0;
+      if (ctx && (overlap_mask() & 1)) {
         DISN_TRY(hipEventRecord(ctx->ev[1 + L.tap], st));
         DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[1 + L.tap], 0));
         rs = ctx->aux;
+        cap = resize_bg_blocks();  // background launch: trickle under the convolutions
       }
       DISN_TRY(resize_bilinear_launch(taps[L.tap], B, kTapHw[L.tap], kTapHw[L.tap], kTapCh[L.tap],
                                       featmap, DISN_IMG_H, DISN_IMG_W, DISN_FEAT_DIM,
-                                      kTapOff[L.tap], rs));
+                                      kTapOff[L.tap], rs, cap));
     }
     if (kPoolAfter[i]) {
       DISN_TRY(maxpool2x2_launch(x, B, L.hw, L.hw, L.cout, s.bufP, st));
@@ -509,15 +528,22 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
                         e.vgg, &pool5, st);
   if (rc) return rc;
   // aux (MFMA bound): gather + every MLP layer that does not need the embedding ...
+  const bool mlp_aux = (overlap_mask() & 2) != 0;
+  if (!mlp_aux) {  // join the up-samples here; everything below runs on the caller's stream
+    DISN_TRY(hipEventRecord(ctx->ev[7], ctx->aux));
+    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[7], 0));
+    if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
+  }
+  hipStream_t ms = mlp_aux ? ctx->aux : st;
   const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
   for (int b = 0; b < B; ++b)
     DISN_TRY(project_gather_launch(featmap + b * map_stride, trans_mat + (size_t)b * 12,
                                    pts + (size_t)b * N * 3, N,
-                                   e.q.feat + (size_t)b * N * DISN_FEAT_DIM, ctx->aux));
-  if ((rc = mlp_phase1(mw, pts_rot, B * N, e.q.feat, e.q.mlp, ctx->aux))) return rc;
+                                   e.q.feat + (size_t)b * N * DISN_FEAT_DIM, ms));
+  if ((rc = mlp_phase1(mw, pts_rot, B * N, e.q.feat, e.q.mlp, ms))) return rc;
   DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
   // ... while main streams the 495 MB of fc6/fc7/fc8 weights (HBM bound) and folds the bias
-  if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
+  if (mlp_aux && (rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, mw->g_w4_global, mw->g_b4, 512, 0, e.q.gbias,
                        e.q.gemv_ws, st));
   // join, then the short tail behind the embedding

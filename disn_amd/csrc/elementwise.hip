@@ -78,17 +78,18 @@ static inline int grid_for(size_t total, int cap = 8192) {
 
 hipError_t resize_bilinear_launch(const float* in, int B, int Hin, int Win, int C, float* out,
                                   int Hout, int Wout, int out_cstride, int out_coff,
-                                  hipStream_t st) {
+                                  hipStream_t st, int max_blocks) {
+  const int cap = max_blocks > 0 ? max_blocks : 8192;
   const float sy = (float)Hin / (float)Hout;  // CalculateResizeScale, float32 division
   const float sx = (float)Win / (float)Wout;
   const bool vec = (C % 4 == 0) && (out_cstride % 4 == 0) && (out_coff % 4 == 0);
   if (vec) {
     const size_t total = (size_t)B * Hout * Wout * (C / 4);
-    hipLaunchKernelGGL((resize_kernel<4>), dim3(grid_for(total)), dim3(256), 0, st, in, B, Hin, Win,
+    hipLaunchKernelGGL((resize_kernel<4>), dim3(grid_for(total, cap)), dim3(256), 0, st, in, B, Hin, Win,
                        C, out, Hout, Wout, out_cstride, out_coff, sy, sx);
   } else {
     const size_t total = (size_t)B * Hout * Wout * C;
-    hipLaunchKernelGGL((resize_kernel<1>), dim3(grid_for(total)), dim3(256), 0, st, in, B, Hin, Win,
+    hipLaunchKernelGGL((resize_kernel<1>), dim3(grid_for(total, cap)), dim3(256), 0, st, in, B, Hin, Win,
                        C, out, Hout, Wout, out_cstride, out_coff, sy, sx);
   }
   return hipGetLastError();

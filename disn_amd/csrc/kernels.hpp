@@ -49,9 +49,11 @@ hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const fl
                        int relu, float* out, float* ws, hipStream_t st);
 
 // ---- elementwise.hip (compiled with -ffp-contract=off) --------------------
+// max_blocks > 0 caps the grid (grid-stride): a background launch that should trickle under
+// MFMA-bound work instead of flooding the CUs
 hipError_t resize_bilinear_launch(const float* in, int B, int Hin, int Win, int C, float* out,
                                   int Hout, int Wout, int out_cstride, int out_coff,
-                                  hipStream_t st);
+                                  hipStream_t st, int max_blocks = 0);
 hipError_t maxpool2x2_launch(const float* in, int B, int H, int W, int C, float* out,
                              hipStream_t st);
 hipError_t project_launch(const float* pts, const float* trans_mat, int B, int N, float* xy,
