@@ -94,7 +94,9 @@ int conv3x3_impl(const float* in, int B, int H, int W, int Cin, const float* w_p
 const int kChunk = 65536;  // points per MLP pass inside disn_query / disn_sdf_mlp
 
 struct MlpWs {
-  float *e1g, *e1l, *h256, *h512a, *h512b, *g5, *l5, *gemm_ws;
+  // local stream: e1l -> h256 -> h512a -> (with feat) h512b -> l5
+  // global stream: e1g -> g256 -> g512 -> (with the folded bias) h512b -> g5
+  float *e1g, *e1l, *h256, *h512a, *h512b, *g256, *g512, *g5, *l5, *gemm_ws;
   size_t gemm_ws_bytes, total;
 };
 
@@ -123,6 +125,8 @@ MlpWs mlp_layout(Bump& b, int n) {
   w.h256 = b.take((size_t)n * 256 * f);
   w.h512a = b.take((size_t)n * 512 * f);
   w.h512b = b.take((size_t)n * 512 * f);
+  w.g256 = b.take((size_t)n * 256 * f);
+  w.g512 = b.take((size_t)n * 512 * f);
   w.g5 = b.take((size_t)n * 256 * f);
   w.l5 = b.take((size_t)n * 256 * f);
   w.gemm_ws_bytes = mlp_gemm_ws(n);
@@ -152,25 +156,56 @@ int dense_layer(const float* a1, int lda1, int k1, const float* a2, int lda2, in
   return 0;
 }
 
-// both MLP streams for n points of ONE image (gbias = that image's folded bias row)
+// The MLPs in three dependency phases (the phases of one point set may run on different streams):
+//   phase 0 -- needs only the points: fold1 of both streams  (models/sdfnet.py:71-76,173-178)
+//   phase 1 -- needs the feature map: local fold2/conv1 on [point512 | feat1472], fold2/conv2 (:180-184)
+//   phase 2 -- needs the embedding: global fold2/conv1 with the per-image folded bias, fold2/conv2,
+//              both fold2/conv5 and the sum  (:78-88, :186; models/model_normalization.py:204)
+int mlp_phase0(const disn_mlp_weights_t* w, const float* pts_rot, int n, const MlpWs& s,
+               hipStream_t st) {
+  int rc;
+  DISN_TRY(pt_embed_launch(pts_rot, n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g, s.e1l, st));
+  if ((rc = dense_layer(s.e1l, 64, 64, nullptr, 0, 64, n, w->l_w2, w->l_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->l_w3, w->l_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.e1g, 64, 64, nullptr, 0, 64, n, w->g_w2, w->g_b2, 256, s.g256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.g256, 256, 256, nullptr, 0, 256, n, w->g_w3, w->g_b3, 512, s.g512, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  return 0;
+}
+
+int mlp_phase1(const disn_mlp_weights_t* w, int n, const float* feat, const MlpWs& s,
+               hipStream_t st) {
+  int rc;
+  if ((rc = dense_layer(s.h512a, 512, 512, feat, DISN_FEAT_DIM, 512 + DISN_FEAT_DIM, n, w->l_w4, w->l_b4, 512, s.h512b, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->l_w5, w->l_b5, 256, s.l5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  return 0;
+}
+
+// B images x N points (rows image-major); gbias [B][512]
+int mlp_phase2(const disn_mlp_weights_t* w, int B, int N, const float* gbias, float* sdf,
+               float* sdf_g, float* sdf_l, float out_div, const MlpWs& s, hipStream_t st) {
+  int rc;
+  for (int b = 0; b < B; ++b) {
+    const size_t o = (size_t)b * N;
+    if ((rc = dense_layer(s.g512 + o * 512, 512, 512, nullptr, 0, 512, N, w->g_w4_point,
+                          gbias + (size_t)b * 512, 512, s.h512b + o * 512, s.gemm_ws,
+                          s.gemm_ws_bytes, st)))
+      return rc;
+  }
+  const int n = B * N;
+  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->g_w5, w->g_b5, 256, s.g5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, sdf_g, sdf_l,
+                            out_div, st));
+  return 0;
+}
+
+// both MLP streams for n points of ONE image on one stream (gbias = that image's folded bias row)
 int mlp_chunk(const disn_mlp_weights_t* w, const float* pts_rot, int n, const float* gbias,
               const float* feat, float* sdf, float* sdf_g, float* sdf_l, float out_div,
               const MlpWs& s, hipStream_t st) {
   int rc;
-  DISN_TRY(pt_embed_launch(pts_rot, n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g, s.e1l, st));
-  // global stream  (models/sdfnet.py:71-88)
-  if ((rc = dense_layer(s.e1g, 64, 64, nullptr, 0, 64, n, w->g_w2, w->g_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->g_w3, w->g_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h512a, 512, 512, nullptr, 0, 512, n, w->g_w4_point, gbias, 512, s.h512b, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->g_w5, w->g_b5, 256, s.g5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  // local stream  (models/sdfnet.py:173-186); fold2/conv1 reads [point512 | feat1472]
-  if ((rc = dense_layer(s.e1l, 64, 64, nullptr, 0, 64, n, w->l_w2, w->l_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->l_w3, w->l_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h512a, 512, 512, feat, DISN_FEAT_DIM, 512 + DISN_FEAT_DIM, n, w->l_w4, w->l_b4, 512, s.h512b, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->l_w5, w->l_b5, 256, s.l5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, sdf_g, sdf_l,
-                            out_div, st));
-  return 0;
+  if ((rc = mlp_phase0(w, pts_rot, n, s, st))) return rc;
+  if ((rc = mlp_phase1(w, n, feat, s, st))) return rc;
+  return mlp_phase2(w, 1, n, gbias, sdf, sdf_g, sdf_l, out_div, s, st);
 }
 
 struct QueryWs {
@@ -378,40 +413,6 @@ int vgg_head(const disn_vgg_weights_t* w, const float* pool5, int B, float* embe
   return 0;
 }
 
-// MLP phase 1: everything that does not need the image embedding -- the whole local stream
-// (models/sdfnet.py:173-186) and the global stream up to fold1/conv3 (models/sdfnet.py:71-76).
-// Leaves l5 in s.l5 and the global fold1 output in s.h512a.
-int mlp_phase1(const disn_mlp_weights_t* w, const float* pts_rot, int n, const float* feat,
-               const MlpWs& s, hipStream_t st) {
-  int rc;
-  DISN_TRY(pt_embed_launch(pts_rot, n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g, s.e1l, st));
-  if ((rc = dense_layer(s.e1l, 64, 64, nullptr, 0, 64, n, w->l_w2, w->l_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->l_w3, w->l_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h512a, 512, 512, feat, DISN_FEAT_DIM, 512 + DISN_FEAT_DIM, n, w->l_w4, w->l_b4, 512, s.h512b, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->l_w5, w->l_b5, 256, s.l5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.e1g, 64, 64, nullptr, 0, 64, n, w->g_w2, w->g_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->g_w3, w->g_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  return 0;
-}
-
-// MLP phase 2: the part behind the embedding -- global fold2 (per-image folded bias) and the sum.
-int mlp_phase2(const disn_mlp_weights_t* w, int B, int N, const float* gbias, float* sdf,
-               const MlpWs& s, hipStream_t st) {
-  int rc;
-  for (int b = 0; b < B; ++b) {
-    const size_t o = (size_t)b * N;
-    if ((rc = dense_layer(s.h512a + o * 512, 512, 512, nullptr, 0, 512, N, w->g_w4_point,
-                          gbias + (size_t)b * 512, 512, s.h512b + o * 512, s.gemm_ws,
-                          s.gemm_ws_bytes, st)))
-      return rc;
-  }
-  const int n = B * N;
-  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->g_w5, w->g_b5, 256, s.g5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, nullptr, nullptr,
-                            1.0f, st));
-  return 0;
-}
-
 struct EncQueryWs {
   VggWs vgg;
   QueryWs q;
@@ -522,33 +523,42 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   // fork
   DISN_TRY(hipEventRecord(ctx->ev[0], st));
   DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
-  // main: conv stack; aux: tap up-samples as the taps become final
+  // aux, from the fork on: the point-only MLP layers (phase 0) -- small GEMMs that fill the
+  // quantisation holes of the convolutions running on `st`
+  int rc;
+  const bool mlp_aux0 = (overlap_mask() & 2) != 0;
+  if (mlp_aux0 && (rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, ctx->aux))) return rc;
+  // main: conv stack (+ tap up-samples, on aux only with overlap bit 0)
   const float* pool5 = nullptr;
-  int rc = vgg_features(ctx, vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap,
-                        e.vgg, &pool5, st);
+  rc = vgg_features(ctx, vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap,
+                    e.vgg, &pool5, st);
   if (rc) return rc;
-  // aux (MFMA bound): gather + every MLP layer that does not need the embedding ...
+  if (!mlp_aux0 && (rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, st))) return rc;
+  // aux: behind the feature map (written on `st` when the up-samples are not on aux): gather +
+  // local fold2 (MFMA bound), under the 495 MB fc6/fc7/fc8 weight stream (HBM bound) on `st`
   const bool mlp_aux = (overlap_mask() & 2) != 0;
-  if (!mlp_aux) {  // join the up-samples here; everything below runs on the caller's stream
+  hipStream_t ms = mlp_aux ? ctx->aux : st;
+  if (mlp_aux) {
+    DISN_TRY(hipEventRecord(ctx->ev[7], st));
+    DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
+  } else {  // single-stream order: join the aux work issued so far, then continue on `st`
     DISN_TRY(hipEventRecord(ctx->ev[7], ctx->aux));
     DISN_TRY(hipStreamWaitEvent(st, ctx->ev[7], 0));
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
-  hipStream_t ms = mlp_aux ? ctx->aux : st;
   const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
   for (int b = 0; b < B; ++b)
     DISN_TRY(project_gather_launch(featmap + b * map_stride, trans_mat + (size_t)b * 12,
                                    pts + (size_t)b * N * 3, N,
                                    e.q.feat + (size_t)b * N * DISN_FEAT_DIM, ms));
-  if ((rc = mlp_phase1(mw, pts_rot, B * N, e.q.feat, e.q.mlp, ms))) return rc;
+  if ((rc = mlp_phase1(mw, B * N, e.q.feat, e.q.mlp, ms))) return rc;
   DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
-  // ... while main streams the 495 MB of fc6/fc7/fc8 weights (HBM bound) and folds the bias
   if (mlp_aux && (rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, mw->g_w4_global, mw->g_b4, 512, 0, e.q.gbias,
                        e.q.gemv_ws, st));
   // join, then the short tail behind the embedding
   DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
-  return mlp_phase2(mw, B, N, e.q.gbias, sdf, e.q.mlp, st);
+  return mlp_phase2(mw, B, N, e.q.gbias, sdf, nullptr, nullptr, 1.0f, e.q.mlp, st);
 }
 
 int disn_build_featmap(const float* const taps[5], int B, float* featmap, void* stream) {
