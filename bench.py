@@ -147,9 +147,20 @@ def main():
             tot_ms += ms
             tot_flop += fl
         ach = tot_flop / tot_ms / 1e9
+        # HBM-side bytes of the same 13 launches from the PMC passes of the last profiled round
+        # (profiles/pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch
+        # correction, write counter calibrated on the gather's known output bytes); None if absent
+        traffic, pmc = None, {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = pmc["conv_family_per_step"]["hbm_bytes"]
+        except Exception:
+            pass
         line["roofline"] = {"kernel": "gemm_f32_mfma<*,*,CONV3> (13 conv launches of one VGG-16 forward, B=1)",
                             "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                            "traffic_note": "HBM-side bytes per step of the 13 conv launches (+ fix-ups), PMC pass "
+                                            "profiles/pmc_traffic.json; algorithmic ~150 MB (weights 59 + inputs 36 + outputs 54)",
                             "flop_per_step": tot_flop, "ms_per_step": tot_ms, "layers": layers}
         # ---- gather (HBM bound) -----------------------------------------------------------------
         enc = eng.encode(img)
@@ -160,7 +171,9 @@ def main():
             feat = torch.empty((1, n, 1472), device=dev)
             ms = ev_time_ms(lambda: ops.gather(enc.featmap, xy, feat), 20, torch)
             gbs = n * GATHER_BYTES_PER_PT / ms / 1e6
-            g["n%d" % n] = {"ms": ms, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS}
+            g["n%d" % n] = {"ms": ms, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS,
+                            "traffic": (pmc.get("gather_n%d" % n) or {}).get("hbm_bytes"),
+                            "algorithmic_bytes": n * GATHER_BYTES_PER_PT}
         line["roofline_gather"] = {"kernel": "gather_kernel", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "bytes_per_point": GATHER_BYTES_PER_PT, **g}
         # ---- point MLP + query-only (encoder amortised) ------------------------------------------
