@@ -134,7 +134,7 @@ def main():
 
     if rank == 0:
         print("[bench] main line: %.4g points/s, %.4f ms/step" % (value, line["ms_per_step"]), file=sys.stderr)
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:   # roofline / cpu legs: N=1 only (bench contract)
         # ---- roofline of the dominant kernel family: the 13 implicit-GEMM conv launches ----------
         layers, tot_ms, tot_flop = [], 0.0, 0.0
         for cin, cout, hw in VGG_LAYERS:

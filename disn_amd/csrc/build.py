@@ -27,6 +27,7 @@ SOURCES = {
     "mlp_fused.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],
     "api.hip": [],
+    "host_util.cpp": ["-msse4.2"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 HEADERS = ["kernels.hpp", os.path.join(ROOT, "include", "disn_amd.h")]

@@ -1,0 +1,376 @@
+"""TensorFlow-free reader / writer for ``tf.train.Saver`` V2 checkpoints (tensor bundles).
+
+The reference saves and restores through ``tf.train.Saver`` (train/train_sdf.py:285-286,322-328;
+test/create_sdf.py:180-192) and ships its weights as V2 bundles (``checkpoint/SDF_DISN``,
+``vgg_16.ckpt``; README.md:27-39).  "Keep the checkpoint layout" therefore means: the files
+
+    <prefix>.index                  a LevelDB-style sorted string table (TF lib/io/table):
+                                    key ""   -> BundleHeaderProto {num_shards, endianness, version}
+                                    key name -> BundleEntryProto  {dtype, shape, shard_id, offset, size, crc32c}
+    <prefix>.data-00000-of-00001    the raw little-endian tensor bytes, back to back
+    checkpoint                      text proto: model_checkpoint_path / all_model_checkpoint_paths
+
+This module restates that format from the TensorFlow source (tensorflow/core/util/tensor_bundle,
+tensorflow/core/lib/io/{table_builder,block_builder,format}.cc, protobuf wire format) in plain
+Python.  STATUS: round-trip tested (tests/test_tf_checkpoint.py) and checked field by field
+against the format description; NOT yet validated against a file written by TensorFlow itself
+(none is available in this environment -- the reference's checkpoints are Dropbox downloads).
+Only what DISN checkpoints contain is supported: uncompressed blocks, one shard, float32/int32/
+int64/float64 tensors, no tensor slices.
+"""
+from __future__ import annotations
+
+import os
+import re
+import struct
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+
+TABLE_MAGIC = 0xDB4775248B80FB57          # tensorflow/core/lib/io/format.h kTableMagicNumber
+FOOTER_LEN = 48                            # 2 x BlockHandle::kMaxEncodedLength (20) + 8
+BLOCK_TRAILER = 5                          # 1 byte compression type + 4 byte masked crc32c
+DT = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64}      # types.proto DataType
+DT_INV = {np.dtype(v): k for k, v in DT.items()}
+
+# ---------------------------------------------------------------- crc32c (Castagnoli), masked
+_CRC_TABLE: List[int] = []
+
+
+def _crc_table() -> List[int]:
+    if not _CRC_TABLE:
+        poly = 0x82F63B78
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ poly if c & 1 else c >> 1
+            _CRC_TABLE.append(c)
+    return _CRC_TABLE
+
+
+def _crc32c_py(data: bytes, crc: int = 0) -> int:
+    t = _crc_table()
+    c = crc ^ 0xFFFFFFFF
+    for b in data:
+        c = t[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def crc32c(data, crc: int = 0) -> int:
+    """CRC-32C (Castagnoli).  Large buffers go through the library's host helper disn_crc32c
+    (SSE4.2 instruction); the pure-Python loop is the definition and is used for small blocks."""
+    if len(data) >= 4096:
+        try:
+            from ._lib import lib
+            import ctypes as C
+            buf = (C.c_char * len(data)).from_buffer_copy(data) if not isinstance(data, np.ndarray) else None
+            if buf is None:
+                a = np.ascontiguousarray(data).view(np.uint8)
+                return int(lib().disn_crc32c(a.ctypes.data, a.size, crc))
+            return int(lib().disn_crc32c(C.addressof(buf), len(data), crc))
+        except Exception:  # library not built: fall back to the definition
+            pass
+    return _crc32c_py(bytes(data), crc)
+
+
+def mask_crc(c: int) -> int:
+    """tensorflow/core/lib/hash/crc32c.h Mask(): rotate right 15 and add a constant."""
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+# ---------------------------------------------------------------- varints / protobuf wire format
+def _put_varint(n: int) -> bytes:
+    out = bytearray()
+    n &= (1 << 64) - 1
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        if n:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _get_varint(buf: bytes, pos: int) -> Tuple[int, int]:
+    shift = n = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        n |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return n, pos
+        shift += 7
+
+
+def _pb_fields(buf: bytes) -> Iterable[Tuple[int, int, object]]:
+    """yield (field_number, wire_type, value) -- value is int for varint/fixed, bytes for len-delimited"""
+    pos = 0
+    while pos < len(buf):
+        key, pos = _get_varint(buf, pos)
+        fn, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _get_varint(buf, pos)
+        elif wt == 1:
+            v = struct.unpack_from("<Q", buf, pos)[0]
+            pos += 8
+        elif wt == 2:
+            ln, pos = _get_varint(buf, pos)
+            v = bytes(buf[pos:pos + ln])
+            pos += ln
+        elif wt == 5:
+            v = struct.unpack_from("<I", buf, pos)[0]
+            pos += 4
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % wt)
+        yield fn, wt, v
+
+
+def _pb_varint(fn: int, v: int) -> bytes:
+    return _put_varint(fn << 3) + _put_varint(v)
+
+
+def _pb_bytes(fn: int, v: bytes) -> bytes:
+    return _put_varint((fn << 3) | 2) + _put_varint(len(v)) + v
+
+
+def _encode_shape(shape: Tuple[int, ...]) -> bytes:          # TensorShapeProto: repeated Dim dim = 2
+    return b"".join(_pb_bytes(2, _pb_varint(1, int(d))) for d in shape)
+
+
+def _decode_shape(buf: bytes) -> Tuple[int, ...]:
+    dims = []
+    for fn, wt, v in _pb_fields(buf):
+        if fn == 2 and wt == 2:
+            size = 0
+            for f2, w2, v2 in _pb_fields(v):
+                if f2 == 1 and w2 == 0:
+                    size = v2 if v2 < (1 << 63) else v2 - (1 << 64)
+            dims.append(size)
+    return tuple(dims)
+
+
+def _encode_entry(dtype: int, shape, shard: int, offset: int, size: int, crc: int) -> bytes:
+    """BundleEntryProto (tensor_bundle.proto): dtype=1, shape=2, shard_id=3, offset=4, size=5, crc32c=6 (fixed32)"""
+    out = _pb_varint(1, dtype) + _pb_bytes(2, _encode_shape(shape))
+    if shard:
+        out += _pb_varint(3, shard)
+    if offset:
+        out += _pb_varint(4, offset)
+    out += _pb_varint(5, size) + _put_varint((6 << 3) | 5) + struct.pack("<I", crc)
+    return out
+
+
+def _decode_entry(buf: bytes) -> Dict[str, object]:
+    e = {"dtype": 0, "shape": (), "shard_id": 0, "offset": 0, "size": 0, "crc32c": 0, "slices": 0}
+    for fn, wt, v in _pb_fields(buf):
+        if fn == 1:
+            e["dtype"] = v
+        elif fn == 2:
+            e["shape"] = _decode_shape(v)
+        elif fn == 3:
+            e["shard_id"] = v
+        elif fn == 4:
+            e["offset"] = v
+        elif fn == 5:
+            e["size"] = v
+        elif fn == 6:
+            e["crc32c"] = v
+        elif fn == 7:
+            e["slices"] += 1
+    return e
+
+
+# ---------------------------------------------------------------- table blocks
+def _read_block(buf: bytes, offset: int, size: int, verify: bool) -> bytes:
+    body = buf[offset:offset + size]
+    trailer = buf[offset + size:offset + size + BLOCK_TRAILER]
+    if len(trailer) != BLOCK_TRAILER:
+        raise ValueError("truncated table block")
+    if trailer[0] != 0:
+        raise NotImplementedError("compressed table block (type %d); TF bundles are written uncompressed" % trailer[0])
+    if verify:
+        want = struct.unpack("<I", trailer[1:])[0]
+        got = mask_crc(crc32c(bytes(body) + trailer[:1]))
+        if want != got:
+            raise ValueError("table block crc mismatch at %d" % offset)
+    return bytes(body)
+
+
+def _block_entries(block: bytes) -> List[Tuple[bytes, bytes]]:
+    """block_builder.cc: entries (shared varint, non_shared varint, value_len varint, key delta,
+    value) ... restarts uint32[n], n uint32"""
+    n_restarts = struct.unpack_from("<I", block, len(block) - 4)[0]
+    end = len(block) - 4 - 4 * n_restarts
+    out, pos, key = [], 0, b""
+    while pos < end:
+        shared, pos = _get_varint(block, pos)
+        non_shared, pos = _get_varint(block, pos)
+        vlen, pos = _get_varint(block, pos)
+        key = key[:shared] + block[pos:pos + non_shared]
+        pos += non_shared
+        out.append((key, block[pos:pos + vlen]))
+        pos += vlen
+    return out
+
+
+def _build_block(entries: List[Tuple[bytes, bytes]], restart_interval: int) -> bytes:
+    out = bytearray()
+    restarts, last = [], b""
+    for i, (k, v) in enumerate(entries):
+        if i % restart_interval == 0:
+            restarts.append(len(out))
+            shared = 0
+        else:
+            shared = 0
+            m = min(len(k), len(last))
+            while shared < m and k[shared] == last[shared]:
+                shared += 1
+        out += _put_varint(shared) + _put_varint(len(k) - shared) + _put_varint(len(v)) + k[shared:] + v
+        last = k
+    if not restarts:
+        restarts = [0]
+    for r in restarts:
+        out += struct.pack("<I", r)
+    out += struct.pack("<I", len(restarts))
+    return bytes(out)
+
+
+def _emit_block(f, block: bytes) -> Tuple[int, int]:
+    off = f.tell()
+    f.write(block)
+    f.write(b"\x00" + struct.pack("<I", mask_crc(crc32c(block + b"\x00"))))
+    return off, len(block)
+
+
+# ---------------------------------------------------------------- public API
+def data_path(prefix: str, shard: int = 0, num_shards: int = 1) -> str:
+    return "%s.data-%05d-of-%05d" % (prefix, shard, num_shards)
+
+
+def list_variables(prefix: str, verify: bool = True) -> Dict[str, Dict[str, object]]:
+    """name -> {dtype, shape, shard_id, offset, size, crc32c}; the header is returned under ''."""
+    buf = open(prefix + ".index", "rb").read()
+    if len(buf) < FOOTER_LEN or struct.unpack("<Q", buf[-8:])[0] != TABLE_MAGIC:
+        raise ValueError("%s.index is not a TensorFlow table (bad magic)" % prefix)
+    footer = buf[-FOOTER_LEN:]
+    pos = 0
+    _mi_off, pos = _get_varint(footer, pos)
+    _mi_size, pos = _get_varint(footer, pos)
+    idx_off, pos = _get_varint(footer, pos)
+    idx_size, pos = _get_varint(footer, pos)
+    out: Dict[str, Dict[str, object]] = {}
+    for _, handle in _block_entries(_read_block(buf, idx_off, idx_size, verify)):
+        off, p = _get_varint(handle, 0)
+        size, p = _get_varint(handle, p)
+        for k, v in _block_entries(_read_block(buf, off, size, verify)):
+            if k == b"":
+                hdr = {"num_shards": 1, "endianness": 0}
+                for fn, wt, val in _pb_fields(v):
+                    if fn == 1:
+                        hdr["num_shards"] = val
+                    elif fn == 2:
+                        hdr["endianness"] = val
+                out[""] = hdr
+            else:
+                out[k.decode("utf-8")] = _decode_entry(v)
+    if "" not in out:
+        raise ValueError("bundle header missing in %s.index" % prefix)
+    if out[""]["endianness"] != 0:
+        raise NotImplementedError("big-endian bundle")
+    return out
+
+
+def load_checkpoint(prefix: str, names: Optional[Iterable[str]] = None, verify: bool = True
+                    ) -> Dict[str, np.ndarray]:
+    """Read tensors of a V2 bundle by variable name (all, or the ``names`` given)."""
+    entries = list_variables(prefix, verify)
+    hdr = entries.pop("")
+    want = set(names) if names is not None else None
+    files: Dict[int, np.memmap] = {}
+    out: Dict[str, np.ndarray] = {}
+    for name, e in entries.items():
+        if want is not None and name not in want:
+            continue
+        if e["slices"]:
+            raise NotImplementedError("%s is stored as tensor slices (partitioned variable)" % name)
+        if e["dtype"] not in DT:
+            raise NotImplementedError("%s: DataType %d" % (name, e["dtype"]))
+        sh = int(e["shard_id"])
+        if sh not in files:
+            files[sh] = np.memmap(data_path(prefix, sh, int(hdr["num_shards"])), dtype=np.uint8, mode="r")
+        raw = files[sh][int(e["offset"]):int(e["offset"]) + int(e["size"])]
+        dt = np.dtype(DT[e["dtype"]])
+        n = int(np.prod(e["shape"], dtype=np.int64)) if e["shape"] else 1
+        if n * dt.itemsize != int(e["size"]):
+            raise ValueError("%s: size %d does not match shape %s" % (name, e["size"], e["shape"]))
+        if verify and mask_crc(crc32c(raw.tobytes())) != e["crc32c"]:
+            raise ValueError("%s: tensor crc mismatch" % name)
+        out[name] = np.frombuffer(raw.tobytes(), dtype=dt.newbyteorder("<")).reshape(e["shape"]).astype(dt)
+    return out
+
+
+def save_checkpoint(prefix: str, tensors: Dict[str, np.ndarray], block_bytes: int = 4096) -> None:
+    """Write a one-shard V2 bundle (+ nothing else; see write_checkpoint_state)."""
+    os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
+    items: List[Tuple[bytes, bytes]] = []
+    offset = 0
+    with open(data_path(prefix), "wb") as fd:
+        for name in sorted(tensors, key=lambda s: s.encode("utf-8")):
+            a = np.asarray(tensors[name])            # (ascontiguousarray would turn a scalar into shape (1,))
+            if not a.flags.c_contiguous:
+                a = a.copy(order="C")
+            if a.dtype not in DT_INV:
+                raise NotImplementedError("%s: dtype %s" % (name, a.dtype))
+            raw = a.astype(a.dtype.newbyteorder("<")).tobytes()
+            fd.write(raw)
+            items.append((name.encode("utf-8"),
+                          _encode_entry(DT_INV[a.dtype], a.shape, 0, offset, len(raw), mask_crc(crc32c(raw)))))
+            offset += len(raw)
+    # BundleHeaderProto: num_shards=1 (field 1), endianness LITTLE=0 (default, omitted), version {producer=1}
+    header = _pb_varint(1, 1) + _pb_bytes(3, _pb_varint(1, 1))
+    items.insert(0, (b"", header))
+    with open(prefix + ".index", "wb") as f:
+        index_entries: List[Tuple[bytes, bytes]] = []
+        cur: List[Tuple[bytes, bytes]] = []
+        cur_bytes = 0
+
+        def flush():
+            nonlocal cur, cur_bytes
+            if cur:
+                off, size = _emit_block(f, _build_block(cur, 16))
+                index_entries.append((cur[-1][0], _put_varint(off) + _put_varint(size)))
+                cur, cur_bytes = [], 0
+
+        for k, v in items:
+            cur.append((k, v))
+            cur_bytes += len(k) + len(v) + 3
+            if cur_bytes >= block_bytes:
+                flush()
+        flush()
+        mi_off, mi_size = _emit_block(f, _build_block([], 1))             # empty metaindex block
+        ix_off, ix_size = _emit_block(f, _build_block(index_entries, 1))
+        footer = _put_varint(mi_off) + _put_varint(mi_size) + _put_varint(ix_off) + _put_varint(ix_size)
+        f.write(footer + b"\x00" * (FOOTER_LEN - 8 - len(footer)) + struct.pack("<Q", TABLE_MAGIC))
+
+
+# ---------------------------------------------------------------- the 'checkpoint' state file
+def write_checkpoint_state(directory: str, model_checkpoint_path: str, all_paths: Optional[List[str]] = None) -> None:
+    all_paths = all_paths or [model_checkpoint_path]
+    with open(os.path.join(directory, "checkpoint"), "w") as f:
+        f.write('model_checkpoint_path: "%s"\n' % model_checkpoint_path)
+        for p in all_paths:
+            f.write('all_model_checkpoint_paths: "%s"\n' % p)
+
+
+def get_checkpoint_state(directory: str) -> Optional[str]:
+    """tf.train.get_checkpoint_state(dir).model_checkpoint_path (test/create_sdf.py:182-185):
+    the prefix of the latest checkpoint, resolved relative to ``directory``; None if absent."""
+    p = os.path.join(directory, "checkpoint")
+    if not os.path.exists(p):
+        return None
+    m = re.search(r'^model_checkpoint_path:\s*"([^"]*)"', open(p).read(), flags=re.M)
+    if not m:
+        return None
+    path = m.group(1)
+    return path if os.path.isabs(path) else os.path.join(directory, path)

@@ -116,6 +116,40 @@ class WeightStore:
             raise KeyError("checkpoint %s lacks %d variables, e.g. %s" % (path, len(missing), missing[:3]))
         return ws
 
+    # -- TensorFlow Saver-V2 bundles (the reference's checkpoint format) -----------------------------
+    def save_tf(self, prefix: str, write_state: bool = True) -> None:
+        """``saver.save(sess, prefix)`` for the model variables (train/train_sdf.py:322-328):
+        <prefix>.index + <prefix>.data-00000-of-00001 (+ the 'checkpoint' state file)."""
+        import os
+        from . import tf_checkpoint as tfc
+        tfc.save_checkpoint(prefix, self.arrays)
+        if write_state:
+            tfc.write_checkpoint_state(os.path.dirname(os.path.abspath(prefix)), os.path.basename(prefix))
+
+    @classmethod
+    def load_tf(cls, prefix: str, num_classes: int = 1024, strict: bool = False, name_prefix: str = "",
+                verify: bool = True) -> "WeightStore":
+        """``saver.restore`` semantics of the reference: variables are matched by name (optionally
+        only those under ``name_prefix``, e.g. 'vgg_16' for vgg_16.ckpt -- train/train_sdf.py:276-278)
+        and exact shape; optimizer slots ('.../Adam', 'beta1_power', ...) and anything else unknown
+        are ignored unless ``strict``."""
+        from . import tf_checkpoint as tfc
+        ws = cls(num_classes=num_classes)
+        entries = tfc.list_variables(prefix, verify)
+        want = [n for n in entries if n in ws.shapes and (not name_prefix or n.startswith(name_prefix))]
+        ws.assign(tfc.load_checkpoint(prefix, want, verify), strict=strict, prefix=name_prefix)
+        if strict and not ws.complete():
+            raise KeyError("checkpoint %s lacks model variables" % prefix)
+        return ws
+
+    @classmethod
+    def restore_latest(cls, directory: str, num_classes: int = 1024) -> Optional["WeightStore"]:
+        """``tf.train.get_checkpoint_state(dir)`` + restore (test/create_sdf.py:180-192); None when the
+        directory holds no checkpoint (the caller decides about random init -- never silently)."""
+        from . import tf_checkpoint as tfc
+        prefix = tfc.get_checkpoint_state(directory)
+        return None if prefix is None else cls.load_tf(prefix, num_classes)
+
     def __getitem__(self, k: str) -> np.ndarray:
         return self.arrays[k]
 

@@ -214,6 +214,11 @@ int disn_query_grid(const disn_mlp_weights_t* w, const float* featmap, const flo
                     int64_t k1, float sdf_weight, float* out, void* ws, size_t ws_bytes,
                     void* stream);
 
+/* Host utility (no device work): CRC-32C of a HOST buffer, continuing from `crc` (0 to start);
+ * the checksum of TensorFlow's table blocks and tensor-bundle entries, used by the
+ * TensorFlow-free checkpoint reader/writer (train/train_sdf.py:285-299, test/create_sdf.py:180-192). */
+uint32_t disn_crc32c(const void* data_host, size_t n, uint32_t crc);
+
 #ifdef __cplusplus
 }
 #endif
