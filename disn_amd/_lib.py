@@ -74,6 +74,10 @@ SIGNATURES = {
     "disn_encode_query": (I, [P, C.POINTER(VggWeights), C.POINTER(MlpWeights), P, P, P, P, I, I, P,
                               C.POINTER(C.c_void_p * 5), P, P, P, P, Z, P]),
     "disn_crc32c": (C.c_uint32, [P, Z, C.c_uint32]),
+    "disn_mc_workspace_bytes": (Z, [I]),
+    "disn_mc_count": (I, [P, I, F, P, P, Z, P]),
+    "disn_mc_emit": (I, [P, C.POINTER(C.c_double * 6), I, F, P, P, P, Z, P]),
+    "disn_write_obj": (I, [C.c_char_p, P, L, P, L]),
     "disn_grid_points": (I, [C.POINTER(C.c_double * 6), I, L, L, P, P]),
     "disn_query_grid_workspace_bytes": (Z, [L]),
     "disn_query_grid": (I, [C.POINTER(MlpWeights), P, P, P, C.POINTER(C.c_double * 6), I, L, L, F, P,

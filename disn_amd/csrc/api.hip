@@ -688,4 +688,26 @@ int disn_query_grid(const disn_mlp_weights_t* w, const float* featmap, const flo
   return 0;
 }
 
+size_t disn_mc_workspace_bytes(int R) { return (R < 1 || R > 1290) ? 0 : mc_ws_bytes(R); }
+
+int disn_mc_count(const float* sdf, int R, float iso, uint64_t* counts, void* ws, size_t ws_bytes,
+                  void* stream) {
+  if (!sdf || !counts || !ws || R < 1) return DISN_E_ARG;
+  if (R > 1290) return DISN_E_SHAPE;  // 3*(R+1)^3 edge slots must fit the 32-bit scan
+  if (ws_bytes < mc_ws_bytes(R)) return DISN_E_WS;
+  DISN_TRY(mc_count_launch(sdf, R, iso, reinterpret_cast<unsigned long long*>(counts), ws,
+                           (hipStream_t)stream));
+  return 0;
+}
+
+int disn_mc_emit(const float* sdf, const double* sdf_params_host, int R, float iso, float* verts,
+                 int32_t* faces, void* ws, size_t ws_bytes, void* stream) {
+  GridSpec g;
+  if (!sdf || !verts || !faces || !ws || !grid_spec(sdf_params_host, R, &g)) return DISN_E_ARG;
+  if (R > 1290) return DISN_E_SHAPE;
+  if (ws_bytes < mc_ws_bytes(R)) return DISN_E_WS;
+  DISN_TRY(mc_emit_launch(sdf, g, iso, verts, faces, ws, (hipStream_t)stream));
+  return 0;
+}
+
 }  // extern "C"

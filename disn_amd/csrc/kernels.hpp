@@ -71,6 +71,14 @@ hipError_t grid_points_launch(const GridSpec& g, int64_t k0, int64_t k1, float* 
                               hipStream_t st);
 hipError_t scale_div_launch(const float* in, float divisor, int64_t n, float* out, hipStream_t st);
 
+// ---- marching_cubes.hip (compiled with -ffp-contract=off) ------------------------
+size_t mc_ws_bytes(int R);
+// counts[0] = vertices, counts[1] = triangles (device memory); fills ws for mc_emit_launch
+hipError_t mc_count_launch(const float* vol, int R, float iso, unsigned long long* counts, void* ws,
+                           hipStream_t st);
+hipError_t mc_emit_launch(const float* vol, const GridSpec& g, float iso, float* verts, int* faces,
+                          void* ws, hipStream_t st);
+
 // ---- mlp_small.hip ---------------------------------------------------------
 // relu(p . W1 + b1) for both streams: pts [M][3] -> out_g [M][64], out_l [M][64]
 hipError_t pt_embed_launch(const float* pts, int64_t M, const float* g_w1, const float* g_b1,

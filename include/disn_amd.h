@@ -214,6 +214,34 @@ int disn_query_grid(const disn_mlp_weights_t* w, const float* featmap, const flo
                     int64_t k1, float sdf_weight, float* out, void* ws, size_t ws_bytes,
                     void* stream);
 
+/* ---------------------------------------------------------------------- *
+ * Iso-surface: the reference writes the grid to a .dist     *
+ * file and shells out to the closed Vega-FEM binary                        *
+ * ./isosurface/computeMarchingCubes <dist> <obj> -i <iso>                  *
+ * (test/create_sdf.py:305-323).  Here the grid [(R+1)^3] (x fastest, as    *
+ * produced by disn_query_grid) is meshed where it lies: indexed marching   *
+ * cubes, one vertex per cut grid edge, case table derived in               *
+ * tools/gen_mc_tables.py (crack-free).  Two steps because the sizes are    *
+ * data dependent:                                                          *
+ *   disn_mc_count -> counts[0] = #vertices, counts[1] = #triangles (uint64,*
+ *                    DEVICE memory; read them back, allocate, then)        *
+ *   disn_mc_emit  -> verts [nv,3] float32 world coordinates (bbox =        *
+ *                    sdf_params), faces [nt,3] int32 0-based, outward      *
+ *                    orientation (normals point towards larger values).    *
+ * Both calls take the same workspace (disn_mc_workspace_bytes(R)); emit    *
+ * relies on what count left in it.                                         *
+ * ---------------------------------------------------------------------- */
+size_t disn_mc_workspace_bytes(int R);
+int disn_mc_count(const float* sdf, int R, float iso, uint64_t* counts, void* ws, size_t ws_bytes,
+                  void* stream);
+int disn_mc_emit(const float* sdf, const double* sdf_params_host, int R, float iso, float* verts,
+                 int32_t* faces, void* ws, size_t ws_bytes, void* stream);
+
+/* Host utility: Wavefront .obj writer ("v x y z" / "f a b c", 1-based) for HOST arrays; the
+ * reference's output artefact (test/create_sdf.py:311).  Returns 0, or DISN_E_ARG on I/O error. */
+int disn_write_obj(const char* path, const float* verts_host, int64_t nv, const int32_t* faces_host,
+                   int64_t nf);
+
 /* Host utility (no device work): CRC-32C of a HOST buffer, continuing from `crc` (0 to start);
  * the checksum of TensorFlow's table blocks and tensor-bundle entries, used by the
  * TensorFlow-free checkpoint reader/writer (train/train_sdf.py:285-299, test/create_sdf.py:180-192). */

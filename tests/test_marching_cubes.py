@@ -1,0 +1,160 @@
+"""Iso-surface stage.  CPU part: the derived case table and the oracle against independent
+properties.  GPU part (-m gpu): the HIP kernels against the oracle, bit for bit, and at the full
+257^3 size through properties."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mc_oracle as M
+
+BOX = [-1, -1, -1, 1, 1, 1]
+
+
+def _balanced(faces):
+    """(#edges whose forward/backward uses do not cancel, #edges not used exactly twice)"""
+    f = np.asarray(faces, np.int64)
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    lo, hi = np.minimum(e[:, 0], e[:, 1]), np.maximum(e[:, 0], e[:, 1])
+    sgn = np.where(e[:, 0] < e[:, 1], 1, -1)
+    key = lo * (f.max() + 1) + hi
+    o = np.argsort(key, kind="stable")
+    key, sgn = key[o], sgn[o]
+    _, start = np.unique(key, return_index=True)
+    sums = np.add.reduceat(sgn, start)
+    cnt = np.diff(np.append(start, len(key)))
+    return int((sums != 0).sum()), int((cnt != 2).sum())
+
+
+def _sphere(R, r=0.6, c=(0.05, -0.1, 0.02)):
+    ax = np.linspace(-1, 1, R + 1)
+    z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+    return (np.sqrt((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) - r).astype(np.float32)
+
+
+def _noise(R, seed):
+    v = np.random.default_rng(seed).standard_normal((R + 1,) * 3).astype(np.float32)
+    v[0] = v[-1] = 1; v[:, 0] = v[:, -1] = 1; v[:, :, 0] = v[:, :, -1] = 1     # outside shell -> closed surface
+    return v
+
+
+# ------------------------------------------------------------------ CPU
+def test_case_table_basic_facts():
+    ntri, tri, maxt = M.gen.build_tables()
+    assert maxt == 5 and ntri[0] == 0 and ntri[255] == 0
+    assert ntri[1] == 1 and ntri[254] == 1                 # one corner inside / outside: one triangle
+    for m in range(256):
+        used = tri[m][tri[m] >= 0]
+        assert len(used) == 3 * ntri[m]
+        # every referenced cube edge is cut in this case
+        for e in used:
+            a, b = M.gen.EDGES[e]
+            assert ((m >> a) & 1) != ((m >> b) & 1)
+        # every cut edge is referenced
+        cut = {i for i, (a, b) in enumerate(M.gen.EDGES) if ((m >> a) & 1) != ((m >> b) & 1)}
+        assert set(int(e) for e in used) == cut
+    # the committed header is the generator's output
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "disn_amd", "csrc", "mc_tables.h")).read()
+    assert ("{%s}" % ",".join(str(int(v)) for v in tri[105])) in hdr
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_noise_is_crack_free_manifold_and_oriented(seed):
+    """white noise exercises all 256 cases and every ambiguous face: no cracks, every edge used
+    exactly twice in opposite directions"""
+    v, f = M.marching_cubes(_noise(20, seed), BOX, 0.0)
+    assert len(f) > 10000
+    assert _balanced(f) == (0, 0)
+    assert M.mesh_is_closed_and_oriented(f) == (True, 0)
+    assert len(np.unique(f)) == len(v)                     # every vertex is referenced
+
+
+def test_sphere_converges_and_points_outward():
+    errs = []
+    for R in (16, 32, 64):
+        v, f = M.marching_cubes(_sphere(R), BOX, 0.0)
+        assert M.mesh_is_closed_and_oriented(f) == (True, 0)
+        vol, area = M.mesh_volume_area(v, f)
+        assert vol > 0                                      # outward normals (towards larger SDF)
+        errs.append(abs(vol - 4 / 3 * np.pi * 0.6 ** 3))
+        assert abs(area - 4 * np.pi * 0.36) / (4 * np.pi * 0.36) < 0.02
+        # vertices lie on the analytic surface to O(h^2)
+        rad = np.linalg.norm(v - np.array([0.05, -0.1, 0.02], np.float32), axis=1)
+        assert np.abs(rad - 0.6).max() < 2.0 * (2.0 / R) ** 2
+    assert errs[2] < errs[1] < errs[0] and errs[2] < 2e-3
+
+
+def test_iso_level_and_degenerate_inputs():
+    sp = _sphere(24)
+    v0, f0 = M.marching_cubes(sp, BOX, 0.0)
+    v1, f1 = M.marching_cubes(sp, BOX, 0.1)                 # iso 0.1 == sphere of radius 0.7
+    assert M.mesh_volume_area(v1, f1)[0] > M.mesh_volume_area(v0, f0)[0]
+    assert abs(M.mesh_volume_area(v1, f1)[0] - 4 / 3 * np.pi * 0.7 ** 3) < 0.03
+    ve, fe = M.marching_cubes(np.ones((9, 9, 9), np.float32), BOX, 0.0)   # nothing inside
+    assert ve.shape == (0, 3) and fe.shape == (0, 3)
+    # a value exactly at iso counts as outside; vertex sits exactly on that grid point
+    g = np.ones((3, 3, 3), np.float32); g[1, 1, 1] = -1.0; g[1, 1, 2] = 0.0
+    vv, ff = M.marching_cubes(g, BOX, 0.0)
+    assert M.mesh_is_closed_and_oriented(ff) == (True, 0)
+    assert any(np.allclose(p, [1.0, 0.0, 0.0]) for p in vv)
+    # anisotropic box: coordinates follow sdf_params per axis
+    vb, _ = M.marching_cubes(_sphere(16), [-2, -1, -0.5, 2, 1, 0.5], 0.0)
+    assert vb[:, 0].max() > 1.0 and abs(vb[:, 2]).max() <= 0.5
+
+
+def test_write_obj_roundtrip(tmp_path):
+    from disn_amd import isosurface as iso
+    v, f = M.marching_cubes(_sphere(12), BOX, 0.0)
+    p = str(tmp_path / "a" / "m.obj")
+    iso.write_obj(p, v, f)
+    txt = open(p).read().splitlines()
+    assert txt[0].startswith("v ") and txt[len(v)].startswith("f ") and len(txt) == len(v) + len(f)
+    v2, f2 = iso.read_obj(p)
+    assert np.array_equal(v2, v) and np.array_equal(f2, f)  # %.9g round-trips float32; faces 1-based on disk
+    assert min(int(t) for l in txt[len(v):] for t in l.split()[1:]) == 1
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["sphere33", "noise20", "sphere_aniso", "iso_shift", "empty"])
+def test_gpu_marching_cubes_bit_exact(case):
+    import torch
+    from disn_amd import isosurface as iso
+    box, level = BOX, 0.0
+    if case == "sphere33":
+        vol = _sphere(33)
+    elif case == "noise20":
+        vol = _noise(20, 7)
+    elif case == "sphere_aniso":
+        vol, box = _sphere(40), [-2.0, -1.0, -0.5, 2.0, 1.25, 0.5]
+    elif case == "iso_shift":
+        vol, level = _sphere(24), 0.07
+    else:
+        vol = np.ones((9, 9, 9), np.float32)
+    R = vol.shape[0] - 1
+    v, f = iso.marching_cubes(torch.from_numpy(vol).cuda(), box, R, level)
+    vr, fr = M.marching_cubes(vol, box, level)
+    assert v.shape == vr.shape and f.shape == fr.shape
+    assert np.array_equal(f.cpu().numpy(), fr)
+    assert np.array_equal(v.cpu().numpy(), vr)
+
+
+@pytest.mark.gpu
+def test_gpu_full_resolution_mesh_properties(tmp_path):
+    """257^3 grid (BASELINE config 3 size): closed, oriented, right volume; .obj written and read back"""
+    import torch
+    from disn_amd import isosurface as iso
+    R = 256
+    ax = torch.linspace(-1, 1, R + 1, device="cuda", dtype=torch.float64)
+    z, y, x = torch.meshgrid(ax, ax, ax, indexing="ij")
+    sdf = (torch.sqrt(x * x + y * y + z * z) - 0.6).float().reshape(-1)
+    del x, y, z
+    v, f = iso.marching_cubes(sdf, BOX, R, 0.0)
+    vn, fn = v.cpu().numpy(), f.cpu().numpy()
+    assert M.mesh_is_closed_and_oriented(fn) == (True, 0)
+    vol, area = M.mesh_volume_area(vn, fn)
+    assert abs(vol - 4 / 3 * np.pi * 0.6 ** 3) < 2e-4 and abs(area - 4 * np.pi * 0.36) < 2e-3
+    p = iso.create_obj(sdf, BOX, str(tmp_path), "03001627", "abc", 3, 0.0)
+    assert p.endswith(os.path.join("03001627", "03001627_abc_03.obj"))
+    v2, f2 = iso.read_obj(p)
+    assert np.array_equal(v2, vn) and np.array_equal(f2, fn)
