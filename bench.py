@@ -199,6 +199,23 @@ def main():
         t1 = time.perf_counter() - t0
         line["grid256"] = {"points": 257 ** 3, "seconds": t1, "points_per_s": 257 ** 3 / t1,
                            "includes": "encode + all chunks + /10, single GPU, no marching cubes"}
+        # config 3 end to end: + marching cubes on the device (+ the .obj the reference writes)
+        from disn_amd import isosurface as iso
+        iso.marching_cubes(full, [-1, -1, -1, 1, 1, 1], 256, 0.0)         # warm-up (workspace, code)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enc3 = eng.encode(img)
+        full = cs.dense_grid_sdf(eng, enc3, 0, tm, [-1, -1, -1, 1, 1, 1], 256)
+        verts, faces = iso.marching_cubes(full, [-1, -1, -1, 1, 1, 1], 256, 0.0)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        iso.write_obj("/tmp/disn_bench_mesh.obj", verts, faces)
+        t3 = time.perf_counter() - t0
+        line["grid256_mesh"] = {"seconds": t2, "vertices": int(verts.shape[0]), "triangles": int(faces.shape[0]),
+                                "obj_write_seconds": t3,
+                                "includes": "encode + 257^3 SDF + marching cubes on one GPU (random-init weights: "
+                                            "the iso-surface of an untrained net); .obj write timed separately"}
         del full
         # ---- CPU baseline: the oracle on the same workload, host cores -----------------------------
         from oracle import disn_oracle as O

@@ -328,28 +328,44 @@ void gemm_f32_mfma(const GemmDev d) {
   //  arithmetic out of the segment loop and keeps ~100 VGPRs live across the K loop)
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
+  // Each wave turns its 32x32 accumulator tiles into row-major order through a private 32x36
+  // slice of the (now idle) A-tile LDS and stores 16 bytes per lane, 8 lanes per 128-byte row:
+  // 4 store instructions per tile instead of 16 scalar ones (the tail was store-ISSUE bound:
+  // ~6.4k cycles per workgroup, tools/ubench/gemm_ablate.hip).  DS operations of one wave execute
+  // in order, so the write -> read exchange needs no barrier.
+  float* stage = &lds[wave * 32 * LDA];
+  const int srow = lane_e >> 3, scol = (lane_e & 7) * 4;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int lcol = wn * (BN / 2) + j * 32 + (lane_e & 31);
-    const float bv = complete ? p.bias[n0 + lcol] : 0.f;
+    const int lcol = wn * (BN / 2) + j * 32 + scol;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (complete) bv = *reinterpret_cast<const float4*>(p.bias + n0 + lcol);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lrow = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane_e >> 5);
-        float v = acc[i][j][r];
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * (lane_e >> 5)) * LDA + (lane_e & 31)] = acc[i][j][r];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rr = srow + 8 * k;
+        float4 v = *reinterpret_cast<const float4*>(&stage[rr * LDA + scol]);
+        const int lrow = wm * (BM / 2) + i * 32 + rr;
         if (complete) {
           if (m0 + lrow < p.M) {
-            v += bv;
-            if (p.relu) v = fmaxf(v, 0.f);
-            p.out[(size_t)(m0 + lrow) * p.ldc + n0 + lcol] = v;
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.relu) {
+              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(p.out + (size_t)(m0 + lrow) * p.ldc + n0 + lcol) = v;
           }
         } else {
-          d.ws[((size_t)slot * BM + lrow) * BN + lcol] = v;
+          *reinterpret_cast<float4*>(d.ws + ((size_t)slot * BM + lrow) * BN + lcol) = v;
         }
       }
     }
   }
+  // the staging slices alias the A buffers the next segment's prologue writes
+  if (u < u1) __syncthreads();
   if ((ABL & 16) && threadIdx.x == 0 && dbg_n < 15) d.dbg[(size_t)blockIdx.x * 16 + dbg_n++] = __builtin_readcyclecounter();
   }  // segment loop
   if ((ABL & 16) && threadIdx.x == 0) d.dbg[(size_t)blockIdx.x * 16 + 15] = dbg_n;
@@ -495,6 +511,9 @@ GemmPlan gemm_plan(int M, int N, int K, size_t max_ws) {
       // a wave alone on its SIMD loses ~20 % to the per-step LDS/barrier bubble; two hide it
       const double eff = resident >= 2 ? 0.93 : 0.80;
       double cost = rounds * per_wg * unit * resident / eff + 6000.0;
+      // measured (tools/sweep_gemm.py): with thousands of tiles the hardware dispatcher balances
+      // one-tile workgroups ~5 % better than persistent stream-K workgroups finish together
+      if (W != tiles) cost *= 1.05;
       cost += 600.0 * ((W + 255) / 256);            // prologue/epilogue per workgroup round
       if (fix) {
         const double segs = (double)W + (double)(tiles < W ? tiles : W);
