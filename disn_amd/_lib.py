@@ -73,6 +73,9 @@ SIGNATURES = {
     "disn_encode_query_workspace_bytes": (Z, [I, I]),
     "disn_encode_query": (I, [P, C.POINTER(VggWeights), C.POINTER(MlpWeights), P, P, P, P, I, I, P,
                               C.POINTER(C.c_void_p * 5), P, P, P, P, Z, P]),
+    "disn_query_grid_ctx_workspace_bytes": (Z, [L]),
+    "disn_query_grid_ctx": (I, [P, C.POINTER(MlpWeights), P, P, P, C.POINTER(C.c_double * 6), I, L, L, F, P,
+                                P, Z, P]),
     "disn_crc32c": (C.c_uint32, [P, Z, C.c_uint32]),
     "disn_mc_workspace_bytes": (Z, [I]),
     "disn_mc_count": (I, [P, I, F, P, P, Z, P]),

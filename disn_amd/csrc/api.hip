@@ -688,6 +688,54 @@ int disn_query_grid(const disn_mlp_weights_t* w, const float* featmap, const flo
   return 0;
 }
 
+// Same result as disn_query_grid, chunk-pipelined over two streams: the HBM-bound front of chunk
+// i+1 (grid points, projection, gather: ~0.3 ms per 65536 points) runs on ctx->aux into the other
+// half of a double buffer while the MFMA-bound MLP of chunk i (~2 ms) runs on `stream`.
+size_t disn_query_grid_ctx_workspace_bytes(int64_t max_points) {
+  if (max_points <= 0) return 0;
+  const int chunk = chunk_for(max_points);
+  return query_layout(nullptr, 1, chunk, true, true).total +
+         (((size_t)chunk * (DISN_FEAT_DIM + 3) * sizeof(float) + 1023) & ~size_t(255));
+}
+
+int disn_query_grid_ctx(disn_ctx_t* ctx, const disn_mlp_weights_t* w, const float* featmap,
+                        const float* embedding, const float* trans_mat,
+                        const double* sdf_params_host, int R, int64_t k0, int64_t k1,
+                        float sdf_weight, float* out, void* ws, size_t ws_bytes, void* stream) {
+  GridSpec g;
+  if (!ctx || !mlp_weights_ok(w) || !featmap || !embedding || !trans_mat || !out || !ws ||
+      !grid_spec(sdf_params_host, R, &g))
+    return DISN_E_ARG;
+  const int64_t total = (int64_t)g.res * g.res * g.res;
+  if (k0 < 0 || k1 > total || k0 >= k1 || sdf_weight == 0.0f) return DISN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunk = chunk_for(k1 - k0);
+  const QueryWs q = query_layout(ws, 1, chunk, true, true);
+  if (disn_query_grid_ctx_workspace_bytes(k1 - k0) > ws_bytes) return DISN_E_WS;
+  float* feat[2] = {q.feat, reinterpret_cast<float*>(static_cast<char*>(ws) + q.total)};
+  float* pts[2] = {q.pts, feat[1] + (size_t)chunk * DISN_FEAT_DIM};
+  // events: 0 fork, 1/2 buffer ready (aux -> main), 3/4 buffer free (main -> aux)
+  DISN_TRY(hipEventRecord(ctx->ev[0], st));
+  DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
+  DISN_TRY(gemv_launch(embedding, 1, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
+                       q.gemv_ws, st));
+  int i = 0;
+  for (int64_t k = k0; k < k1; k += chunk, ++i) {
+    const int n = (int)((k1 - k) < chunk ? (k1 - k) : chunk);
+    const int b = i & 1;
+    if (i >= 2) DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[3 + b], 0));
+    DISN_TRY(grid_points_launch(g, k, k + n, pts[b], ctx->aux));
+    DISN_TRY(project_gather_launch(featmap, trans_mat, pts[b], n, feat[b], ctx->aux));
+    DISN_TRY(hipEventRecord(ctx->ev[1 + b], ctx->aux));
+    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[1 + b], 0));
+    const int rc = mlp_chunk(w, pts[b], n, q.gbias, feat[b], out + (k - k0), nullptr, nullptr,
+                             sdf_weight, q.mlp, st);
+    if (rc) return rc;
+    DISN_TRY(hipEventRecord(ctx->ev[3 + b], st));
+  }
+  return 0;
+}
+
 size_t disn_mc_workspace_bytes(int R) { return (R < 1 || R > 1290) ? 0 : mc_ws_bytes(R); }
 
 int disn_mc_count(const float* sdf, int R, float iso, uint64_t* counts, void* ws, size_t ws_bytes,

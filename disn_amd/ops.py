@@ -266,15 +266,26 @@ def grid_points(sdf_params, res: int, k0: int, k1: int, device) -> torch.Tensor:
 
 def query_grid(w: MlpWeights, featmap: torch.Tensor, embedding: torch.Tensor, trans_mat: torch.Tensor,
                sdf_params, res: int, k0: int, k1: int, sdf_weight: float = 10.0,
-               ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """SDF of grid points k0..k1-1 of ONE image (featmap [137,137,1472] or [1,...])."""
+               ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+               ctx: Optional[int] = None) -> torch.Tensor:
+    """SDF of grid points k0..k1-1 of ONE image (featmap [137,137,1472] or [1,...]).  With a
+    context the chunks are pipelined over two streams (gather of chunk i+1 under the MLP of chunk i)."""
     dev = featmap.device
     if out is None:
         out = torch.empty((k1 - k0,), dtype=torch.float32, device=dev)
+    p6 = _params6(sdf_params)
+    if ctx:
+        need = lib().disn_query_grid_ctx_workspace_bytes(k1 - k0)
+        if ws is None or ws.numel() < need:
+            ws = _ws(need, dev)
+        check("disn_query_grid_ctx", lib().disn_query_grid_ctx(
+            ctx, C.byref(w), _chk(featmap, "featmap").data_ptr(), _chk(embedding, "embedding").data_ptr(),
+            _chk(trans_mat, "trans_mat").data_ptr(), C.byref(p6), res, k0, k1, float(sdf_weight),
+            out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return out
     need = lib().disn_query_grid_workspace_bytes(k1 - k0)
     if ws is None or ws.numel() < need:
         ws = _ws(need, dev)
-    p6 = _params6(sdf_params)
     check("disn_query_grid", lib().disn_query_grid(
         C.byref(w), _chk(featmap, "featmap").data_ptr(), _chk(embedding, "embedding").data_ptr(),
         _chk(trans_mat, "trans_mat").data_ptr(), C.byref(p6), res, k0, k1, float(sdf_weight),

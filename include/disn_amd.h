@@ -214,6 +214,14 @@ int disn_query_grid(const disn_mlp_weights_t* w, const float* featmap, const flo
                     int64_t k1, float sdf_weight, float* out, void* ws, size_t ws_bytes,
                     void* stream);
 
+/* disn_query_grid, chunk-pipelined over the context's two streams: the HBM-bound front of chunk
+ * i+1 (grid points, projection, gather) runs under the MFMA-bound MLP of chunk i.  Same result. */
+size_t disn_query_grid_ctx_workspace_bytes(int64_t max_points);
+int disn_query_grid_ctx(disn_ctx_t* ctx, const disn_mlp_weights_t* w, const float* featmap,
+                        const float* embedding, const float* trans_mat,
+                        const double* sdf_params_host, int R, int64_t k0, int64_t k1,
+                        float sdf_weight, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------- *
  * Iso-surface: the reference writes the grid to a .dist     *
  * file and shells out to the closed Vega-FEM binary                        *

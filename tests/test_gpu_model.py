@@ -251,3 +251,20 @@ def test_encode_query_equals_encode_plus_query(B, N):
     ref = O.get_model({"imgs": imgs, "sample_pc": pts, "sample_pc_rot": pts, "trans_mat": tms},
                       eng.weights and WeightStore.random_init(0, mode="he").arrays, dtype=np.float64)
     report_close("encode_query vs oracle", sdf_a.cpu().numpy(), ref["pred_sdf"][..., 0], ATOL, RTOL)
+
+
+def test_pipelined_grid_equals_sequential():
+    """disn_query_grid_ctx (gather of chunk i+1 on the aux stream under the MLP of chunk i, double
+    buffer + events) == disn_query_grid, bit for bit, on a range with several chunks and a ragged
+    tail, repeatedly (a buffer-reuse race would differ on some run)."""
+    from disn_amd.engine import SdfEngine
+    from disn_amd.weights import WeightStore
+    eng = SdfEngine(WeightStore.random_init(0, mode="he"))
+    enc = eng.encode(O.synth_inputs(1, 1, 8)["imgs"])
+    R, sp = 128, [-1, -0.9, -0.8, 1, 0.9, 0.8]
+    k0, k1 = 1000, 1000 + 5 * 65536 + 4321
+    ref = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, k0, k1, pipelined=False).clone()
+    for rep in range(4):
+        got = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, k0, k1, pipelined=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), "rep %d: max diff %g" % (rep, float((got - ref).abs().max()))
