@@ -268,3 +268,49 @@ def test_pipelined_grid_equals_sequential():
         got = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, k0, k1, pipelined=True)
         torch.cuda.synchronize()
         assert torch.equal(got, ref), "rep %d: max diff %g" % (rep, float((got - ref).abs().max()))
+
+
+def test_batched_images_equal_single_images():
+    """BASELINE config 4's per-GPU shape: a batch of images through one encode / create_sdf equals the
+    images processed one by one (different GEMM plans for M = B*H*W rows: fp32 noise only), and the
+    sharded driver with a single rank equals the plain one exactly."""
+    from disn_amd import create_sdf as cs, parallel as par
+    from disn_amd.engine import SdfEngine
+    from disn_amd.weights import WeightStore
+    eng = SdfEngine(WeightStore.random_init(0, mode="he"))
+    rng = np.random.default_rng(21)
+    B, R = 4, 24
+    imgs = rng.random((B, 137, 137, 3), dtype=np.float32)
+    tms = np.stack([O.DEMO_TRANS_MAT[0], O.synth_trans_mat(30, 25, 0.8), O.synth_trans_mat(201.5, 30, 0.65),
+                    O.synth_trans_mat(310, 12.5, 0.9)])
+    sps = np.array([[-1, -1, -1, 1, 1, 1], [-0.9, -0.8, -0.7, 0.9, 0.8, 0.7], [-1, -1, -1, 1, 1, 1],
+                    [-0.5, -0.6, -0.7, 0.8, 0.9, 1.0]], np.float64)
+    enc = eng.encode(imgs)
+    for b in range(B):
+        e1 = eng.encode(imgs[b:b + 1])
+        report_close("embedding[%d]" % b, enc.embedding[b].cpu().numpy(), e1.embedding[0].cpu().numpy(), ATOL, RTOL)
+        report_close("featmap[%d]" % b, enc.featmap[b].cpu().numpy(), e1.featmap[0].cpu().numpy(), ATOL, RTOL)
+    batch = cs.create_sdf(eng, imgs, tms, sps, R)
+    assert batch.shape == (B, (R + 1) ** 3)
+    for b in range(B):
+        one = cs.create_sdf(eng, imgs[b:b + 1], tms[b:b + 1], sps[b:b + 1], R)[0]
+        report_close("grid[%d]" % b, batch[b].cpu().numpy(), one.cpu().numpy(), ATOL / 10, RTOL)
+    sharded = par.sharded_create_sdf(eng, imgs, tms, sps, R)          # world size 1: no process group
+    assert torch.equal(sharded, batch)
+
+
+def test_bench_contract_on_gpu():
+    """bench.py --no-extras prints ONE JSON line with the contract's keys, finite value"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 1e5 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert "workload" in d["config"]
