@@ -73,7 +73,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # torch.distributed.run / torchrun
+    if launched:       # also with one rank: same RCCL init / barrier / all-reduce sequence as N ranks
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
@@ -104,18 +105,18 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if launched:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if launched:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if launched:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -240,7 +241,7 @@ def main():
                                           "median; nproc=%d; %s" % (len(ts), os.cpu_count(), cpu_name)}
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

@@ -49,8 +49,10 @@ def sharded_grid(query_fn: Callable[[int, int, int], torch.Tensor], n_images: in
     for b in range(n_images):
         if k1 > k0:
             mine[b, :k1 - k0] = query_fn(b, k0, k1)
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return mine[:, :total]
+    # (a one-rank process group still goes through the collective: the same RCCL call sequence as
+    #  the 8-rank job, which is how the path is exercised on a single-GPU box)
     gathered = torch.empty((world, n_images, pad), dtype=torch.float32, device=device)
     if _supports_flat(group):      # RCCL: one flat collective into the contiguous buffer
         dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)

@@ -314,3 +314,41 @@ def test_bench_contract_on_gpu():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 1e5 and d["dtype"] == "f32" and d["vs_baseline"] is None
     assert "workload" in d["config"]
+
+
+def test_one_rank_rccl_group_runs_the_collective_path(tmp_path):
+    """A one-rank 'nccl' (= RCCL) process group on this GPU: bench.py launched by
+    torch.distributed.run (init, barrier, MAX all-reduce) and the sharded grid's
+    all_gather_into_tensor -- the call sequence of the 8-rank job."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-extras"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["value"] > 1e5
+    script = tmp_path / "shard.py"
+    script.write_text('''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from disn_amd import create_sdf as cs, parallel as par
+from disn_amd.engine import SdfEngine
+from disn_amd.weights import WeightStore
+eng = SdfEngine(WeightStore.random_init(0))
+imgs = np.random.default_rng(0).random((2, 137, 137, 3), dtype=np.float32)
+tm = np.array([[[-68.453156, 5.5086656, -0.37556022], [-17.138561, -84.685486, -0.250198],
+                [-47.284092, -3.6569588, 0.2493176], [101.133705, 101.34268, 1.4305686]]] * 2, np.float32)
+sp = np.array([[-1, -1, -1, 1, 1, 1]] * 2, np.float64)
+a = par.sharded_create_sdf(eng, imgs, tm, sp, 20)
+b = cs.create_sdf(eng, imgs, tm, sp, 20)
+assert torch.equal(a, b), float((a - b).abs().max())
+dist.barrier(); dist.destroy_process_group(); print("SHARD_OK")
+''' % root)
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env2)
+    assert r.returncode == 0 and "SHARD_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
