@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / grid / cpu legs")
-    ap.add_argument("--cpu-runs", type=int, default=3)
+    ap.add_argument("--cpu-runs", type=int, default=5)
     args = ap.parse_args()
 
     import torch
@@ -235,10 +235,31 @@ def main():
             cpu_name = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
         except Exception:
             pass
-        line["cpu_baseline"] = {"value": N_POINTS / med, "unit": "points/s", "cores": torch.get_num_threads(),
+        # one-thread figure: torch intra-op threads = 1; numpy's BLAS pool is limited through
+        # threadpoolctl when available
+        nthreads = torch.get_num_threads()
+        one = None
+        try:
+            torch.set_num_threads(1)
+            try:
+                from threadpoolctl import threadpool_limits
+                limiter = threadpool_limits(limits=1)
+            except Exception:
+                limiter = None
+            t0 = time.perf_counter()
+            O.get_model(feed, Wn)
+            one = time.perf_counter() - t0
+            if limiter is not None:
+                limiter.unregister() if hasattr(limiter, "unregister") else limiter.restore_original_limits()
+        except Exception:
+            pass
+        finally:
+            torch.set_num_threads(nthreads)
+        line["cpu_baseline"] = {"value": N_POINTS / med, "unit": "points/s", "cores": nthreads,
                                 "kind": "port", "seconds_per_step": med,
-                                "sample": "%d full steps (encode + 2048 points) of the numpy/torch-CPU oracle, "
-                                          "median; nproc=%d; %s" % (len(ts), os.cpu_count(), cpu_name)}
+                                "value_1thread": (N_POINTS / one) if one else None,
+                                "sample": "%d full steps (encode + 2048 points) of the numpy/torch-CPU oracle after "
+                                          "1 warm-up, median; nproc=%d; %s" % (len(ts), os.cpu_count(), cpu_name)}
     if rank == 0:
         print(json.dumps(line))
     if launched:

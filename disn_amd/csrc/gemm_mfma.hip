@@ -246,7 +246,9 @@ void gemm_f32_mfma(const GemmDev d) {
           af[kb][i] = *reinterpret_cast<const float4*>(la + i * 32 * LDA + kb * 8);
     }
     if (!(ABL & 2)) load_b(bn);
-    if (!(ABL & 1)) load_a(a_ld, ok_ld);
+    // (the K=27 first layer has a single k-step: nothing to prefetch, and its loader is 16 scalar
+    //  loads per row)
+    if (!(ABL & 1) && MODE != GEMM_CONV3_C3) load_a(a_ld, ok_ld);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
@@ -294,7 +296,7 @@ void gemm_f32_mfma(const GemmDev d) {
     load_a(ra0, ok0);          // tile s_begin
     load_b(b0);                // B of s_begin
     store_a(0, ra0, ok0);
-    load_a(ra0, ok0);          // tile s_begin+1 (in flight while step s_begin computes)
+    if (MODE != GEMM_CONV3_C3) load_a(ra0, ok0);   // tile s_begin+1 (in flight while step s_begin computes)
     if (ABL) {                 // give every register set a defined value for the ablated variants
       ra1[0] = ra0[0];
 #pragma unroll
@@ -384,13 +386,20 @@ __global__ __launch_bounds__(256) void streamk_fixup(const GemmDev d) {
   if (unit_begin(d.units, d.W, w) <= tb && unit_begin(d.units, d.W, w + 1) >= te) return;
   const int idx4 = blockIdx.y * 256 + threadIdx.x;
   const int lrow = idx4 / (BN / 4), lcol = (idx4 - lrow * (BN / 4)) * 4;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (; w < d.W; ++w) {
-    const long wb = unit_begin(d.units, d.W, w), we = unit_begin(d.units, d.W, w + 1);
-    if (wb >= te) break;
-    if (we <= wb) continue;  // empty range (W > units)
-    const int slot = (wb >= tb) ? 2 * w : 2 * w + 1;  // segment starts the workgroup's range?
-    const float4 u = *reinterpret_cast<const float4*>(d.ws + ((size_t)slot * BM + lrow) * BN + lcol);
+  // contributing workgroups w .. w_last (the planner guarantees W <= units: no empty ranges).  Only
+  // the first one can have started before this tile (its segment is then its LAST -> slab 2w+1);
+  // every later one starts inside the tile (its FIRST segment -> slab 2w).  Both bounds are found
+  // once (wave-uniform), so the summation loop is divide-free and its loads are independent.
+  int w_last = (int)(((te - 1) * d.W) / d.units);
+  while (w_last + 1 < d.W && unit_begin(d.units, d.W, w_last + 1) <= te - 1) ++w_last;
+  while (w_last > 0 && unit_begin(d.units, d.W, w_last) > te - 1) --w_last;
+  const float* base = d.ws + (size_t)lrow * BN + lcol;
+  const size_t slab = (size_t)BM * BN;
+  const int first_slot = (unit_begin(d.units, d.W, w) >= tb) ? 2 * w : 2 * w + 1;
+  float4 v = *reinterpret_cast<const float4*>(base + (size_t)first_slot * slab);
+#pragma unroll 4
+  for (int k = w + 1; k <= w_last; ++k) {
+    const float4 u = *reinterpret_cast<const float4*>(base + (size_t)(2 * k) * slab);
     v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
   }
   const int mt = tile / d.ntiles, nt = tile - mt * d.ntiles;
