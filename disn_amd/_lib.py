@@ -44,6 +44,13 @@ class MlpWeights(C.Structure):  # disn_mlp_weights_t
     _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS]
 
 
+NUM_VARS = 56
+
+
+class ParamLayout(C.Structure):  # disn_param_layout_t
+    _fields_ = [("offset", C.c_int64 * NUM_VARS), ("count", C.c_int64 * NUM_VARS), ("total", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/disn_amd.h
 I, Z, P, F, L = C.c_int, C.c_size_t, C.c_void_p, C.c_float, C.c_int64
 SIGNATURES = {
@@ -77,6 +84,17 @@ SIGNATURES = {
     "disn_query_grid_ctx": (I, [P, C.POINTER(MlpWeights), P, P, P, C.POINTER(C.c_double * 6), I, L, L, F, P,
                                 P, Z, P]),
     "disn_crc32c": (C.c_uint32, [P, Z, C.c_uint32]),
+    "disn_param_layout": (I, [C.POINTER(ParamLayout)]),
+    "disn_train_workspace_bytes": (Z, [I, I]),
+    "disn_train_step": (I, [P, P, P, P, P, P, P, I, I, F, F, F, P, P, P, Z, P]),
+    "disn_adam_update": (I, [P, P, P, P, L, F, F, F, F, F, P]),
+    "disn_dense_backward_workspace_bytes": (Z, [I, I, I]),
+    "disn_dense_backward": (I, [P, I, I, P, P, P, I, I, F, P, P, P, P, Z, P]),
+    "disn_conv3x3_backward_workspace_bytes": (Z, [I, I, I, I, I]),
+    "disn_conv3x3_backward": (I, [P, I, I, I, I, P, P, P, I, F, P, P, P, P, Z, P]),
+    "disn_maxpool2x2_backward": (I, [P, P, I, I, I, I, P, P]),
+    "disn_resize_bilinear_backward": (I, [P, I, I, I, I, I, I, I, I, P, I, P]),
+    "disn_gather_backward": (I, [P, P, I, I, P, P]),
     "disn_mc_workspace_bytes": (Z, [I]),
     "disn_mc_count": (I, [P, I, F, P, P, Z, P]),
     "disn_mc_emit": (I, [P, C.POINTER(C.c_double * 6), I, F, P, P, P, Z, P]),

@@ -23,6 +23,10 @@ ARCH = "gfx950"
 SOURCES = {
     "gemm_mfma.hip": [],
     "gemv.hip": [],
+    "gemm_tn_mfma.hip": [],
+    "backward.hip": [],
+    "backward_img.hip": ["-munsafe-fp-atomics", "-ffp-contract=off"],  # same lerp weights as the forward
+    "train.hip": [],
     "mlp_small.hip": [],
     "mlp_fused.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],

@@ -71,6 +71,84 @@ hipError_t grid_points_launch(const GridSpec& g, int64_t k0, int64_t k1, float* 
                               hipStream_t st);
 hipError_t scale_div_launch(const float* in, float divisor, int64_t n, float* out, hipStream_t st);
 
+// ---- gemm_tn_mfma.hip: weight gradients C[P][Q] = sum_m A[m][p] B[m][q] ----------------
+struct TnParams {
+  const float* a;  // dense: [M][lda]; conv (Cin > 0): NHWC activations, P = 9*Cin (implicit im2col)
+  int lda;
+  const float* b;  // [M][ldb]
+  int ldb;
+  long M;
+  int P, Q;  // multiples of 64
+  float* c;  // [P][ldc]
+  int ldc;
+  int H, W, Cin;
+  float l2;           // the fix-up adds l2 * wcur (weight-decay gradient); 0: nothing
+  const float* wcur;  // same layout as c
+};
+size_t gemm_tn_ws_bytes(long M, int P, int Q);
+hipError_t gemm_tn_launch(const TnParams& p, float* ws, hipStream_t st);
+
+// ---- backward.hip: the small kernels of the training step --------------------------
+// packed (disn_pack_kn order) form of W^T for dX = dZ W^T; W is [K][N], K % 32 == 0, N % 8 == 0
+hipError_t pack_kn_T_launch(const float* w, int K, int N, float* packed, hipStream_t st);
+// packed form of the flipped / transposed 3x3 kernel for conv backward-data:
+// rows (8-t)*Cout + co, cols ci  <-  W[t][ci][co]
+hipError_t pack_conv_bwd_launch(const float* w, int Cin, int Cout, float* packed, hipStream_t st);
+// dZ = dY * (Y > 0) in place (relu != 0) and column sums of dZ -> db[N] (+= when accumulate)
+size_t colsum_ws_bytes(long M, int N);
+hipError_t relu_bwd_colsum_launch(float* dy, const float* y, long M, int N, int relu, float* db,
+                                  float* ws, hipStream_t st);
+// d(sdf_loss)/d(pred): -sign(10*gt - pred) * w * 1000/M, w = 4 if gt <= 0.01 else 1
+hipError_t loss_grad_launch(const float* pred, const float* gt, long M, float sdf_weight,
+                            float mask_weight, float* dpred, hipStream_t st);
+// last layer of both streams: dZ5 = (dpred w6) * (h5 > 0) -> dz5 [M][256]; dw6[k] = sum_m h5 dpred;
+// db6 = sum dpred; db5 = colsum(dz5).  ws >= final_bwd_ws_bytes
+size_t final_bwd_ws_bytes(long M);
+hipError_t final_bwd_launch(const float* h5, const float* dpred, long M, const float* w6, float* dz5,
+                            float* dw6, float* db6, float* db5, float l2, float* ws, hipStream_t st);
+// first layer (K = 3): dw1[3][64] = sum_m p[m][c] dz1[m][n] (+ l2 w1)
+hipError_t embed_bwd_launch(const float* pts, const float* dz1, long M, float* dw1, const float* w1,
+                            float l2, float* ws, hipStream_t st);
+// per-image sums: out[b][n] = sum over the N rows of image b of x[b*N + i][n]
+hipError_t image_colsum_launch(const float* x, int B, long N, int C, float* out, float* ws,
+                               hipStream_t st);
+// rank-B outer product: c[k][n] (+ l2 w) = sum_b x[b][k] dy[b][n]
+hipError_t outer_launch(const float* x, const float* dy, int B, int K, int N, float* c, const float* wcur,
+                        float l2, hipStream_t st);
+// dx[b][k] = sum_n W[k][n] dy[b][n] (* (xact[b][k] > 0) when xact != nullptr)
+hipError_t gemv_t_launch(const float* w_kn, const float* dy, int B, int K, int N, const float* xact,
+                         float* dx, hipStream_t st);
+
+// out[i] = src[i] + l2 * w[i]
+hipError_t axpby_launch(const float* src, const float* w, float l2, size_t n, float* out,
+                        hipStream_t st);
+// out5 = {accuracy, sdf_loss_realvalue, sdf_loss, regularization (read), overall_loss}
+hipError_t loss_reduce_launch(const float* pred, const float* gt, long M, float sdf_weight,
+                              float mask_weight, float* out5, hipStream_t st);
+struct SumsqSegs {
+  int n;
+  long off[32], cnt[32];
+};
+// *out = half_wd * sum over the segments of sum(params[off..off+cnt)^2); ws: 32*64 floats
+hipError_t sumsq_launch(const float* params, const SumsqSegs& segs, float half_wd, float* out, float* ws,
+                        hipStream_t st);
+// TF Adam on n floats (n % 4 == 0); the gradient is scaled by gscale first (1/world for DDP)
+hipError_t adam_launch(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float b1,
+                       float b2, float eps, float gscale, hipStream_t st);
+
+// ---- backward_img.hip ------------------------------------------------------------------
+// dmap [B,137,137,1472] (zeroed by the caller) += resampler-grad of dfeat [B*N][1472] at xy [B*N][2]
+hipError_t gather_bwd_launch(const float* dfeat, const float* xy, int B, int N, float* dmap,
+                             hipStream_t st);
+// din [B,Hin,Win,C] (+)= ResizeBilinearGrad of channels [coff, coff+C) of dout [B,Hout,Wout,cstride]
+hipError_t resize_bwd_launch(const float* dout, int B, int Hin, int Win, int C, int Hout, int Wout,
+                             int out_cstride, int out_coff, float* din, int accumulate, hipStream_t st);
+// x [B,H,W,C] pre-pool activations, dy [B,H/2,W/2,C] -> dx [B,H,W,C] (every element written)
+hipError_t maxpool_bwd_launch(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
+                              hipStream_t st);
+// 3x3 SAME patches of a 3-channel image as [B*H*W][64] rows (27 used, rest zero)
+hipError_t im2col_c3_launch(const float* img, int B, int H, int W, float* col, hipStream_t st);
+
 // ---- marching_cubes.hip (compiled with -ffp-contract=off) ------------------------
 size_t mc_ws_bytes(int R);
 // counts[0] = vertices, counts[1] = triangles (device memory); fills ws for mc_emit_launch

@@ -291,3 +291,112 @@ def query_grid(w: MlpWeights, featmap: torch.Tensor, embedding: torch.Tensor, tr
         _chk(trans_mat, "trans_mat").data_ptr(), C.byref(p6), res, k0, k1, float(sdf_weight),
         out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
     return out
+
+
+# ---------------------------------------------------------------------------
+# training step
+# ---------------------------------------------------------------------------
+def param_layout() -> _lib.ParamLayout:
+    """offsets / counts (in floats) of the 56 variables in the flat parameter buffer"""
+    L = _lib.ParamLayout()
+    check("disn_param_layout", lib().disn_param_layout(C.byref(L)))
+    return L
+
+
+def dense_backward(a: torch.Tensor, w_kn: torch.Tensor, y: Optional[torch.Tensor], dy: torch.Tensor,
+                   wd: float = 0.0, need_da: bool = True):
+    """backward of out = act(a @ w + b): -> (da or None, dw, db); dy is masked IN PLACE when y is given"""
+    a, w_kn, dy = _chk(a, "a"), _chk(w_kn, "w_kn"), _chk(dy, "dy")
+    M, K = a.shape
+    N = w_kn.shape[1]
+    dev = a.device
+    da = torch.empty((M, K), dtype=torch.float32, device=dev) if need_da else None
+    dw = torch.empty((K, N), dtype=torch.float32, device=dev)
+    db = torch.empty((N,), dtype=torch.float32, device=dev)
+    ws = _ws(lib().disn_dense_backward_workspace_bytes(M, K, N), dev)
+    check("disn_dense_backward", lib().disn_dense_backward(
+        a.data_ptr(), K, K, w_kn.data_ptr(), _chk(y, "y").data_ptr() if y is not None else None,
+        dy.data_ptr(), M, N, float(wd), da.data_ptr() if need_da else None, dw.data_ptr(), db.data_ptr(),
+        ws.data_ptr(), ws.numel(), _stream()))
+    return da, dw, db
+
+
+def conv3x3_backward(x: torch.Tensor, w_hwio: torch.Tensor, y: Optional[torch.Tensor], dy: torch.Tensor,
+                     wd: float = 0.0, need_dx: bool = True):
+    """backward of a SAME 3x3 conv (+ReLU when y is given): -> (dx or None, dw [3,3,Cin,Cout], db)"""
+    x, w_hwio, dy = _chk(x, "x"), _chk(w_hwio, "w_hwio"), _chk(dy, "dy")
+    B, H, W, Cin = x.shape
+    Cout = w_hwio.shape[-1]
+    dev = x.device
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty((3, 3, Cin, Cout), dtype=torch.float32, device=dev)
+    db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+    ws = _ws(lib().disn_conv3x3_backward_workspace_bytes(B, H, W, Cin, Cout), dev)
+    check("disn_conv3x3_backward", lib().disn_conv3x3_backward(
+        x.data_ptr(), B, H, W, Cin, w_hwio.data_ptr(), _chk(y, "y").data_ptr() if y is not None else None,
+        dy.data_ptr(), Cout, float(wd), dx.data_ptr() if need_dx else None, dw.data_ptr(), db.data_ptr(),
+        ws.data_ptr(), ws.numel(), _stream()))
+    return dx, dw, db
+
+
+def maxpool2x2_backward(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    x, dy = _chk(x, "x"), _chk(dy, "dy")
+    B, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    check("disn_maxpool2x2_backward", lib().disn_maxpool2x2_backward(
+        x.data_ptr(), dy.data_ptr(), B, H, W, Cc, dx.data_ptr(), _stream()))
+    return dx
+
+
+def resize_bilinear_backward(dout: torch.Tensor, in_h: int, in_w: int, channels: Optional[int] = None,
+                             out_coff: int = 0, din: Optional[torch.Tensor] = None,
+                             accumulate: bool = False) -> torch.Tensor:
+    dout = _chk(dout, "dout")
+    B, Ho, Wo, cs = dout.shape
+    Cc = channels or cs
+    if din is None:
+        din = torch.empty((B, in_h, in_w, Cc), dtype=torch.float32, device=dout.device)
+        accumulate = False
+    check("disn_resize_bilinear_backward", lib().disn_resize_bilinear_backward(
+        dout.data_ptr(), B, in_h, in_w, Cc, Ho, Wo, cs, out_coff, din.data_ptr(), int(accumulate),
+        _stream()))
+    return din
+
+
+def gather_backward(dfeat: torch.Tensor, xy: torch.Tensor) -> torch.Tensor:
+    dfeat, xy = _chk(dfeat, "dfeat"), _chk(xy, "xy")
+    B, N, _ = dfeat.shape
+    dmap = torch.empty((B, IMG, IMG, FEAT_DIM), dtype=torch.float32, device=dfeat.device)
+    check("disn_gather_backward", lib().disn_gather_backward(dfeat.data_ptr(), xy.data_ptr(), B, N,
+                                                             dmap.data_ptr(), _stream()))
+    return dmap
+
+
+def train_step(params: torch.Tensor, grads: torch.Tensor, img: torch.Tensor, trans_mat: torch.Tensor,
+               pts: torch.Tensor, pts_rot: torch.Tensor, gt: torch.Tensor, wd: float = 1e-5,
+               sdf_weight: float = 10.0, mask_weight: float = 4.0, ws: Optional[torch.Tensor] = None):
+    """forward + get_loss + gradients into `grads`: -> (pred [B,N], losses [5] device tensor)"""
+    B, N = pts.shape[0], pts.shape[1]
+    dev = params.device
+    need = lib().disn_train_workspace_bytes(B, N)
+    if need == 0:
+        raise ValueError("unsupported training shape B=%d N=%d (B*N <= 65536)" % (B, N))
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, dev)
+    pred = torch.empty((B, N), dtype=torch.float32, device=dev)
+    losses = torch.empty((5,), dtype=torch.float32, device=dev)
+    check("disn_train_step", lib().disn_train_step(
+        _chk(params, "params").data_ptr(), _chk(grads, "grads").data_ptr(), _chk(img, "img").data_ptr(),
+        _chk(trans_mat, "trans_mat").data_ptr(), _chk(pts, "pts").data_ptr(),
+        _chk(pts_rot, "pts_rot").data_ptr(), _chk(gt, "gt").data_ptr(), B, N, float(wd),
+        float(sdf_weight), float(mask_weight), pred.data_ptr(), losses.data_ptr(), ws.data_ptr(),
+        ws.numel(), _stream()))
+    return pred, losses
+
+
+def adam_update(params: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr_t: float,
+                beta1: float = 0.5, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0) -> None:
+    check("disn_adam_update", lib().disn_adam_update(
+        _chk(params, "params").data_ptr(), _chk(grads, "grads").data_ptr(), _chk(m, "m").data_ptr(),
+        _chk(v, "v").data_ptr(), params.numel(), float(lr_t), float(beta1), float(beta2), float(eps),
+        float(grad_scale), _stream()))

@@ -1,0 +1,154 @@
+"""Host side of the training step -- mirrors train/train_sdf.py of the reference.
+
+  get_learning_rate   train/train_sdf.py:153-161 (staircase exponential decay, floor 1e-6)
+  Trainer.step        one sess.run([train_op, step, lr, loss, pred_sdf, ...]) of :371-387
+  Trainer.save/restore  tf.train.Saver over every global variable whose name lacks 'lr'/'batch'
+                      (:285-286): the model variables AND the Adam slots '<var>/Adam', '<var>/Adam_1',
+                      'beta1_power', 'beta2_power', as a TF V2 bundle (disn_amd/tf_checkpoint.py)
+
+All device work is the HIP library (disn_train_step / disn_adam_update); data-parallel training is one
+process per GPU, each on its own shard of the batch, with ONE sum all-reduce over the flat gradient
+buffer (RCCL over xGMI; gloo on CPU tensors is not supported: the path has no CPU fallback) and the
+1/world scale folded into the Adam kernel.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .weights import WeightStore, variable_shapes
+
+LOSS_NAMES = ("accuracy", "sdf_loss_realvalue", "sdf_loss", "regularization", "overall_loss")
+VARIABLE_ORDER = tuple(variable_shapes())  # == the order of disn_param_layout
+
+
+def get_learning_rate(step: int, batch_size: int, base_lr: float = 1e-4, decay_step: int = 200000,
+                      decay_rate: float = 0.9) -> float:
+    """tf.train.exponential_decay(base, step*batch, decay_step, decay_rate, staircase=True) floored
+    at 1e-6 (train/train_sdf.py:153-161; flags :36-40)"""
+    return max(base_lr * decay_rate ** ((step * batch_size) // decay_step), 1e-6)
+
+
+class FlatParams:
+    """the 56 variables of the graph in ONE device buffer (include/disn_amd.h, disn_param_layout)"""
+
+    def __init__(self, device):
+        self.layout = ops.param_layout()
+        self.total = int(self.layout.total)
+        self.device = device
+        self.shapes = variable_shapes()
+        self.index = {n: i for i, n in enumerate(VARIABLE_ORDER)}
+
+    def zeros(self) -> torch.Tensor:
+        return torch.zeros(self.total, dtype=torch.float32, device=self.device)
+
+    def view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
+        i = self.index[name]
+        o, c = int(self.layout.offset[i]), int(self.layout.count[i])
+        return buf[o:o + c].view(self.shapes[name])
+
+    def from_store(self, store: WeightStore) -> torch.Tensor:
+        host = np.zeros(self.total, np.float32)
+        for n, i in self.index.items():
+            o, c = int(self.layout.offset[i]), int(self.layout.count[i])
+            host[o:o + c] = np.asarray(store[n], np.float32).reshape(-1)
+        return torch.from_numpy(host).to(self.device)
+
+    def to_arrays(self, buf: torch.Tensor, suffix: str = "") -> Dict[str, np.ndarray]:
+        host = buf.detach().cpu().numpy()
+        out = {}
+        for n, i in self.index.items():
+            o, c = int(self.layout.offset[i]), int(self.layout.count[i])
+            out[n + suffix] = host[o:o + c].reshape(self.shapes[n]).copy()
+        return out
+
+
+class Trainer:
+    def __init__(self, store: WeightStore, device="cuda:0", batch_size: int = 20, base_lr: float = 1e-4,
+                 decay_step: int = 200000, decay_rate: float = 0.9, wd: float = 1e-5,
+                 sdf_weight: float = 10.0, mask_weight: float = 4.0, beta1: float = 0.5,
+                 beta2: float = 0.999, eps: float = 1e-8, process_group=None):
+        self.flat = FlatParams(torch.device(device))
+        self.params = self.flat.from_store(store)
+        self.grads = self.flat.zeros()
+        self.m = self.flat.zeros()
+        self.v = self.flat.zeros()
+        self.step_count = 0  # the reference's `batch` variable (global step)
+        self.batch_size = batch_size  # GLOBAL batch (all ranks), as the LR schedule counts samples
+        self.base_lr, self.decay_step, self.decay_rate = base_lr, decay_step, decay_rate
+        self.wd, self.sdf_weight, self.mask_weight = wd, sdf_weight, mask_weight
+        self.beta1, self.beta2, self.eps = beta1, beta2, eps
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self._ws: Optional[torch.Tensor] = None
+
+    # ---- one step ---------------------------------------------------------------------
+    def forward_backward(self, feed: Dict[str, torch.Tensor]):
+        """gradients of THIS rank's shard into self.grads; -> (pred, losses tensor[5])"""
+        B, N = feed["sample_pc"].shape[:2]
+        need = ops.lib().disn_train_workspace_bytes(B, N)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.params.device)
+        return ops.train_step(self.params, self.grads, feed["imgs"], feed["trans_mat"], feed["sample_pc"],
+                              feed["sample_pc_rot"], feed["sdf"], self.wd, self.sdf_weight,
+                              self.mask_weight, ws=self._ws)
+
+    def learning_rate(self) -> float:
+        return get_learning_rate(self.step_count, self.batch_size, self.base_lr, self.decay_step,
+                                 self.decay_rate)
+
+    def apply_gradients(self) -> float:
+        lr = self.learning_rate()
+        t = self.step_count + 1
+        lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        if self.world > 1:
+            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        ops.adam_update(self.params, self.grads, self.m, self.v, lr_t, self.beta1, self.beta2, self.eps,
+                        1.0 / self.world)
+        self.step_count = t
+        return lr
+
+    def step(self, feed: Dict[str, torch.Tensor]):
+        """-> (pred [B,N] device, losses dict name -> device scalar, lr)"""
+        pred, losses = self.forward_backward(feed)
+        lr = self.apply_gradients()
+        return pred, {n: losses[i] for i, n in enumerate(LOSS_NAMES)}, lr
+
+    # ---- checkpoints --------------------------------------------------------------------
+    def state_arrays(self) -> Dict[str, np.ndarray]:
+        out = self.flat.to_arrays(self.params)
+        out.update(self.flat.to_arrays(self.m, "/Adam"))
+        out.update(self.flat.to_arrays(self.v, "/Adam_1"))
+        out["beta1_power"] = np.asarray(self.beta1 ** (self.step_count + 1), np.float32)
+        out["beta2_power"] = np.asarray(self.beta2 ** (self.step_count + 1), np.float32)
+        return out
+
+    def weight_store(self) -> WeightStore:
+        return WeightStore(self.flat.to_arrays(self.params))
+
+    def save(self, prefix: str) -> None:
+        from . import tf_checkpoint as tfc
+        tfc.save_checkpoint(prefix, self.state_arrays())
+
+    def restore(self, prefix: str) -> int:
+        """prefix + exact-shape match, as load_model (train/train_sdf.py:190-219); -> #restored"""
+        from . import tf_checkpoint as tfc
+        arrays = tfc.load_checkpoint(prefix)
+        n = 0
+        for buf, suffix in ((self.params, ""), (self.m, "/Adam"), (self.v, "/Adam_1")):
+            for name in VARIABLE_ORDER:
+                a = arrays.get(name + suffix)
+                if a is not None and tuple(a.shape) == tuple(self.flat.shapes[name]):
+                    self.flat.view(buf, name).copy_(torch.from_numpy(np.ascontiguousarray(a, np.float32)))
+                    n += 1
+        b2 = arrays.get("beta2_power")
+        if b2 is not None and 0.0 < float(b2) < 1.0:
+            self.step_count = max(int(round(math.log(float(b2)) / math.log(self.beta2))) - 1, 0)
+        return n

@@ -245,6 +245,77 @@ int disn_mc_count(const float* sdf, int R, float iso, uint64_t* counts, void* ws
 int disn_mc_emit(const float* sdf, const double* sdf_params_host, int R, float iso, float* verts,
                  int32_t* faces, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------- *
+ * Training step (BASELINE config 5): what ONE                *
+ * sess.run([train_op, losses...]) of train/train_sdf.py:371-387 executes.  *
+ * Every variable of the graph (train/train_sdf.py:266-268 minimises over   *
+ * ALL globals, the VGG is fine-tuned) lives in ONE flat float32 device     *
+ * buffer, each in the reference's own TF layout ([kh,kw,Cin,Cout] =        *
+ * [K][N] row-major; biases [N]), at the offsets disn_param_layout returns  *
+ * (offsets are multiples of 64 floats; the gaps are never written: keep    *
+ * them zero).  Variable order:                                             *
+ *   0..25   vgg_16/conv{1..5}/conv{i}_{j}/{weights,biases}                 *
+ *   26..31  vgg_16/{fc6,fc7,fc8}/{weights,biases}                          *
+ *   32..43  sdfprediction/{fold1/conv1,fold1/conv2,fold1/conv3,            *
+ *           fold2/conv1,fold2/conv2,fold2/conv5}/{weights,biases}          *
+ *   44..55  sdfprediction_imgfeat/ (same six layers)                       *
+ * `grads` and the Adam slots m, v have the same layout, so data-parallel   *
+ * training all-reduces ONE buffer and updates with ONE kernel.             *
+ * ---------------------------------------------------------------------- */
+#define DISN_NUM_VARS 56
+typedef struct disn_param_layout {
+  int64_t offset[DISN_NUM_VARS]; /* in floats */
+  int64_t count[DISN_NUM_VARS];
+  int64_t total; /* floats, multiple of 64 */
+} disn_param_layout_t;
+int disn_param_layout(disn_param_layout_t* out);
+
+/* Forward (rows A..H, activations kept in ws), get_loss
+ * (models/model_normalization.py:254-300) and the gradient of overall_loss
+ * w.r.t. every variable, written to `grads` (layout above; weight-decay term
+ * wd*w included for every '/weights' variable).  B*N <= 65536.
+ * gt [B,N] = the fed 'sdf' (sdf_val - 0.003, train/train_sdf.py:375).
+ * pred [B,N] = pred_sdf (un-divided).  losses: 5 device floats =
+ * {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}. */
+size_t disn_train_workspace_bytes(int B, int N);
+int disn_train_step(const float* params, float* grads, const float* img, const float* trans_mat,
+                    const float* pts, const float* pts_rot, const float* gt, int B, int N, float wd,
+                    float sdf_weight, float mask_weight, float* pred, float* losses, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* tf.train.AdamOptimizer update (train/train_sdf.py:251) on n floats (n % 4 == 0):
+ * g = grads*grad_scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * params -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+int disn_adam_update(float* params, const float* grads, float* m, float* v, int64_t n, float lr_t,
+                     float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* Building blocks of the step (unit-test / composition surface).
+ * disn_dense_backward: one [1,1] conv layer out = act(a W + b).  dy [M][N] is the gradient w.r.t.
+ *   the layer OUTPUT; with y (the saved post-ReLU output) non-NULL it is masked in place to the
+ *   pre-activation gradient first.  Outputs db [N], dw [K][N] (+ wd*w), da [M][K] (NULL: skipped).
+ *   a [M][lda] (first K columns), w_kn raw [K][N]; K, N multiples of 64.
+ * disn_conv3x3_backward: same for a SAME 3x3 conv, x [B,H,W,Cin], w_hwio [3,3,Cin,Cout],
+ *   Cin == 3 (dx must be NULL) or a multiple of 64, Cout a multiple of 64. */
+size_t disn_dense_backward_workspace_bytes(int M, int K, int N);
+int disn_dense_backward(const float* a, int lda, int K, const float* w_kn, const float* y, float* dy,
+                        int M, int N, float wd, float* da, float* dw, float* db, void* ws,
+                        size_t ws_bytes, void* stream);
+size_t disn_conv3x3_backward_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int disn_conv3x3_backward(const float* x, int B, int H, int W, int Cin, const float* w_hwio,
+                          const float* y, float* dy, int Cout, float wd, float* dx, float* dw,
+                          float* db, void* ws, size_t ws_bytes, void* stream);
+/* dx [B,H,W,C]: dy routed to the first maximum of each 2x2 window of x, zero elsewhere (H, W even) */
+int disn_maxpool2x2_backward(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
+                             void* stream);
+/* din [B,Hin,Win,C] (= or +=) gradient of disn_resize_bilinear w.r.t. its input, given dout (channels
+ * [out_coff, out_coff+C) of a [B,Hout,Wout,out_cstride] tensor).  C, strides multiples of 4. */
+int disn_resize_bilinear_backward(const float* dout, int B, int Hin, int Win, int C, int Hout, int Wout,
+                                  int out_cstride, int out_coff, float* din, int accumulate,
+                                  void* stream);
+/* dfeatmap [B,137,137,1472] = gradient of disn_gather w.r.t. featmap (zeroed here, then fp32 atomics) */
+int disn_gather_backward(const float* dfeat, const float* xy, int B, int N, float* dfeatmap,
+                         void* stream);
+
 /* Host utility: Wavefront .obj writer ("v x y z" / "f a b c", 1-based) for HOST arrays; the
  * reference's output artefact (test/create_sdf.py:311).  Returns 0, or DISN_E_ARG on I/O error. */
 int disn_write_obj(const char* path, const float* verts_host, int64_t nv, const int32_t* faces_host,

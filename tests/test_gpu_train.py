@@ -1,0 +1,291 @@
+"""GPU parity of the training step: every backward building block and the whole
+disn_train_step, through the C ABI, against torch-CPU float64 autograd (oracle/train_oracle.py).
+Gradients are sums of up to 4e5 products: the tolerance of each test is relative to the scale of the
+reference gradient (max |ref|), written in the test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fnn
+
+from conftest import report_close
+from oracle import disn_oracle as O
+from oracle import train_oracle as T
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from disn_amd import ops as _ops
+    return _ops
+
+
+def rel_close(name, got, ref, rtol_of_max):
+    ref = np.asarray(ref, np.float64)
+    report_close(name, got, ref, atol=rtol_of_max * max(float(np.abs(ref).max()), 1e-30))
+
+
+# ------------------------------------------------------------------ dense layer ----------------
+@pytest.mark.parametrize("M,K,N,relu", [(1000, 64, 256, True), (4096, 512, 512, True), (777, 1472, 512, True),
+                                        (2048, 256, 64, False), (33, 512, 256, True), (20000, 512, 512, True)])
+def test_dense_backward(ops, M, K, N, relu):
+    rng = np.random.default_rng(M + K + N)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / math.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    wd = 1e-3
+    at = torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    y = at @ wt + bt
+    if relu:
+        y = torch.relu(y)
+    (y * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    y32 = host(torch.relu(dev(a) @ dev(w) + dev(b))) if relu else None
+    # the mask must come from the SAME activations the gradient is checked against
+    if relu:
+        y32 = np.where(y.detach().numpy() > 0, np.maximum(y32, 1e-30), 0.0).astype(np.float32)
+    da, dw, db = ops.dense_backward(dev(a), dev(w), dev(y32) if relu else None, dev(dy), wd=wd)
+    rel_close("da", host(da), at.grad.numpy(), 2e-6)
+    rel_close("dw", host(dw), wt.grad.numpy() + wd * w.astype(np.float64), 2e-6)
+    rel_close("db", host(db), bt.grad.numpy(), 2e-6)
+
+
+# ------------------------------------------------------------------ 3x3 conv -------------------
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 64, 128), (1, 28, 128, 64), (3, 20, 3, 64), (2, 56, 64, 64),
+                                          (2, 14, 512, 512), (8, 14, 512, 512)])
+def test_conv3x3_backward(ops, B, H, Cin, Cout):
+    rng = np.random.default_rng(B * 1000 + H + Cin)
+    x = rng.standard_normal((B, H, H, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / math.sqrt(9 * Cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    dy = rng.standard_normal((B, H, H, Cout)).astype(np.float32)
+    wd = 1e-3
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    y = torch.relu(Fnn.conv2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), bt, padding=1).permute(0, 2, 3, 1))
+    (y * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    y32 = y.detach().numpy().astype(np.float32)
+    y32 = np.where(y.detach().numpy() > 0, np.maximum(y32, 1e-30), 0.0).astype(np.float32)
+    dx, dw, db = ops.conv3x3_backward(dev(x), dev(w), dev(y32), dev(dy), wd=wd, need_dx=Cin != 3)
+    if Cin != 3:
+        rel_close("dx", host(dx), xt.grad.numpy(), 2e-6)
+    rel_close("dw", host(dw), wt.grad.numpy() + wd * w.astype(np.float64), 2e-6)
+    rel_close("db", host(db), bt.grad.numpy(), 2e-6)
+
+
+# ------------------------------------------------------------------ pool / resize / gather ------
+def test_maxpool_backward(ops):
+    rng = np.random.default_rng(5)
+    x = np.maximum(rng.standard_normal((2, 28, 28, 64)), 0).astype(np.float32)  # ties at zero, as after ReLU
+    dy = rng.standard_normal((2, 14, 14, 64)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    p = Fnn.max_pool2d(xt.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    (p * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    got = host(ops.maxpool2x2_backward(dev(x), dev(dy)))
+    ref = xt.grad.numpy()
+    nz = x > 0  # among tied zeros the route is irrelevant (ReLU' = 0 there); compare where x > 0
+    assert np.array_equal(got[nz], ref[nz].astype(np.float32))
+    # and the total routed gradient is conserved window by window
+    assert np.array_equal(got.reshape(2, 14, 2, 14, 2, 64).sum((2, 4)), dy)
+
+
+@pytest.mark.parametrize("hin,c,coff,cs", [(224, 64, 0, 64), (112, 128, 64, 256), (56, 8, 4, 16), (28, 4, 0, 4),
+                                           (14, 512, 960, 1472)])
+def test_resize_backward(ops, hin, c, coff, cs):
+    rng = np.random.default_rng(hin + c)
+    B = 2
+    dout = rng.standard_normal((B, 137, 137, cs)).astype(np.float32)
+    xt = torch.zeros((B, hin, hin, c), dtype=torch.float64, requires_grad=True)
+    y = T._resize_legacy(xt, 137, 137)
+    (y * torch.tensor(dout[..., coff:coff + c], dtype=torch.float64)).sum().backward()
+    got = host(ops.resize_bilinear_backward(dev(dout), hin, hin, channels=c, out_coff=coff))
+    rel_close("din", got, xt.grad.numpy(), 1e-6)
+    base = rng.standard_normal((B, hin, hin, c)).astype(np.float32)
+    acc = dev(base)
+    ops.resize_bilinear_backward(dev(dout), hin, hin, channels=c, out_coff=coff, din=acc, accumulate=True)
+    rel_close("din+=", host(acc), xt.grad.numpy() + base, 1e-6)
+
+
+def test_gather_backward(ops):
+    rng = np.random.default_rng(9)
+    B, N = 2, 300
+    xy = rng.uniform(-2.0, 139.0, (B, N, 2)).astype(np.float32)
+    xy[0, :8] = [[0, 0], [136, 136], [136.5, 3], [-0.5, 7], [5, 136.9], [-1, 5], [137, 5], [20, 20]]
+    xy[1, :40] = xy[1, 40:41]  # many points on one pixel: the atomics must accumulate
+    dfeat = rng.standard_normal((B, N, 1472)).astype(np.float32)
+    mt = torch.zeros((B, 137, 137, 1472), dtype=torch.float64, requires_grad=True)
+    f = T._resampler(mt, xy)
+    (f * torch.tensor(dfeat, dtype=torch.float64)).sum().backward()
+    got = host(ops.gather_backward(dev(dfeat), dev(xy)))
+    rel_close("dfeatmap", got, mt.grad.numpy(), 1e-6)
+
+
+# ------------------------------------------------------------------ Adam -----------------------
+def test_adam_update(ops):
+    rng = np.random.default_rng(11)
+    n = 4 * 1000 + 64
+    w = rng.standard_normal(n).astype(np.float32)
+    m = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    v = (0.01 * rng.random(n)).astype(np.float32)
+    g = rng.standard_normal(n).astype(np.float32)
+    t, lr = 7, 1e-4
+    w2, m2, v2 = T.adam_step(w.astype(np.float64), 0.5 * g.astype(np.float64), m.astype(np.float64),
+                             v.astype(np.float64), t, lr)
+    lr_t = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.5 ** t)
+    dw, dm, dv = dev(w), dev(m), dev(v)
+    ops.adam_update(dw, dev(g), dm, dv, lr_t, grad_scale=0.5)
+    report_close("m", host(dm), m2, atol=1e-7)
+    report_close("v", host(dv), v2, atol=1e-7)
+    report_close("w", host(dw), w2, atol=1e-7, rtol=1e-6)
+
+
+# ------------------------------------------------------------------ the whole step --------------
+def _feed(B, N, seed):
+    feed = O.synth_inputs(seed=seed, batch=B, n_points=N)
+    rng = np.random.default_rng(seed + 1)
+    feed["sample_pc_rot"] = (feed["sample_pc"] @ np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], np.float32)).astype(np.float32)
+    feed["sdf"] = (0.05 * rng.standard_normal((B, N, 1))).astype(np.float32)
+    return feed
+
+
+def _dev_feed(feed):
+    return {k: dev(feed[k]) for k in ("imgs", "trans_mat", "sample_pc", "sample_pc_rot", "sdf")}
+
+
+@pytest.fixture(scope="module")
+def small_step():
+    """B=2, N=256, He weights: oracle float64 autograd vs disn_train_step"""
+    from disn_amd.train_sdf import Trainer
+    from disn_amd.weights import WeightStore
+    B, N = 2, 256
+    weights = O.init_weights(3, "he")
+    feed = _feed(B, N, 21)
+    L, grads, pred = T.loss_and_grads(feed, weights, np.float64)
+    tr = Trainer(WeightStore(weights), batch_size=B)
+    dpred, dl = tr.forward_backward(_dev_feed(feed))
+    torch.cuda.synchronize()
+    return dict(tr=tr, L=L, grads=grads, pred=pred, dpred=host(dpred), dl=host(dl), feed=feed, weights=weights)
+
+
+def test_train_step_forward_and_losses(small_step):
+    s = small_step
+    report_close("pred", s["dpred"], s["pred"].reshape(s["dpred"].shape), atol=2e-5, rtol=1e-5)
+    from disn_amd.train_sdf import LOSS_NAMES
+    for i, n in enumerate(LOSS_NAMES):
+        assert abs(s["dl"][i] - s["L"][n]) <= 1e-5 * max(abs(s["L"][n]), 1.0) + 1e-6, (n, s["dl"][i], s["L"][n])
+
+
+def test_train_step_gradients(small_step):
+    s = small_step
+    tr = s["tr"]
+    got = tr.flat.to_arrays(tr.grads)
+    # Everything that is NOT downstream of a max-pool / ReLU routing decision of the conv stack
+    # (both MLPs, fc6-fc8, the conv5_3 bias) must agree to fp32 accumulation accuracy: 2e-5 of
+    # the gradient's own scale (measured 1e-7 .. 3e-6).
+    # The conv-stack gradients depend on ~1e7 discrete decisions (ReLU sign, pool arg-max) taken on
+    # fp32 activations; a float64 run takes a handful of them differently and each flip moves a
+    # few weight-gradient entries by ~1% of the maximum -- the CPU oracle run in float32 differs
+    # from its own float64 run by 1.1e-2 (conv4_2) on this very input.  For those variables the
+    # test is flip-tolerant: relative L2 error < 2e-2 and cosine > 0.9995 (a wrong kernel or a
+    # missing term gives O(1)); the kernels themselves are held to 2e-6 in the unit tests above,
+    # where the masks are inputs.
+    tight, loose = [], []
+    for name, ref in s["grads"].items():
+        g = got[name].astype(np.float64).ravel()
+        r = np.asarray(ref, np.float64).ravel()
+        scale = max(float(np.abs(r).max()), 1e-12)
+        emax = float(np.abs(g - r).max()) / scale
+        routed = name.startswith("vgg_16/conv") and name != "vgg_16/conv5/conv5_3/biases"
+        if routed:
+            l2 = float(np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30))
+            cos = float(g @ r / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
+            loose.append((l2, cos, name))
+        else:
+            tight.append((emax, name))
+    tight.sort(reverse=True)
+    loose.sort(reverse=True)
+    print("tight (max err / max ref):", tight[:4])
+    print("flip-tolerant (rel L2, cos):", loose[:4])
+    assert tight[0][0] < 2e-5, tight[:6]
+    assert loose[0][0] < 2e-2 and min(c for _, c, _ in loose) > 0.9995, loose[:6]
+
+
+def test_train_step_is_repeatable_except_atomics(small_step):
+    s = small_step
+    tr = s["tr"]
+    g1 = tr.grads.clone()
+    tr.forward_backward(_dev_feed(s["feed"]))
+    torch.cuda.synchronize()
+    mlp = slice(int(tr.flat.layout.offset[32]), tr.flat.total)
+    assert torch.equal(g1[mlp], tr.grads[mlp])  # no atomics on the MLP side: bit-identical
+    assert torch.allclose(g1, tr.grads, rtol=0, atol=1e-4 * float(g1.abs().max()))
+
+
+def test_trainer_steps_match_oracle_adam(small_step):
+    """two optimizer steps from the same state: parameters follow TF Adam on the oracle's gradients"""
+    from disn_amd.train_sdf import Trainer, get_learning_rate
+    from disn_amd.weights import WeightStore
+    s = small_step
+    tr = Trainer(WeightStore(s["weights"]), batch_size=2)
+    feed = _dev_feed(s["feed"])
+    w = {k: np.asarray(v, np.float64) for k, v in s["weights"].items()}
+    m = {k: np.zeros_like(v) for k, v in w.items()}
+    v_ = {k: np.zeros_like(v) for k, v in w.items()}
+    _, losses, lr = tr.step(feed)
+    assert lr == get_learning_rate(0, 2)
+    for k in w:
+        w[k], m[k], v_[k] = T.adam_step(w[k], s["grads"][k], m[k], v_[k], 1, lr)
+    got = tr.flat.to_arrays(tr.params)
+    # step 1 of Adam moves every weight by ~lr*sign(g): compare the UPDATE, which is what the kernel computes
+    for k in ("vgg_16/conv1/conv1_1/weights", "vgg_16/fc8/weights", "sdfprediction/fold2/conv1/weights",
+              "sdfprediction_imgfeat/fold2/conv5/biases"):
+        upd_ref = w[k] - np.asarray(s["weights"][k], np.float64)
+        upd_got = got[k].astype(np.float64) - np.asarray(s["weights"][k], np.float64)
+        big = np.abs(s["grads"][k]) > 1e-3 * np.abs(s["grads"][k]).max()  # sign of a ~0 gradient is noise
+        report_close(k, upd_got[big], upd_ref[big], atol=2e-6)
+    assert float(losses["overall_loss"]) > 0 and tr.step_count == 1
+
+
+def test_training_reduces_the_loss():
+    from disn_amd.train_sdf import Trainer
+    from disn_amd.weights import WeightStore
+    B, N = 2, 512
+    tr = Trainer(WeightStore(O.init_weights(5, "he")), batch_size=B)
+    feed = _dev_feed(_feed(B, N, 33))
+    first = None
+    for i in range(12):
+        _, losses, _ = tr.step(feed)
+        if first is None:
+            first = float(losses["sdf_loss"])
+    last = float(losses["sdf_loss"])
+    assert math.isfinite(last) and last < 0.7 * first, (first, last)
+
+
+def test_checkpoint_roundtrip_with_adam_slots(tmp_path, small_step):
+    from disn_amd.train_sdf import Trainer
+    from disn_amd.weights import WeightStore
+    s = small_step
+    tr = Trainer(WeightStore(s["weights"]), batch_size=2)
+    feed = _dev_feed(s["feed"])
+    tr.step(feed); tr.step(feed)
+    prefix = str(tmp_path / "model.ckpt")
+    tr.save(prefix)
+    tr2 = Trainer(WeightStore(O.init_weights(99, "he")), batch_size=2)
+    assert tr2.restore(prefix) == 3 * 56 and tr2.step_count == 2
+    assert torch.equal(tr.params, tr2.params) and torch.equal(tr.m, tr2.m) and torch.equal(tr.v, tr2.v)
+    tr.step(feed); tr2.step(feed)
+    mlp = slice(int(tr.flat.layout.offset[32]), tr.flat.total)
+    assert torch.equal(tr.params[mlp], tr2.params[mlp])
