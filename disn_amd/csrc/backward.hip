@@ -67,15 +67,16 @@ constexpr int kRowsPerChunk = 256;
 // block: 256 threads = CG float4 column groups x RL row lanes; chunk of 256 rows
 __global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__ dy,
                                                              const float* __restrict__ y, long M, int N,
-                                                             int relu, float* __restrict__ partial) {
+                                                             int relu, int rpc,
+                                                             float* __restrict__ partial) {
   __shared__ float4 red[256];
   const int cgn = N >> 2;                       // float4 column groups of the matrix
   const int cg_per_block = cgn < 256 ? cgn : 256;
   const int rl_n = 256 / cg_per_block;
   const int cg = threadIdx.x % cg_per_block, rl = threadIdx.x / cg_per_block;
   const int col = (blockIdx.x * cg_per_block + cg) * 4;
-  const long r0 = (long)blockIdx.y * kRowsPerChunk;
-  const long r1 = r0 + kRowsPerChunk < M ? r0 + kRowsPerChunk : M;
+  const long r0 = (long)blockIdx.y * rpc;
+  const long r1 = r0 + rpc < M ? r0 + rpc : M;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < N && rl < rl_n) {
     for (long r = r0 + rl; r < r1; r += rl_n) {
@@ -112,23 +113,59 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
   out[n] = s;
 }
 
+// the same sum with 8 lanes per column (lane j takes chunks j, j+8, ...; fixed-order LDS tree):
+// for the long reductions (up to 512 chunks) of the convolution bias gradients
+// blockIdx.y = group of `chunks` consecutive partial rows -> out[group][N]
+__global__ __launch_bounds__(256) void colsum_finish8_kernel(const float* __restrict__ partial, int chunks,
+                                                             int N, float* __restrict__ out) {
+  __shared__ float red[8][32];
+  const int c = threadIdx.x & 31, j = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  const float* pg = partial + (size_t)blockIdx.y * chunks * N;
+  float s = 0.f;
+  if (n < N)
+    for (int k = j; k < chunks; k += 8) s += pg[(size_t)k * N + n];
+  red[j][c] = s;
+  __syncthreads();
+  if (j == 0 && n < N)
+    out[(size_t)blockIdx.y * N + n] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) +
+                                      ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
+}
+
+// rows per chunk: about M/1024 (one workgroup per chunk and column block: ~1000 workgroups keep
+// 256 CUs streaming), at least 32, a multiple of 16 (the row lanes of a workgroup)
+static int colsum_rpc(long M) {
+  long r = (M + 1023) / 1024;
+  r = (r + 15) & ~15L;
+  return (int)(r < 32 ? 32 : r);
+}
+
 size_t colsum_ws_bytes(long M, int N) {
-  return (size_t)((M + kRowsPerChunk - 1) / kRowsPerChunk) * N * sizeof(float);
+  const int rpc = colsum_rpc(M);
+  return (size_t)((M + rpc - 1) / rpc) * N * sizeof(float);
 }
 
 hipError_t relu_bwd_colsum_launch(float* dy, const float* y, long M, int N, int relu, float* db,
                                   float* ws, hipStream_t st) {
-  const int chunks = (int)((M + kRowsPerChunk - 1) / kRowsPerChunk);
+  const int rpc = colsum_rpc(M);
+  const int chunks = (int)((M + rpc - 1) / rpc);
   const int cgn = N / 4, cgb = cgn < 256 ? cgn : 256;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((cgn + cgb - 1) / cgb, chunks), dim3(256), 0, st, dy, y,
-                     M, N, relu, ws);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws, chunks, N, db,
-                     (const float*)nullptr, 0.f);
+                     M, N, relu, rpc, ws);
+  hipLaunchKernelGGL(colsum_finish8_kernel, dim3((N + 31) / 32), dim3(256), 0, st, ws, chunks, N, db);
   return hipGetLastError();
 }
 
 hipError_t image_colsum_launch(const float* x, int B, long N, int C, float* out, float* ws,
                                hipStream_t st) {
+  const int rpc = colsum_rpc((long)B * N);
+  if (N % rpc == 0) {  // chunks never straddle two images: one pass + a grouped finish
+    const int cpg = (int)(N / rpc), cgn = C / 4, cgb = cgn < 256 ? cgn : 256;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cgn + cgb - 1) / cgb, B * cpg), dim3(256), 0, st,
+                       const_cast<float*>(x), (const float*)nullptr, (long)B * N, C, 0, rpc, ws);
+    hipLaunchKernelGGL(colsum_finish8_kernel, dim3((C + 31) / 32, B), dim3(256), 0, st, ws, cpg, C, out);
+    return hipGetLastError();
+  }
   for (int b = 0; b < B; ++b) {
     hipError_t e = relu_bwd_colsum_launch(const_cast<float*>(x) + (size_t)b * N * C, nullptr, N, C, 0,
                                           out + (size_t)b * C, ws, st);
@@ -164,59 +201,73 @@ hipError_t loss_grad_launch(const float* pred, const float* gt, long M, float sd
 }
 
 // ---------------------------------------------------------------------------
-// fold2/conv5 (256 -> 1, linear) backward fused with the ReLU mask of fold2/conv2
-// thread = column k (256), block = chunk of 256 rows
+// fold2/conv5 (256 -> 1, linear) backward fused with the ReLU mask of fold2/conv2.
+// workgroup = chunk of 32 rows: 64 float4 column groups x 4 row lanes
 // ---------------------------------------------------------------------------
+constexpr int kFinalRows = 32;
+
 __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ h5,
                                                         const float* __restrict__ dpred, long M,
                                                         const float* __restrict__ w6,
                                                         float* __restrict__ dz5,
                                                         float* __restrict__ partial) {
-  const int k = threadIdx.x;
-  const long r0 = (long)blockIdx.x * kRowsPerChunk;
-  const long r1 = r0 + kRowsPerChunk < M ? r0 + kRowsPerChunk : M;
-  const float wk = w6[k];
-  float aw = 0.f, ab = 0.f, ad = 0.f;
-  for (long r = r0; r < r1; ++r) {
+  __shared__ float4 red[2][4][64];
+  __shared__ float redd[4];
+  const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * kFinalRows;
+  const long r1 = r0 + kFinalRows < M ? r0 + kFinalRows : M;
+  const float4 wk = *reinterpret_cast<const float4*>(w6 + cg * 4);
+  float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = aw;
+  float ad = 0.f;
+  for (long r = r0 + rl; r < r1; r += 4) {
     const float d = dpred[r];
-    const float h = h5[(size_t)r * 256 + k];
-    aw += h * d;
-    const float dz = h > 0.f ? d * wk : 0.f;
-    dz5[(size_t)r * 256 + k] = dz;
-    ab += dz;
+    const float4 h = *reinterpret_cast<const float4*>(h5 + (size_t)r * 256 + cg * 4);
+    float4 dz;
+    dz.x = h.x > 0.f ? d * wk.x : 0.f; dz.y = h.y > 0.f ? d * wk.y : 0.f;
+    dz.z = h.z > 0.f ? d * wk.z : 0.f; dz.w = h.w > 0.f ? d * wk.w : 0.f;
+    *reinterpret_cast<float4*>(dz5 + (size_t)r * 256 + cg * 4) = dz;
+    aw.x += h.x * d; aw.y += h.y * d; aw.z += h.z * d; aw.w += h.w * d;
+    ab.x += dz.x; ab.y += dz.y; ab.z += dz.z; ab.w += dz.w;
     ad += d;
   }
-  float* p = partial + (size_t)blockIdx.x * 768;
-  p[k] = aw;        // dw6 partial
-  p[256 + k] = ab;  // db5 partial
-  p[512 + k] = ad;  // db6 partial (identical in every column; column 0 is used)
+  red[0][rl][cg] = aw;
+  red[1][rl][cg] = ab;
+  if (cg == 0) redd[rl] = ad;
+  __syncthreads();
+  if (rl < 2) {  // rl selects dw6 / db5
+    const float4 a0 = red[rl][0][cg], a1 = red[rl][1][cg], a2 = red[rl][2][cg], a3 = red[rl][3][cg];
+    float4 o;
+    o.x = (a0.x + a1.x) + (a2.x + a3.x); o.y = (a0.y + a1.y) + (a2.y + a3.y);
+    o.z = (a0.z + a1.z) + (a2.z + a3.z); o.w = (a0.w + a1.w) + (a2.w + a3.w);
+    *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * 768 + rl * 256 + cg * 4) = o;
+  } else if (rl == 2) {  // db6 partial, replicated over the 256 columns (column 0 is used)
+    const float o = (redd[0] + redd[1]) + (redd[2] + redd[3]);
+    *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * 768 + 512 + cg * 4) = make_float4(o, o, o, o);
+  }
 }
 
-__global__ __launch_bounds__(256) void final_bwd_finish_kernel(const float* __restrict__ partial,
-                                                               int chunks, const float* __restrict__ w6,
-                                                               float l2, float* __restrict__ dw6,
-                                                               float* __restrict__ db6,
-                                                               float* __restrict__ db5) {
+__global__ __launch_bounds__(256) void final_bwd_emit_kernel(const float* __restrict__ sums,
+                                                             const float* __restrict__ w6, float l2,
+                                                             float* __restrict__ dw6,
+                                                             float* __restrict__ db6,
+                                                             float* __restrict__ db5) {
   const int k = threadIdx.x;
-  float aw = 0.f, ab = 0.f, ad = 0.f;
-  for (int c = 0; c < chunks; ++c) {
-    const float* p = partial + (size_t)c * 768;
-    aw += p[k]; ab += p[256 + k]; ad += p[512 + k];
-  }
-  dw6[k] = aw + l2 * w6[k];
-  db5[k] = ab;
-  if (k == 0) db6[0] = ad;
+  dw6[k] = sums[k] + l2 * w6[k];
+  db5[k] = sums[256 + k];
+  if (k == 0) db6[0] = sums[512];
 }
 
 size_t final_bwd_ws_bytes(long M) {
-  return (size_t)((M + kRowsPerChunk - 1) / kRowsPerChunk) * 768 * sizeof(float);
+  return (size_t)((M + kFinalRows - 1) / kFinalRows + 1) * 768 * sizeof(float);
 }
 
 hipError_t final_bwd_launch(const float* h5, const float* dpred, long M, const float* w6, float* dz5,
                             float* dw6, float* db6, float* db5, float l2, float* ws, hipStream_t st) {
-  const int chunks = (int)((M + kRowsPerChunk - 1) / kRowsPerChunk);
+  const int chunks = (int)((M + kFinalRows - 1) / kFinalRows);
+  float* sums = ws + (size_t)chunks * 768;
   hipLaunchKernelGGL(final_bwd_kernel, dim3(chunks), dim3(256), 0, st, h5, dpred, M, w6, dz5, ws);
-  hipLaunchKernelGGL(final_bwd_finish_kernel, dim3(1), dim3(256), 0, st, ws, chunks, w6, l2, dw6, db6, db5);
+  hipLaunchKernelGGL(colsum_finish8_kernel, dim3(768 / 32, 1), dim3(256), 0, st, ws, chunks, 768, sums);
+  hipLaunchKernelGGL(final_bwd_emit_kernel, dim3(1), dim3(256), 0, st, sums, w6, l2, dw6, db6, db5);
   return hipGetLastError();
 }
 
@@ -403,42 +454,48 @@ hipError_t loss_reduce_launch(const float* pred, const float* gt, long M, float 
   return hipGetLastError();
 }
 
-// regularization = wd/2 * sum over the weight segments of sum(w^2): 64 partial sums per segment
+// regularization = wd/2 * sum over the weight segments of sum(w^2): 256 partial sums per segment
+// (segments start on 64-float boundaries and hold a multiple of 4 floats: float4 loads)
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ params,
                                                             const SumsqSegs segs,
                                                             float* __restrict__ partial) {
   __shared__ float red[256];
   const int seg = blockIdx.y;
-  const float* p = params + segs.off[seg];
-  const long n = segs.cnt[seg];
-  float a = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += 64L * 256) {
-    const float v = p[i];
-    a += v * v;
+  const float4* p = reinterpret_cast<const float4*>(params + segs.off[seg]);
+  const long n4 = segs.cnt[seg] >> 2;
+  float a = 0.f, b = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 256L * 256) {
+    const float4 v = p[i];
+    a += v.x * v.x + v.y * v.y;
+    b += v.z * v.z + v.w * v.w;
   }
+  red[threadIdx.x] = a + b;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[seg * 256 + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partial, int nseg,
+                                                           float half_wd, float* __restrict__ out) {
+  __shared__ float red[256];
+  float a = 0.f;
+  for (int s = 0; s < nseg; ++s) a += partial[s * 256 + threadIdx.x];
   red[threadIdx.x] = a;
   __syncthreads();
   for (int w = 128; w >= 1; w >>= 1) {
     if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[seg * 64 + blockIdx.x] = red[0];
-}
-
-__global__ __launch_bounds__(64) void sumsq_finish_kernel(const float* __restrict__ partial, int nseg,
-                                                          float half_wd, float* __restrict__ out) {
-  // one wave: lane l sums partial[.][l] over the segments, then a fixed butterfly
-  float a = 0.f;
-  for (int s = 0; s < nseg; ++s) a += partial[s * 64 + threadIdx.x];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
-  if (threadIdx.x == 0) *out = half_wd * a;
+  if (threadIdx.x == 0) *out = half_wd * red[0];
 }
 
 hipError_t sumsq_launch(const float* params, const SumsqSegs& segs, float half_wd, float* out, float* ws,
                         hipStream_t st) {
-  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(64, segs.n), dim3(256), 0, st, params, segs, ws);
-  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(64), 0, st, ws, segs.n, half_wd, out);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(256, segs.n), dim3(256), 0, st, params, segs, ws);
+  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, st, ws, segs.n, half_wd, out);
   return hipGetLastError();
 }
 

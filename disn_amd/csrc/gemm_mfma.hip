@@ -536,8 +536,9 @@ GemmPlan gemm_plan(int M, int N, int K, size_t max_ws) {
   }
   int fbm, fbn, fw;
   if (parse_force(&fbm, &fbn, &fw) && (fbm == 64 || fbm == 128) && (fbn == 64 || fbn == 128) &&
-      N % fbn == 0 && fw >= 1) {
+      N % fbn == 0 && (fw >= 1 || fw == -1)) {  // W = -1: one workgroup per tile
     const long tiles = (long)((M + fbm - 1) / fbm) * (N / fbn);
+    if (fw == -1) fw = (int)tiles;
     if (fw > tiles * ksteps) fw = (int)(tiles * ksteps);
     if (!needs_fixup(tiles, ksteps, fw) || slab_bytes(fbm, fbn, fw) <= max_ws) {
       plan.bm = fbm; plan.bn = fbn; plan.wgs = fw;

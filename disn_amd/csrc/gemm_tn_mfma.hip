@@ -3,15 +3,19 @@
 // im2col, of a 3x3 SAME conv (models/CNN/vgg.py:187-196): p = tap*Cin + ci, A[m][p] = X at pixel m
 // shifted by the tap (zero outside the image).  Training step of SURVEY 8f #3.
 //
-// fp32 MFMA (v_mfma_f32_32x32x2_f32); 64x64 output tile per workgroup, 4 waves 2x2, one 32x32
-// accumulator each; the reduction advances 32 rows per step.  Both operands are staged through LDS
-// as [32 rows][64 cols] row-major copies of global memory (coalesced float4 loads); the MFMA
-// fragments want 32 consecutive COLUMNS of one row per half-wave, i.e. consecutive LDS words:
-// conflict-free ds_read_b32.  k-permutation as in gemm_mfma.hip: MFMA k-index h of step t inside an
-// 8-row block is row 4h + t on both operands.
+// fp32 MFMA (v_mfma_f32_32x32x2_f32); BP x BQ output tile per workgroup (64 or 128 each), 4 waves
+// 2x2, (BP/64)x(BQ/64) 32x32 accumulators per wave; the reduction advances 32 rows per step.  Both
+// operands are staged through LDS as [32 rows][BP | BQ cols] row-major copies of global memory
+// (coalesced float4 loads); an MFMA fragment wants 32 consecutive COLUMNS of one row per half-wave,
+// i.e. consecutive LDS words (row stride padded by 8 words so the two half-waves, 4 rows apart, use
+// disjoint banks): conflict-free ds_read_b32.  k-permutation as in gemm_mfma.hip: MFMA k-index h of
+// step t inside an 8-row block is row 4h + t on both operands.
+// A 128x128 tile moves 32 KB per 1 MFLOP (64x64: 16 KB per 0.26 MFLOP): the 64x64 version of this
+// kernel was L2-bandwidth bound at 77 TFLOP/s.
 // The output is small (<= 4608 x 512) and the reduction long (2k .. 400k rows), so the work is
-// ALWAYS stream-K: (tile, row-step) units split evenly over W workgroups, every segment goes to a
-// slab, tn_fixup sums the slabs of a tile in workgroup order (deterministic, no atomics).
+// ALWAYS stream-K: (tile, row-step) units split evenly over W workgroups; a segment that covers a
+// whole tile is finished in place, any other goes to a slab and tn_fixup sums the slabs of a tile in
+// workgroup order (deterministic, no atomics).
 #include "kernels.hpp"
 
 namespace disn {
@@ -20,17 +24,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct TnDev {
   TnParams p;
-  float* ws;  // slabs [2*W][64*64]
+  float* ws;  // slabs [2*W][BP*BQ]
   int msteps, ptiles, qtiles, W;
   long units;
 };
 
 __device__ __forceinline__ long tn_unit_begin(long U, int W, int w) { return (U * w) / W; }
 
-template <bool CONV>
-__global__ __launch_bounds__(256) void gemm_tn_f32_mfma(const TnDev d) {
-  constexpr int BP = 64, BQ = 64;
-  __shared__ __attribute__((aligned(16))) float lds[2 * 32 * (BP + BQ)];
+template <int BP, int BQ, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
+  constexpr int LDP = BP + 8, LDQ = BQ + 8;      // padded LDS row strides (words)
+  constexpr int BUF = 32 * (LDP + LDQ);          // one stage
+  constexpr int TP = BP / 64, TQ = BQ / 64;      // 32x32 accumulators per wave, per dimension
+  constexpr int AV = BP / 4, BV = BQ / 4;        // float4 per operand row
+  constexpr int AROWS = 256 / AV, BROWS = 256 / BV;  // rows one loader pass covers
+  constexpr int APASS = 32 / AROWS, BPASS = 32 / BROWS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const TnParams& p = d.p;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -54,53 +63,63 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_mfma(const TnDev d) {
     u += s_end - s_begin;
     const int pt = tile / d.qtiles, qt = tile - pt * d.qtiles;
     const int p0 = pt * BP, q0 = qt * BQ;
-    // conv: this P tile lies inside ONE tap (Cin % 64 == 0)
-    int dy = 0, dx = 0, ci0 = p0;
+    // loaders: thread -> float4 column (tid % AV), rows (tid / AV) + AROWS*i
+    const int arow = tid / AV, acol = (tid % AV) * 4;
+    const int brow = tid / BV, bcol = (tid % BV) * 4;
+    // conv: the tap / channel of THIS thread's A column (a P tile may span taps)
+    int dy = 0, dx = 0, ci = p0 + acol;
     if (CONV) {
-      const int tap = p0 / p.Cin;
-      ci0 = p0 - tap * p.Cin;
+      const int tap = (p0 + acol) / p.Cin;
+      ci = p0 + acol - tap * p.Cin;
       dy = tap / 3 - 1;
       dx = tap - (tap / 3) * 3 - 1;
     }
-    // loader: thread -> rows (tid>>4) and (tid>>4)+16 of the 32-row step, float4 column tid&15
-    const int lrow = tid >> 4, lc4 = (tid & 15) * 4;
-    float4 ra[2], rb[2];
+    float4 ra[APASS], rb[BPASS];
     auto load = [&](int s) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const long m = (long)s * 32 + lrow + 16 * i;
-        bool oka = m < p.M;
-        const float* src = p.a;
+      for (int i = 0; i < APASS; ++i) {
+        const long m = (long)s * 32 + arow + AROWS * i;
+        bool ok = m < p.M;
+        const float* src;
         if (CONV) {
           const int hw = p.H * p.W;
-          const long mm = oka ? m : 0;
+          const long mm = ok ? m : 0;
           const int rem = (int)(mm % hw);
           const int y = rem / p.W, x = rem - y * p.W;
           const int yy = y + dy, xx = x + dx;
-          oka = oka && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-          src = p.a + (size_t)(oka ? mm + dy * p.W + dx : 0) * p.Cin + ci0 + lc4;
+          ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+          src = p.a + (size_t)(ok ? mm + dy * p.W + dx : 0) * p.Cin + ci;
         } else {
-          src = p.a + (size_t)(oka ? m : 0) * p.lda + p0 + lc4;
+          src = p.a + (size_t)(ok ? m : 0) * p.lda + ci;
         }
-        const float4 va = *reinterpret_cast<const float4*>(src);
-        ra[i] = oka ? va : make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool okb = m < p.M;
-        const float4 vb = *reinterpret_cast<const float4*>(p.b + (size_t)(okb ? m : 0) * p.ldb + q0 + lc4);
-        rb[i] = okb ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        const long m = (long)s * 32 + brow + BROWS * i;
+        const bool ok = m < p.M;
+        const float4 v = *reinterpret_cast<const float4*>(p.b + (size_t)(ok ? m : 0) * p.ldb + q0 + bcol);
+        rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
     auto store = [&](int buf) {
-      float* la = &lds[buf * 32 * (BP + BQ)];
-      float* lb = la + 32 * BP;
+      float* la = &lds[buf * BUF];
+      float* lb = la + 32 * LDP;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        *reinterpret_cast<float4*>(&la[(lrow + 16 * i) * BP + lc4]) = ra[i];
-        *reinterpret_cast<float4*>(&lb[(lrow + 16 * i) * BQ + lc4]) = rb[i];
-      }
+      for (int i = 0; i < APASS; ++i)
+        *reinterpret_cast<float4*>(&la[(arow + AROWS * i) * LDP + acol]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i)
+        *reinterpret_cast<float4*>(&lb[(brow + BROWS * i) * LDQ + bcol]) = rb[i];
     };
-    f32x16 acc;
+    f32x16 acc[TP][TQ];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+      for (int j = 0; j < TQ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     load(s_begin);
     store(0);
     __syncthreads();
@@ -108,48 +127,55 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_mfma(const TnDev d) {
     for (int s = s_begin; s < s_end; ++s) {
       const int sn = (s + 1 < s_end) ? s + 1 : s;
       load(sn);
-      const float* la = &lds[cur * 32 * (BP + BQ)] + wm * 32 + (lane & 31);
-      const float* lb = &lds[cur * 32 * (BP + BQ)] + 32 * BP + wn * 32 + (lane & 31);
+      const float* la = &lds[cur * BUF] + wm * (BP / 2) + (lane & 31);
+      const float* lb = &lds[cur * BUF] + 32 * LDP + wn * (BQ / 2) + (lane & 31);
       const int hrow = (lane >> 5) * 4;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float a = la[(kb * 8 + hrow + t) * BP];
-          const float b = lb[(kb * 8 + hrow + t) * BQ];
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+          float a[TP], b[TQ];
+#pragma unroll
+          for (int i = 0; i < TP; ++i) a[i] = la[(kb * 8 + hrow + t) * LDP + i * 32];
+#pragma unroll
+          for (int j = 0; j < TQ; ++j) b[j] = lb[(kb * 8 + hrow + t) * LDQ + j * 32];
+#pragma unroll
+          for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < TQ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
       }
       store(cur ^ 1);
       __syncthreads();
       cur ^= 1;
     }
-    if (s_begin == 0 && s_end == MS) {
-      // the whole reduction of this tile: finish in place (tn_fixup skips such tiles)
+    const bool whole = s_begin == 0 && s_end == MS;
+    float* slab = d.ws + (size_t)slot * BP * BQ;  // tile-local row-major [BP][BQ]
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const size_t o = (size_t)(p0 + row) * p.ldc + q0 + wn * 32 + (lane & 31);
-        float v = acc[r];
-        if (p.l2 != 0.f) v += p.l2 * p.wcur[o];
-        p.c[o] = v;
-      }
-    } else {
-      // slab: tile-local row-major [64][64]
-      float* slab = d.ws + (size_t)slot * BP * BQ;
+    for (int i = 0; i < TP; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        slab[row * BQ + wn * 32 + (lane & 31)] = acc[r];
-      }
-    }
+      for (int j = 0; j < TQ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * (BP / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int col = wn * (BQ / 2) + j * 32 + (lane & 31);
+          if (whole) {  // the whole reduction of this tile: finish in place (tn_fixup skips it)
+            const size_t o = (size_t)(p0 + row) * p.ldc + q0 + col;
+            float v = acc[i][j][r];
+            if (p.l2 != 0.f) v += p.l2 * p.wcur[o];
+            p.c[o] = v;
+          } else {
+            slab[row * BQ + col] = acc[i][j][r];
+          }
+        }
     if (u < u1) __syncthreads();
   }
 }
 
-// C[p][q] (+)= sum of the slabs of tile (pt,qt) in workgroup order, + l2 * Wcur[p][q]
+// C[p][q] = sum of the slabs of tile (pt,qt) in workgroup order, + l2 * Wcur[p][q]
+template <int BP, int BQ>
 __global__ __launch_bounds__(256) void tn_fixup(const TnDev d) {
-  constexpr int BP = 64, BQ = 64;
   const TnParams& p = d.p;
   const int tile = blockIdx.x;
   const long MS = d.msteps, tb = (long)tile * MS, te = tb + MS;
@@ -172,37 +198,61 @@ __global__ __launch_bounds__(256) void tn_fixup(const TnDev d) {
     v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
   }
   const int pt = tile / d.qtiles, qt = tile - pt * d.qtiles;
-  float* o = p.c + (size_t)(pt * BP + lrow) * p.ldc + qt * BQ + lcol;
+  const size_t o = (size_t)(pt * BP + lrow) * p.ldc + qt * BQ + lcol;
   if (p.l2 != 0.f) {  // d(wd*|w|^2/2)/dw = wd * w
-    const float4 wv = *reinterpret_cast<const float4*>(p.wcur + (size_t)(pt * BP + lrow) * p.ldc + qt * BQ + lcol);
+    const float4 wv = *reinterpret_cast<const float4*>(p.wcur + o);
     v.x += p.l2 * wv.x; v.y += p.l2 * wv.y; v.z += p.l2 * wv.z; v.w += p.l2 * wv.w;
   }
-  *reinterpret_cast<float4*>(o) = v;
+  *reinterpret_cast<float4*>(p.c + o) = v;
 }
+
+static const int kTnMaxW = 512;  // 2 workgroups per CU
 
 size_t gemm_tn_ws_bytes(long M, int P, int Q) {
-  const long units = (long)(P / 64) * (Q / 64) * ((M + 31) / 32);
-  const long W = units < 512 ? units : 512;
-  return (size_t)2 * W * 64 * 64 * sizeof(float);
+  (void)M; (void)P; (void)Q;
+  return (size_t)2 * kTnMaxW * 128 * 128 * sizeof(float);
 }
 
-hipError_t gemm_tn_launch(const TnParams& p, float* ws, hipStream_t st) {
+template <int BP, int BQ>
+static hipError_t tn_launch_tile(const TnParams& p, float* ws, hipStream_t st) {
   TnDev d;
   d.p = p;
   d.ws = ws;
   d.msteps = (int)((p.M + 31) / 32);
-  d.ptiles = p.P / 64;
-  d.qtiles = p.Q / 64;
+  d.ptiles = p.P / BP;
+  d.qtiles = p.Q / BQ;
   d.units = (long)d.ptiles * d.qtiles * d.msteps;
-  d.W = (int)(d.units < 512 ? d.units : 512);
-  if (p.Cin > 0)
-    hipLaunchKernelGGL((gemm_tn_f32_mfma<true>), dim3(d.W), dim3(256), 0, st, d);
-  else
-    hipLaunchKernelGGL((gemm_tn_f32_mfma<false>), dim3(d.W), dim3(256), 0, st, d);
+  d.W = (int)(d.units < kTnMaxW ? d.units : kTnMaxW);
+  const size_t lds_bytes = (size_t)2 * 32 * (BP + 8 + BQ + 8) * sizeof(float);
+  if (p.Cin > 0) {
+    static bool attr_done = false;  // benign race: idempotent attribute
+    if (!attr_done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_mfma<BP, BQ, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_f32_mfma<BP, BQ, true>), dim3(d.W), dim3(256), lds_bytes, st, d);
+  } else {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_mfma<BP, BQ, false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_f32_mfma<BP, BQ, false>), dim3(d.W), dim3(256), lds_bytes, st, d);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(tn_fixup, dim3(d.ptiles * d.qtiles, 64 * 64 / 1024), dim3(256), 0, st, d);
+  hipLaunchKernelGGL((tn_fixup<BP, BQ>), dim3(d.ptiles * d.qtiles, BP * BQ / 1024), dim3(256), 0, st, d);
   return hipGetLastError();
+}
+
+hipError_t gemm_tn_launch(const TnParams& p, float* ws, hipStream_t st) {
+  const bool p128 = p.P % 128 == 0, q128 = p.Q % 128 == 0;
+  if (p128 && q128) return tn_launch_tile<128, 128>(p, ws, st);
+  if (p128) return tn_launch_tile<128, 64>(p, ws, st);
+  if (q128) return tn_launch_tile<64, 128>(p, ws, st);
+  return tn_launch_tile<64, 64>(p, ws, st);
 }
 
 }  // namespace disn

@@ -129,7 +129,7 @@ struct SumsqSegs {
   int n;
   long off[32], cnt[32];
 };
-// *out = half_wd * sum over the segments of sum(params[off..off+cnt)^2); ws: 32*64 floats
+// *out = half_wd * sum over the segments of sum(params[off..off+cnt)^2); ws: 32*256 floats
 hipError_t sumsq_launch(const float* params, const SumsqSegs& segs, float half_wd, float* out, float* ws,
                         hipStream_t st);
 // TF Adam on n floats (n % 4 == 0); the gradient is scaled by gscale first (1/world for DDP)

@@ -124,7 +124,7 @@ BwdWs bwd_layout(Bump& b, size_t wt_floats, long max_m, size_t gemm_ws_bytes, si
   w.zero = b.take(4096);
   w.gemm_ws_bytes = gemm_ws_bytes;
   w.gemm_ws = b.take(gemm_ws_bytes / sizeof(float) + 1);
-  w.tn_ws = b.take((size_t)2 * 512 * 64 * 64);
+  w.tn_ws = b.take(gemm_tn_ws_bytes(max_m, 128, 128) / sizeof(float));
   w.red_ws = b.take(red_bytes / sizeof(float) + 1);
   (void)max_m;
   w.total = (b.off + 255) & ~size_t(255);
@@ -243,7 +243,7 @@ TrainWs train_layout(void* ws, int B, int N) {
   fws = max_sz(fws, gemv_ws_bytes(B, 4096, DISN_EMBED_DIM));
   fws = max_sz(fws, gemv_ws_bytes(B, DISN_EMBED_DIM, 512));
   t.fc_ws = b.take(fws / sizeof(float) + 1);
-  t.sumsq_ws = b.take(32 * 64);
+  t.sumsq_ws = b.take(32 * 256);
   size_t red = max_sz(colsum_ws_bytes((long)B * 224 * 224, 64), colsum_ws_bytes(M, 512));
   red = max_sz(red, max_sz(final_bwd_ws_bytes(M), colsum_ws_bytes(M, DISN_FEAT_DIM)));
   t.bw = bwd_layout(b, (size_t)9 * 512 * 512, M, train_gemm_ws(B, M), red);
