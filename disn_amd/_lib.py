@@ -93,7 +93,8 @@ SIGNATURES = {
     "disn_conv3x3_backward_workspace_bytes": (Z, [I, I, I, I, I]),
     "disn_conv3x3_backward": (I, [P, I, I, I, I, P, P, P, I, F, P, P, P, P, Z, P]),
     "disn_maxpool2x2_backward": (I, [P, P, I, I, I, I, P, P]),
-    "disn_resize_bilinear_backward": (I, [P, I, I, I, I, I, I, I, I, P, I, P]),
+    "disn_resize_bilinear_backward_workspace_bytes": (Z, [I, I, I, I, I, I]),
+    "disn_resize_bilinear_backward": (I, [P, I, I, I, I, I, I, I, I, P, I, P, Z, P]),
     "disn_gather_backward": (I, [P, P, I, I, P, P]),
     "disn_mc_workspace_bytes": (Z, [I]),
     "disn_mc_count": (I, [P, I, F, P, P, Z, P]),

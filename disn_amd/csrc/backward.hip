@@ -118,18 +118,20 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
 // blockIdx.y = group of `chunks` consecutive partial rows -> out[group][N]
 __global__ __launch_bounds__(256) void colsum_finish8_kernel(const float* __restrict__ partial, int chunks,
                                                              int N, float* __restrict__ out) {
-  __shared__ float red[8][32];
-  const int c = threadIdx.x & 31, j = threadIdx.x >> 5;
-  const int n = blockIdx.x * 32 + c;
+  __shared__ float red[32][9];
+  const int c = threadIdx.x & 7, j = threadIdx.x >> 3;  // 8 columns x 32 lanes
+  const int n = blockIdx.x * 8 + c;
   const float* pg = partial + (size_t)blockIdx.y * chunks * N;
   float s = 0.f;
   if (n < N)
-    for (int k = j; k < chunks; k += 8) s += pg[(size_t)k * N + n];
+    for (int k = j; k < chunks; k += 32) s += pg[(size_t)k * N + n];
   red[j][c] = s;
   __syncthreads();
-  if (j == 0 && n < N)
-    out[(size_t)blockIdx.y * N + n] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) +
-                                      ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
+  for (int w = 16; w >= 1; w >>= 1) {  // fixed tree over the 32 lanes
+    if (j < w) red[j][c] += red[j + w][c];
+    __syncthreads();
+  }
+  if (j == 0 && n < N) out[(size_t)blockIdx.y * N + n] = red[0][c];
 }
 
 // rows per chunk: about M/1024 (one workgroup per chunk and column block: ~1000 workgroups keep
@@ -152,7 +154,7 @@ hipError_t relu_bwd_colsum_launch(float* dy, const float* y, long M, int N, int 
   const int cgn = N / 4, cgb = cgn < 256 ? cgn : 256;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((cgn + cgb - 1) / cgb, chunks), dim3(256), 0, st, dy, y,
                      M, N, relu, rpc, ws);
-  hipLaunchKernelGGL(colsum_finish8_kernel, dim3((N + 31) / 32), dim3(256), 0, st, ws, chunks, N, db);
+  hipLaunchKernelGGL(colsum_finish8_kernel, dim3((N + 7) / 8), dim3(256), 0, st, ws, chunks, N, db);
   return hipGetLastError();
 }
 
@@ -163,7 +165,7 @@ hipError_t image_colsum_launch(const float* x, int B, long N, int C, float* out,
     const int cpg = (int)(N / rpc), cgn = C / 4, cgb = cgn < 256 ? cgn : 256;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((cgn + cgb - 1) / cgb, B * cpg), dim3(256), 0, st,
                        const_cast<float*>(x), (const float*)nullptr, (long)B * N, C, 0, rpc, ws);
-    hipLaunchKernelGGL(colsum_finish8_kernel, dim3((C + 31) / 32, B), dim3(256), 0, st, ws, cpg, C, out);
+    hipLaunchKernelGGL(colsum_finish8_kernel, dim3((C + 7) / 8, B), dim3(256), 0, st, ws, cpg, C, out);
     return hipGetLastError();
   }
   for (int b = 0; b < B; ++b) {
@@ -266,7 +268,7 @@ hipError_t final_bwd_launch(const float* h5, const float* dpred, long M, const f
   const int chunks = (int)((M + kFinalRows - 1) / kFinalRows);
   float* sums = ws + (size_t)chunks * 768;
   hipLaunchKernelGGL(final_bwd_kernel, dim3(chunks), dim3(256), 0, st, h5, dpred, M, w6, dz5, ws);
-  hipLaunchKernelGGL(colsum_finish8_kernel, dim3(768 / 32, 1), dim3(256), 0, st, ws, chunks, 768, sums);
+  hipLaunchKernelGGL(colsum_finish8_kernel, dim3(768 / 8, 1), dim3(256), 0, st, ws, chunks, 768, sums);
   hipLaunchKernelGGL(final_bwd_emit_kernel, dim3(1), dim3(256), 0, st, sums, w6, l2, dw6, db6, db5);
   return hipGetLastError();
 }

@@ -515,18 +515,25 @@ GemmPlan gemm_plan(int M, int N, int K, size_t max_ws) {
       const bool fix = needs_fixup(tiles, ksteps, (int)W);
       if (fix && slab_bytes(bm, bn, (int)W) > max_ws) continue;
       const long per_wg = (U + W - 1) / W;          // k-steps of the busiest workgroup
-      const long resident = W < 256L * occ ? (W + 255) / 256 : occ;   // per CU at a time
-      const double rounds = (double)((W + 256L * resident - 1) / (256L * resident));
-      // a wave alone on its SIMD loses ~20 % to the per-step LDS/barrier bubble; two hide it
-      const double eff = resident >= 2 ? 0.93 : 0.80;
-      double cost = rounds * per_wg * unit * resident / eff + 6000.0;
-      // measured (tools/sweep_gemm.py): with thousands of tiles the hardware dispatcher balances
-      // one-tile workgroups ~5 % better than persistent stream-K workgroups finish together
-      if (W != tiles) cost *= 1.05;
-      cost += 600.0 * ((W + 255) / 256);            // prologue/epilogue per workgroup round
+      // workgroups the busiest CU executes: round-robin for a few, dynamically balanced (half a
+      // workgroup of tail) once there are >= 4 per CU
+      const double cu_wgs = W >= 1024 ? (double)W / 256.0 + 0.5 : (double)((W + 255) / 256);
+      const long resident = (W + 255) / 256 < occ ? (W + 255) / 256 : occ;   // per CU at a time
+      // Co-resident workgroups share the CU's MFMA pipes, so the busiest CU needs
+      // cu_wgs * per_wg * unit MFMA cycles however they are scheduled.  MFMA-busy fractions fitted
+      // to tools/sweep_gemm.py at B = 1 and B = 8: a wave alone on its SIMD loses ~14 % to the
+      // per-step LDS/barrier bubble; bigger tiles re-use more of each staged operand, and the A
+      // side (im2col gather) is the expensive one to widen.
+      const double tile_eff = tq >= 4 ? 0.93 : (tq == 1 ? 0.84 : (bm == 128 ? 0.83 : 0.86));
+      const double eff = (resident >= 2 ? 1.0 : 0.86) * tile_eff;
+      double cost = cu_wgs * per_wg * unit / eff + 6000.0;
+      // persistent stream-K workgroups finish together; the dispatcher balances one-tile
+      // workgroups a little better
+      if (W != tiles) cost *= 1.03;
+      cost += 600.0 * cu_wgs;                        // prologue/epilogue per workgroup
       if (fix) {
         const double segs = (double)W + (double)(tiles < W ? tiles : W);
-        cost += 7000.0 + segs * bm * bn * 8.0 / 1500.0;  // slab write + read at ~3.3 TB/s
+        cost += 16000.0 + segs * bm * bn * 8.0 / 2500.0;  // fix-up launch + slab write/read
       }
       if (cost < best) {
         best = cost;

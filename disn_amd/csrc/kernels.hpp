@@ -141,8 +141,12 @@ hipError_t adam_launch(float* w, const float* g, float* m, float* v, size_t n, f
 hipError_t gather_bwd_launch(const float* dfeat, const float* xy, int B, int N, float* dmap,
                              hipStream_t st);
 // din [B,Hin,Win,C] (+)= ResizeBilinearGrad of channels [coff, coff+C) of dout [B,Hout,Wout,cstride]
+// tmp: resize_bwd_ws_bytes of scratch for the separable (rows, then columns) form used for
+// >= 2x up-sampling; nullptr (or 0 bytes needed): one direct pass
+size_t resize_bwd_ws_bytes(int B, int Hin, int Win, int C, int Hout, int Wout);
 hipError_t resize_bwd_launch(const float* dout, int B, int Hin, int Win, int C, int Hout, int Wout,
-                             int out_cstride, int out_coff, float* din, int accumulate, hipStream_t st);
+                             int out_cstride, int out_coff, float* din, int accumulate, float* tmp,
+                             hipStream_t st);
 // x [B,H,W,C] pre-pool activations, dy [B,H/2,W/2,C] -> dx [B,H,W,C] (every element written)
 hipError_t maxpool_bwd_launch(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
                               hipStream_t st);

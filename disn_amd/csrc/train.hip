@@ -318,15 +318,22 @@ int disn_maxpool2x2_backward(const float* x, const float* dy, int B, int H, int 
   return 0;
 }
 
+size_t disn_resize_bilinear_backward_workspace_bytes(int B, int Hin, int Win, int C, int Hout, int Wout) {
+  if (B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || Hout <= 0 || Wout <= 0) return 0;
+  return resize_bwd_ws_bytes(B, Hin, Win, C, Hout, Wout);
+}
+
 int disn_resize_bilinear_backward(const float* dout, int B, int Hin, int Win, int C, int Hout, int Wout,
-                                  int out_cstride, int out_coff, float* din, int accumulate,
-                                  void* stream) {
+                                  int out_cstride, int out_coff, float* din, int accumulate, void* ws,
+                                  size_t ws_bytes, void* stream) {
   if (!dout || !din || B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || Hout <= 0 || Wout <= 0)
     return DISN_E_ARG;
   if (C % 4 || out_cstride % 4 || out_coff % 4 || out_coff < 0 || out_coff + C > out_cstride)
     return DISN_E_SHAPE;
+  const size_t need = resize_bwd_ws_bytes(B, Hin, Win, C, Hout, Wout);
+  if (need > 0 && (!ws || ws_bytes < need)) return DISN_E_WS;
   DISN_TRY(resize_bwd_launch(dout, B, Hin, Win, C, Hout, Wout, out_cstride, out_coff, din, accumulate,
-                             (hipStream_t)stream));
+                             need > 0 ? (float*)ws : nullptr, (hipStream_t)stream));
   return 0;
 }
 
@@ -502,8 +509,9 @@ int disn_train_step(const float* params, float* grads, const float* img, const f
       dy = bufs[which];
       which ^= 1;
       DISN_TRY(maxpool_bwd_launch(t.act[i], dcur, B, c.hw, c.hw, c.cout, dy, st));
+      // t.col ([B,224,224,64] floats, free until conv1_1) is the row-pass scratch (<= B*56*137*256)
       DISN_TRY(resize_bwd_launch(t.dmap, B, c.hw, c.hw, c.cout, DISN_IMG_H, DISN_IMG_W, DISN_FEAT_DIM,
-                                 kTapOff[c.tap], dy, 1, st));
+                                 kTapOff[c.tap], dy, 1, t.col, st));
     } else {
       dy = const_cast<float*>(dcur);
     }

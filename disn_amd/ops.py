@@ -357,9 +357,10 @@ def resize_bilinear_backward(dout: torch.Tensor, in_h: int, in_w: int, channels:
     if din is None:
         din = torch.empty((B, in_h, in_w, Cc), dtype=torch.float32, device=dout.device)
         accumulate = False
+    ws = _ws(lib().disn_resize_bilinear_backward_workspace_bytes(B, in_h, in_w, Cc, Ho, Wo), dout.device)
     check("disn_resize_bilinear_backward", lib().disn_resize_bilinear_backward(
         dout.data_ptr(), B, in_h, in_w, Cc, Ho, Wo, cs, out_coff, din.data_ptr(), int(accumulate),
-        _stream()))
+        ws.data_ptr(), ws.numel(), _stream()))
     return din
 
 

@@ -308,10 +308,12 @@ int disn_conv3x3_backward(const float* x, int B, int H, int W, int Cin, const fl
 int disn_maxpool2x2_backward(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
                              void* stream);
 /* din [B,Hin,Win,C] (= or +=) gradient of disn_resize_bilinear w.r.t. its input, given dout (channels
- * [out_coff, out_coff+C) of a [B,Hout,Wout,out_cstride] tensor).  C, strides multiples of 4. */
+ * [out_coff, out_coff+C) of a [B,Hout,Wout,out_cstride] tensor).  C, strides multiples of 4.
+ * ws: scratch of the separable form used for >= 2x up-sampling (0 bytes otherwise). */
+size_t disn_resize_bilinear_backward_workspace_bytes(int B, int Hin, int Win, int C, int Hout, int Wout);
 int disn_resize_bilinear_backward(const float* dout, int B, int Hin, int Win, int C, int Hout, int Wout,
-                                  int out_cstride, int out_coff, float* din, int accumulate,
-                                  void* stream);
+                                  int out_cstride, int out_coff, float* din, int accumulate, void* ws,
+                                  size_t ws_bytes, void* stream);
 /* dfeatmap [B,137,137,1472] = gradient of disn_gather w.r.t. featmap (zeroed here, then fp32 atomics) */
 int disn_gather_backward(const float* dfeat, const float* xy, int B, int N, float* dfeatmap,
                          void* stream);
