@@ -86,7 +86,7 @@ SIGNATURES = {
     "disn_crc32c": (C.c_uint32, [P, Z, C.c_uint32]),
     "disn_param_layout": (I, [C.POINTER(ParamLayout)]),
     "disn_train_workspace_bytes": (Z, [I, I]),
-    "disn_train_step": (I, [P, P, P, P, P, P, P, I, I, F, F, F, P, P, P, Z, P]),
+    "disn_train_step": (I, [P, P, P, P, P, P, P, P, I, I, F, F, F, P, P, P, P, Z, P]),
     "disn_adam_update": (I, [P, P, P, P, L, F, F, F, F, F, P]),
     "disn_dense_backward_workspace_bytes": (Z, [I, I, I]),
     "disn_dense_backward": (I, [P, I, I, P, P, P, I, I, F, P, P, P, P, Z, P]),

@@ -325,10 +325,7 @@ size_t disn_vgg16_workspace_bytes(int B) {
 
 }  // extern "C"
 
-struct disn_ctx {
-  hipStream_t aux;
-  hipEvent_t ev[8];  // 0: fork, 1..5: tap ready, 6: aux done, 7: spare
-};
+// struct disn_ctx (kernels.hpp) as used here -- ev 0: fork, 1..5: tap ready, 6: aux done, 7: spare
 
 namespace {
 

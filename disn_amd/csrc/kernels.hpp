@@ -5,6 +5,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// disn_ctx_t of include/disn_amd.h: the auxiliary stream and the fork/join events of one caller stream
+struct disn_ctx {
+  hipStream_t aux;
+  hipEvent_t ev[8];
+};
+
 namespace disn {
 
 // ---- gemm_mfma.hip -------------------------------------------------------

@@ -183,7 +183,7 @@ struct TrainWs {
   float *g1, *l1, *g2, *l2, *g3, *l3, *g4, *l4, *g5, *l5;
   // gradients
   float *dpred, *d5, *d4, *d3, *d2, *d1, *dfeat, *dmap, *dgbias, *demb, *dz7, *dz6, *dpool5, *gA, *gB;
-  float *col, *fc_ws, *sumsq_ws;
+  float *col, *fc_ws, *sumsq_ws, *red_aux;
   BwdWs bw;
   size_t total;
 };
@@ -244,6 +244,7 @@ TrainWs train_layout(void* ws, int B, int N) {
   fws = max_sz(fws, gemv_ws_bytes(B, DISN_EMBED_DIM, 512));
   t.fc_ws = b.take(fws / sizeof(float) + 1);
   t.sumsq_ws = b.take(32 * 256);
+  t.red_aux = b.take(colsum_ws_bytes(B, 4096) / sizeof(float) + 1);
   size_t red = max_sz(colsum_ws_bytes((long)B * 224 * 224, 64), colsum_ws_bytes(M, 512));
   red = max_sz(red, max_sz(final_bwd_ws_bytes(M), colsum_ws_bytes(M, DISN_FEAT_DIM)));
   t.bw = bwd_layout(b, (size_t)9 * 512 * 512, M, train_gemm_ws(B, M), red);
@@ -361,10 +362,10 @@ size_t disn_train_workspace_bytes(int B, int N) {
   return train_layout(nullptr, B, N).total;
 }
 
-int disn_train_step(const float* params, float* grads, const float* img, const float* trans_mat,
-                    const float* pts, const float* pts_rot, const float* gt, int B, int N, float wd,
-                    float sdf_weight, float mask_weight, float* pred, float* losses, void* ws,
-                    size_t ws_bytes, void* stream) {
+int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const float* img,
+                    const float* trans_mat, const float* pts, const float* pts_rot, const float* gt, int B,
+                    int N, float wd, float sdf_weight, float mask_weight, float* pred, float* losses,
+                    void* head_ready_event, void* ws, size_t ws_bytes, void* stream) {
   if (!params || !grads || !img || !trans_mat || !pts || !pts_rot || !gt || !pred || !losses || !ws ||
       B <= 0 || N <= 0)
     return DISN_E_ARG;
@@ -372,6 +373,9 @@ int disn_train_step(const float* params, float* grads, const float* img, const f
   const TrainWs t = train_layout(ws, B, N);
   if (ws_bytes < t.total) return DISN_E_WS;
   hipStream_t st = (hipStream_t)stream;
+  // HBM-bound side work (weight-norm sum, fc6-fc8 forward and backward: ~1.3 GB of weight traffic)
+  // runs on the context's auxiliary stream under MFMA-bound GEMMs of the main stream
+  hipStream_t as = ctx ? ctx->aux : st;
   disn_param_layout_t L;
   build_layout(&L);
   auto P = [&](int idx) { return params + L.offset[idx]; };
@@ -394,6 +398,20 @@ int disn_train_step(const float* params, float* grads, const float* img, const f
   DISN_TRY(pack_kn_launch(P(V_L + 6), 1984, 512, 1984, t.l_p4, st));
   DISN_TRY(pack_kn_launch(P(V_L + 8), 512, 256, 512, t.l_p5, st));
   DISN_TRY(hipMemsetAsync(s.zero, 0, 4096 * sizeof(float), st));
+  if (ctx) {
+    DISN_TRY(hipEventRecord(ctx->ev[0], st));
+    DISN_TRY(hipStreamWaitEvent(as, ctx->ev[0], 0));
+  }
+  {  // regularization loss: depends on the parameters only
+    SumsqSegs segs{};
+    int n = 0;
+    for (int i = 0; i < 13; ++i) { segs.off[n] = L.offset[2 * i]; segs.cnt[n++] = L.count[2 * i]; }
+    for (int i = 0; i < 3; ++i) { segs.off[n] = L.offset[V_FC + 2 * i]; segs.cnt[n++] = L.count[V_FC + 2 * i]; }
+    for (int i = 0; i < 6; ++i) { segs.off[n] = L.offset[V_G + 2 * i]; segs.cnt[n++] = L.count[V_G + 2 * i]; }
+    for (int i = 0; i < 6; ++i) { segs.off[n] = L.offset[V_L + 2 * i]; segs.cnt[n++] = L.count[V_L + 2 * i]; }
+    segs.n = n;
+    DISN_TRY(sumsq_launch(params, segs, 0.5f * wd, losses + 3, t.sumsq_ws, as));
+  }
 
   DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, t.resized, DISN_VGG_SIZE,
                                   DISN_VGG_SIZE, 3, 0, st));
@@ -411,12 +429,17 @@ int disn_train_step(const float* params, float* grads, const float* img, const f
     }
   }
   const float* pool5 = x;
-  DISN_TRY(gemv_launch(pool5, B, 25088, P(V_FC), P(V_FC + 1), 4096, 1, t.h6, t.fc_ws, st));
-  DISN_TRY(gemv_launch(t.h6, B, 4096, P(V_FC + 2), P(V_FC + 3), 4096, 1, t.h7, t.fc_ws, st));
-  DISN_TRY(gemv_launch(t.h7, B, 4096, P(V_FC + 4), P(V_FC + 5), DISN_EMBED_DIM, 0, t.emb, t.fc_ws, st));
+  if (ctx) {
+    DISN_TRY(hipEventRecord(ctx->ev[1], st));
+    DISN_TRY(hipStreamWaitEvent(as, ctx->ev[1], 0));
+  }
+  DISN_TRY(gemv_launch(pool5, B, 25088, P(V_FC), P(V_FC + 1), 4096, 1, t.h6, t.fc_ws, as));
+  DISN_TRY(gemv_launch(t.h6, B, 4096, P(V_FC + 2), P(V_FC + 3), 4096, 1, t.h7, t.fc_ws, as));
+  DISN_TRY(gemv_launch(t.h7, B, 4096, P(V_FC + 4), P(V_FC + 5), DISN_EMBED_DIM, 0, t.emb, t.fc_ws, as));
   // folded global block: gbias[b] = emb[b] . W4[512:1536] + b4
   DISN_TRY(gemv_launch(t.emb, B, DISN_EMBED_DIM, P(V_G + 6) + (size_t)512 * 512, P(V_G + 7), 512, 0,
-                       t.gbias, t.fc_ws, st));
+                       t.gbias, t.fc_ws, as));
+  if (ctx) DISN_TRY(hipEventRecord(ctx->ev[2], as));
   DISN_TRY(project_launch(pts, trans_mat, B, N, t.xy, st));
   DISN_TRY(gather_launch(t.featmap, t.xy, B, N, t.feat, st));
   DISN_TRY(pt_embed_launch(pts_rot, M, P(V_G), P(V_G + 1), P(V_L), P(V_L + 1), t.g1, t.l1, st));
@@ -426,6 +449,7 @@ int disn_train_step(const float* params, float* grads, const float* img, const f
   DISN_RC(dense_fwd(t.l4, 512, 512, nullptr, 0, 512, (int)M, t.l_p5, P(V_L + 9), 256, 1, t.l5, gws, gwb, st));
   DISN_RC(dense_fwd(t.g1, 64, 64, nullptr, 0, 64, (int)M, t.g_p2, P(V_G + 3), 256, 1, t.g2, gws, gwb, st));
   DISN_RC(dense_fwd(t.g2, 256, 256, nullptr, 0, 256, (int)M, t.g_p3, P(V_G + 5), 512, 1, t.g3, gws, gwb, st));
+  if (ctx) DISN_TRY(hipStreamWaitEvent(st, ctx->ev[2], 0));  // embedding, gbias, regularization
   for (int b = 0; b < B; ++b) {
     const size_t o = (size_t)b * N * 512;
     DISN_RC(dense_fwd(t.g3 + o, 512, 512, nullptr, 0, 512, N, t.g_p4, t.gbias + (size_t)b * 512, 512, 1,
@@ -435,17 +459,7 @@ int disn_train_step(const float* params, float* grads, const float* img, const f
   DISN_TRY(final_dot_launch(t.g5, t.l5, M, P(V_G + 10), P(V_G + 11), P(V_L + 10), P(V_L + 11), pred,
                             nullptr, nullptr, 1.0f, st));
 
-  // ---------------- losses ----------------
-  {
-    SumsqSegs segs{};
-    int n = 0;
-    for (int i = 0; i < 13; ++i) { segs.off[n] = L.offset[2 * i]; segs.cnt[n++] = L.count[2 * i]; }
-    for (int i = 0; i < 3; ++i) { segs.off[n] = L.offset[V_FC + 2 * i]; segs.cnt[n++] = L.count[V_FC + 2 * i]; }
-    for (int i = 0; i < 6; ++i) { segs.off[n] = L.offset[V_G + 2 * i]; segs.cnt[n++] = L.count[V_G + 2 * i]; }
-    for (int i = 0; i < 6; ++i) { segs.off[n] = L.offset[V_L + 2 * i]; segs.cnt[n++] = L.count[V_L + 2 * i]; }
-    segs.n = n;
-    DISN_TRY(sumsq_launch(params, segs, 0.5f * wd, losses + 3, t.sumsq_ws, st));
-  }
+  // ---------------- losses (losses[3] was written by the weight-norm pass above) ----------------
   DISN_TRY(loss_reduce_launch(pred, gt, M, sdf_weight, mask_weight, losses, st));
   DISN_TRY(loss_grad_launch(pred, gt, M, sdf_weight, mask_weight, t.dpred, st));
 
@@ -481,22 +495,34 @@ int disn_train_step(const float* params, float* grads, const float* img, const f
     DISN_RC(dense_bwd(h1, 64, 64, P(V + 2), t.d2, M, 256, wd, t.d1, G(V + 2), s, st));
     DISN_TRY(relu_bwd_colsum_launch(t.d1, h1, M, 64, 1, G(V + 1), s.red_ws, st));
     DISN_TRY(embed_bwd_launch(pts_rot, t.d1, M, G(V), P(V), wd, s.red_ws, st));
+    if (!loc) {
+      // ------------ backward: fc8, fc7, fc6 (needs only d(embedding) of the global stream) ------------
+      // on the auxiliary stream, under the local stream's GEMMs
+      if (ctx) {
+        DISN_TRY(hipEventRecord(ctx->ev[3], st));
+        DISN_TRY(hipStreamWaitEvent(as, ctx->ev[3], 0));
+      }
+      float* r2 = t.red_aux;
+      DISN_TRY(relu_bwd_colsum_launch(t.demb, nullptr, B, DISN_EMBED_DIM, 0, G(V_FC + 5), r2, as));
+      DISN_TRY(outer_launch(t.h7, t.demb, B, 4096, DISN_EMBED_DIM, G(V_FC + 4), P(V_FC + 4), wd, as));
+      DISN_TRY(gemv_t_launch(P(V_FC + 4), t.demb, B, 4096, DISN_EMBED_DIM, t.h7, t.dz7, as));
+      DISN_TRY(relu_bwd_colsum_launch(t.dz7, nullptr, B, 4096, 0, G(V_FC + 3), r2, as));
+      DISN_TRY(outer_launch(t.h6, t.dz7, B, 4096, 4096, G(V_FC + 2), P(V_FC + 2), wd, as));
+      DISN_TRY(gemv_t_launch(P(V_FC + 2), t.dz7, B, 4096, 4096, t.h6, t.dz6, as));
+      DISN_TRY(relu_bwd_colsum_launch(t.dz6, nullptr, B, 4096, 0, G(V_FC + 1), r2, as));
+      DISN_TRY(outer_launch(pool5, t.dz6, B, 25088, 4096, G(V_FC), P(V_FC), wd, as));
+      DISN_TRY(gemv_t_launch(P(V_FC), t.dz6, B, 25088, 4096, nullptr, t.dpool5, as));
+      if (ctx) DISN_TRY(hipEventRecord(ctx->ev[4], as));
+    }
   }
 
   // ---------------- backward: image feature map ----------------
   DISN_TRY(hipMemsetAsync(t.dmap, 0, (size_t)B * 137 * 137 * DISN_FEAT_DIM * sizeof(float), st));
   DISN_TRY(gather_bwd_launch(t.dfeat, t.xy, B, N, t.dmap, st));
-
-  // ---------------- backward: fc8, fc7, fc6 ----------------
-  DISN_TRY(relu_bwd_colsum_launch(t.demb, nullptr, B, DISN_EMBED_DIM, 0, G(V_FC + 5), s.red_ws, st));
-  DISN_TRY(outer_launch(t.h7, t.demb, B, 4096, DISN_EMBED_DIM, G(V_FC + 4), P(V_FC + 4), wd, st));
-  DISN_TRY(gemv_t_launch(P(V_FC + 4), t.demb, B, 4096, DISN_EMBED_DIM, t.h7, t.dz7, st));
-  DISN_TRY(relu_bwd_colsum_launch(t.dz7, nullptr, B, 4096, 0, G(V_FC + 3), s.red_ws, st));
-  DISN_TRY(outer_launch(t.h6, t.dz7, B, 4096, 4096, G(V_FC + 2), P(V_FC + 2), wd, st));
-  DISN_TRY(gemv_t_launch(P(V_FC + 2), t.dz7, B, 4096, 4096, t.h6, t.dz6, st));
-  DISN_TRY(relu_bwd_colsum_launch(t.dz6, nullptr, B, 4096, 0, G(V_FC + 1), s.red_ws, st));
-  DISN_TRY(outer_launch(pool5, t.dz6, B, 25088, 4096, G(V_FC), P(V_FC), wd, st));
-  DISN_TRY(gemv_t_launch(P(V_FC), t.dz6, B, 25088, 4096, nullptr, t.dpool5, st));
+  if (ctx) DISN_TRY(hipStreamWaitEvent(st, ctx->ev[4], 0));
+  // every gradient from offset[26] on (fc6..fc8 and both MLPs: 96 % of the bytes) is final here;
+  // the caller may start reducing that part while the convolution backward below still runs
+  if (head_ready_event) DISN_TRY(hipEventRecord((hipEvent_t)head_ready_event, st));
 
   // ---------------- backward: conv stack ----------------
   const float* dcur = t.dpool5;  // gradient w.r.t. the input of the layer above

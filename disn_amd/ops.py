@@ -375,8 +375,11 @@ def gather_backward(dfeat: torch.Tensor, xy: torch.Tensor) -> torch.Tensor:
 
 def train_step(params: torch.Tensor, grads: torch.Tensor, img: torch.Tensor, trans_mat: torch.Tensor,
                pts: torch.Tensor, pts_rot: torch.Tensor, gt: torch.Tensor, wd: float = 1e-5,
-               sdf_weight: float = 10.0, mask_weight: float = 4.0, ws: Optional[torch.Tensor] = None):
-    """forward + get_loss + gradients into `grads`: -> (pred [B,N], losses [5] device tensor)"""
+               sdf_weight: float = 10.0, mask_weight: float = 4.0, ws: Optional[torch.Tensor] = None,
+               ctx: Optional[int] = None, head_ready: Optional[torch.cuda.Event] = None):
+    """forward + get_loss + gradients into `grads`: -> (pred [B,N], losses [5] device tensor).
+    ctx: concurrency context (ctx_create); head_ready: a torch.cuda.Event (already recorded once, so
+    that its handle exists) recorded when the fc/MLP part of `grads` is final."""
     B, N = pts.shape[0], pts.shape[1]
     dev = params.device
     need = lib().disn_train_workspace_bytes(B, N)
@@ -387,11 +390,11 @@ def train_step(params: torch.Tensor, grads: torch.Tensor, img: torch.Tensor, tra
     pred = torch.empty((B, N), dtype=torch.float32, device=dev)
     losses = torch.empty((5,), dtype=torch.float32, device=dev)
     check("disn_train_step", lib().disn_train_step(
-        _chk(params, "params").data_ptr(), _chk(grads, "grads").data_ptr(), _chk(img, "img").data_ptr(),
+        ctx, _chk(params, "params").data_ptr(), _chk(grads, "grads").data_ptr(), _chk(img, "img").data_ptr(),
         _chk(trans_mat, "trans_mat").data_ptr(), _chk(pts, "pts").data_ptr(),
         _chk(pts_rot, "pts_rot").data_ptr(), _chk(gt, "gt").data_ptr(), B, N, float(wd),
-        float(sdf_weight), float(mask_weight), pred.data_ptr(), losses.data_ptr(), ws.data_ptr(),
-        ws.numel(), _stream()))
+        float(sdf_weight), float(mask_weight), pred.data_ptr(), losses.data_ptr(),
+        head_ready.cuda_event if head_ready is not None else None, ws.data_ptr(), ws.numel(), _stream()))
     return pred, losses
 
 

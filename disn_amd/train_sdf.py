@@ -20,10 +20,12 @@ import numpy as np
 import torch
 
 from . import ops
+from .parallel import GradientReducer
 from .weights import WeightStore, variable_shapes
 
 LOSS_NAMES = ("accuracy", "sdf_loss_realvalue", "sdf_loss", "regularization", "overall_loss")
 VARIABLE_ORDER = tuple(variable_shapes())  # == the order of disn_param_layout
+HEAD_FIRST_VAR = 26  # vgg_16/fc6/weights: everything from here on is final before the conv backward
 
 
 def get_learning_rate(step: int, batch_size: int, base_lr: float = 1e-4, decay_step: int = 200000,
@@ -87,6 +89,24 @@ class Trainer:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         self._ws: Optional[torch.Tensor] = None
+        self.ctx = ops.ctx_create()  # auxiliary stream for the HBM-bound side work of the step
+        # gradient exchange: fc + MLP bucket under the convolution backward, conv bucket at the end
+        self.reducer = GradientReducer(int(self.flat.layout.offset[HEAD_FIRST_VAR]), process_group)
+        self.head_ready = torch.cuda.Event()
+        with torch.cuda.device(self.params.device):
+            self.head_ready.record()  # creates the hipEvent_t handed to the library
+
+    def close(self) -> None:
+        if self.ctx:
+            torch.cuda.synchronize(self.params.device)
+            ops.ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
     # ---- one step ---------------------------------------------------------------------
     def forward_backward(self, feed: Dict[str, torch.Tensor]):
@@ -96,9 +116,11 @@ class Trainer:
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.params.device)
-        return ops.train_step(self.params, self.grads, feed["imgs"], feed["trans_mat"], feed["sample_pc"],
-                              feed["sample_pc_rot"], feed["sdf"], self.wd, self.sdf_weight,
-                              self.mask_weight, ws=self._ws)
+        out = ops.train_step(self.params, self.grads, feed["imgs"], feed["trans_mat"], feed["sample_pc"],
+                             feed["sample_pc_rot"], feed["sdf"], self.wd, self.sdf_weight,
+                             self.mask_weight, ws=self._ws, ctx=self.ctx, head_ready=self.head_ready)
+        self.reducer.start_head(self.grads, self.head_ready)
+        return out
 
     def learning_rate(self) -> float:
         return get_learning_rate(self.step_count, self.batch_size, self.base_lr, self.decay_step,
@@ -108,8 +130,7 @@ class Trainer:
         lr = self.learning_rate()
         t = self.step_count + 1
         lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
-        if self.world > 1:
-            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        self.reducer.finish(self.grads)
         ops.adam_update(self.params, self.grads, self.m, self.v, lr_t, self.beta1, self.beta2, self.eps,
                         1.0 / self.world)
         self.step_count = t

@@ -276,12 +276,20 @@ int disn_param_layout(disn_param_layout_t* out);
  * wd*w included for every '/weights' variable).  B*N <= 65536.
  * gt [B,N] = the fed 'sdf' (sdf_val - 0.003, train/train_sdf.py:375).
  * pred [B,N] = pred_sdf (un-divided).  losses: 5 device floats =
- * {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}. */
+ * {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}.
+ * ctx (may be NULL): the HBM-bound side work (weight-norm sum, fc6-fc8 forward and backward) runs on
+ *   the context's auxiliary stream under the MFMA-bound GEMMs; the caller still sees one
+ *   asynchronous operation on `stream`.
+ * head_ready_event (may be NULL): a hipEvent_t recorded on `stream` at the point where every
+ *   gradient from offset[26] on (fc6..fc8 and both MLPs, 96 % of the bytes) is final, before the
+ *   convolution backward: a data-parallel caller starts reducing that part under the rest of the
+ *   step.  Gradients of the MLPs and fc layers are bit-reproducible; those of the convolutions
+ *   depend on fp32 atomics (resampler gradient) in their last bits. */
 size_t disn_train_workspace_bytes(int B, int N);
-int disn_train_step(const float* params, float* grads, const float* img, const float* trans_mat,
-                    const float* pts, const float* pts_rot, const float* gt, int B, int N, float wd,
-                    float sdf_weight, float mask_weight, float* pred, float* losses, void* ws,
-                    size_t ws_bytes, void* stream);
+int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const float* img,
+                    const float* trans_mat, const float* pts, const float* pts_rot, const float* gt, int B,
+                    int N, float wd, float sdf_weight, float mask_weight, float* pred, float* losses,
+                    void* head_ready_event, void* ws, size_t ws_bytes, void* stream);
 
 /* tf.train.AdamOptimizer update (train/train_sdf.py:251) on n floats (n % 4 == 0):
  * g = grads*grad_scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;

@@ -281,3 +281,18 @@ def test_checkpoint_roundtrip_with_adam_slots(tmp_path, small_step):
     tr.step(feed); tr2.step(feed)
     mlp = slice(int(tr.flat.layout.offset[32]), tr.flat.total)
     assert torch.equal(tr.params[mlp], tr2.params[mlp])
+
+
+def test_trainer_with_one_rank_rccl_group_overlapped_exchange():
+    """The data-parallel call sequence on one GPU (tools/ddp_one_rank.py): a one-rank 'nccl' (= RCCL)
+    group with the exchange forced on -- head bucket on the side stream gated by the library's
+    head-ready event, tail bucket after the step, Adam with grad_scale 1/world.  After one step the
+    result must equal the exchange-free trainer bit for bit on everything that is reproducible
+    (fc + MLP variables)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_one_rank.py")], capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "DDP1_OK" in r.stdout, "\n".join(r.stderr.splitlines()[-25:])

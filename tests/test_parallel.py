@@ -76,3 +76,62 @@ def test_single_process_equals_unsharded():
 
     out = par.sharded_grid(query_fn, 2, total, torch.device("cpu"))
     assert torch.equal(out[1], torch.arange(total, dtype=torch.float32) + 1000)
+
+
+# ---------------------------------------------------------------- data-parallel training ----------
+def test_shard_batch():
+    assert [par.shard_batch(64, 8, r) for r in (0, 7)] == [(0, 8), (56, 64)]
+    with pytest.raises(ValueError):
+        par.shard_batch(20, 8, 0)
+
+
+def _ddp_worker(rank, world, port, q):
+    """Two ranks, each with the gradient of its half of a quadratic loss: after the bucketed exchange
+    plus the 1/world scale inside Adam, both ranks hold the same parameters as a single process that
+    saw the whole batch (oracle/train_oracle.adam_step is the optimizer reference)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import train_oracle as T
+        n, head = 1000, 300
+        rng = np.random.default_rng(5)
+        w0 = rng.standard_normal(n)
+        targets = rng.standard_normal((world, n))            # rank r fits targets[r]
+        w, m, v = w0.copy(), np.zeros(n), np.zeros(n)
+        red = par.GradientReducer(head, use_side_stream=False)
+        assert red.world == world
+        for t in range(1, 4):
+            g = torch.from_numpy(w - targets[rank])            # d/dw 0.5*|w - target_r|^2
+            red.start_head(g)
+            red.finish(g)
+            w, m, v = T.adam_step(w, g.numpy() / world, m, v, t, 1e-2)
+        q.put((rank, w))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradient_reducer_gloo_world2_matches_single_process():
+    from oracle import train_oracle as T
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 77) % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 1000
+    rng = np.random.default_rng(5)
+    w = rng.standard_normal(n)
+    targets = rng.standard_normal((world, n))
+    m, v = np.zeros(n), np.zeros(n)
+    for t in range(1, 4):
+        g = (w[None] - targets).mean(0)                        # gradient of the mean over the global batch
+        w, m, v = T.adam_step(w, g, m, v, t, 1e-2)
+    assert np.array_equal(results[0], results[1])              # replicas stay bit-identical
+    assert np.allclose(results[0], w, rtol=0, atol=1e-12)
