@@ -59,6 +59,60 @@ def ev_time_ms(fn, reps, torch):
     return s.elapsed_time(e) / reps
 
 
+def train_feed(torch, dev, B, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    feed = {"imgs": torch.rand((B, 137, 137, 3), device=dev, generator=g),
+            "sample_pc": torch.rand((B, N_POINTS, 3), device=dev, generator=g) - 0.5,
+            "trans_mat": torch.tensor([[[-68.453156, 5.5086656, -0.37556022], [-17.138561, -84.685486, -0.250198],
+                                        [-47.284092, -3.6569588, 0.2493176], [101.133705, 101.34268, 1.4305686]]] * B,
+                                      dtype=torch.float32, device=dev),
+            "sdf": 0.05 * torch.randn((B, N_POINTS, 1), device=dev, generator=g)}
+    feed["sample_pc_rot"] = feed["sample_pc"].clone()
+    return feed
+
+
+def train_bench(args, torch, dist, dev, world, rank, launched):
+    """timed region = K full optimizer steps (forward, get_loss, backward of every variable, gradient
+    exchange, Adam) with the batch resident in HBM"""
+    from disn_amd.train_sdf import Trainer
+    from disn_amd.weights import WeightStore
+    B = args.train_batch
+    tr = Trainer(WeightStore.random_init(0, mode="he"), dev, batch_size=B * world)
+    feed = train_feed(torch, dev, B, 1000 + rank)
+    for _ in range(args.warmup):
+        tr.step(feed)
+    torch.cuda.synchronize()
+    if launched:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, losses, _ = tr.step(feed)
+    torch.cuda.synchronize()
+    if launched:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if launched:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(losses["overall_loss"])
+    assert np.isfinite(loss)
+    tr.close()
+    return {"metric": "training samples/sec (train_sdf.py step: VGG-16 + two-stream SDF net, 2048 points/sample, "
+                      "all variables trained, Adam)",
+            "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5 shape in fp32: data-parallel training step, %d samples x %d "
+                                   "points per GPU, random-init (he) weights" % (B, N_POINTS),
+                       "global_batch": B * world, "points_per_sample": N_POINTS,
+                       "parallelism": "dp%d (one sum all-reduce of the flat gradient buffer in two buckets, the "
+                                      "fc+MLP bucket under the conv backward)" % world},
+            "final_loss": loss}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +120,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / grid / cpu legs")
     ap.add_argument("--cpu-runs", type=int, default=5)
+    ap.add_argument("--workload", choices=("query", "train"), default="query",
+                    help="query: BASELINE.json metric (default); train: config-5 training step")
+    ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step")
     args = ap.parse_args()
 
     import torch
@@ -88,6 +145,17 @@ def main():
     from disn_amd import ops
     from disn_amd.engine import SdfEngine
     from disn_amd.weights import WeightStore
+
+    if args.workload == "train":
+        # BASELINE config 5 (not the north-star metric): data-parallel training step, B images x 2048
+        # points per GPU, fp32, TF Adam; gradients exchanged by RCCL under the convolution backward
+        line = train_bench(args, torch, dist, dev, world, rank, launched)
+        if rank == 0:
+            print(json.dumps(line))
+        if launched:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     store = WeightStore.random_init(0, mode="xavier")          # "random-init weights" (create_sdf.py:184-192)
     eng = SdfEngine(store, dev)
@@ -218,6 +286,28 @@ def main():
                                 "includes": "encode + 257^3 SDF + marching cubes on one GPU (random-init weights: "
                                             "the iso-surface of an untrained net); .obj write timed separately"}
         del full
+        # ---- training step (BASELINE config 5 shape, one GPU's share: 8 samples x 2048 points) -----
+        try:
+            from disn_amd.train_sdf import Trainer
+            tr = Trainer(WeightStore.random_init(0, mode="he"), dev, batch_size=8)
+            tfeed = train_feed(torch, dev, 8, 1)
+            for _ in range(2):
+                tr.step(tfeed)
+            ms_fb = ev_time_ms(lambda: tr.forward_backward(tfeed), 5, torch)
+            ms_step = ev_time_ms(lambda: tr.step(tfeed), 5, torch)
+            # 3x the forward MACs of the convolutions and the two point MLPs (data + weight gradients)
+            conv_flop = 8 * sum(2.0 * hw * hw * cout * 9 * cin for cin, cout, hw in VGG_LAYERS)
+            mlp_flop = 8 * N_POINTS * MLP_FLOP_PER_PT
+            line["train_step"] = {"samples": 8, "points_per_sample": N_POINTS, "ms_forward_backward": ms_fb,
+                                  "ms_step": ms_step, "samples_per_s": 8 / ms_step * 1e3, "dtype": "f32",
+                                  "mfma_tflops": 3 * (conv_flop + mlp_flop) / ms_fb / 1e9,
+                                  "note": "forward + get_loss + gradient of all 56 variables + TF Adam; "
+                                          "python bench.py --workload train [--gpus N] times it as the main line"}
+            tr.close()
+            del tr, tfeed
+            torch.cuda.empty_cache()
+        except Exception as e:  # the north-star line must survive a failure of this leg
+            line["train_step"] = {"error": repr(e)}
         # ---- CPU baseline: the oracle on the same workload, host cores -----------------------------
         from oracle import disn_oracle as O
         Wn = store.arrays
