@@ -44,6 +44,13 @@ class MlpWeights(C.Structure):  # disn_mlp_weights_t
     _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS]
 
 
+CAM_FIELDS = tuple("%s_%s%d" % (t, k, i) for t in "srt" for i in (1, 2, 3) for k in "wb")
+
+
+class CamWeights(C.Structure):  # disn_cam_weights_t: s_w1, s_b1, s_w2, ... t_b3
+    _fields_ = [(n, C.c_void_p) for n in CAM_FIELDS]
+
+
 NUM_VARS = 56
 
 
@@ -84,6 +91,7 @@ SIGNATURES = {
     "disn_query_grid_ctx": (I, [P, C.POINTER(MlpWeights), P, P, P, C.POINTER(C.c_double * 6), I, L, L, F, P,
                                 P, Z, P]),
     "disn_crc32c": (C.c_uint32, [P, Z, C.c_uint32]),
+    "disn_cam_head": (I, [C.POINTER(CamWeights), P, C.POINTER(C.c_float * 9), I, P, P, P, P, P]),
     "disn_param_layout": (I, [C.POINTER(ParamLayout)]),
     "disn_train_workspace_bytes": (Z, [I, I]),
     "disn_train_step": (I, [P, P, P, P, P, P, P, P, I, I, F, F, F, P, P, P, P, Z, P]),

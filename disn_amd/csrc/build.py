@@ -27,6 +27,7 @@ SOURCES = {
     "backward.hip": [],
     "backward_img.hip": ["-munsafe-fp-atomics", "-ffp-contract=off"],  # same lerp weights as the forward
     "train.hip": [],
+    "cam_head.hip": [],
     "mlp_small.hip": [],
     "mlp_fused.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],

@@ -173,3 +173,48 @@ class Trainer:
         if b2 is not None and 0.0 < float(b2) < 1.0:
             self.step_count = max(int(round(math.log(float(b2)) / math.log(self.beta2))) - 1, 0)
         return n
+
+
+def feed_from_batch(batch_data: Dict[str, np.ndarray], device, rank: int = 0, world: int = 1
+                    ) -> Dict[str, torch.Tensor]:
+    """the feed_dict of train/train_sdf.py:371-378 ('sdf' = sdf_val - 0.003, :375) as device tensors;
+    with world > 1 this rank's shard of the batch (parallel.shard_batch)"""
+    from .parallel import shard_batch
+    B = batch_data["img"].shape[0]
+    b0, b1 = shard_batch(B, world, rank) if world > 1 else (0, B)
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a[b0:b1], np.float32)).to(device, non_blocking=True)
+
+    return {"imgs": dev(batch_data["img"]), "sample_pc": dev(batch_data["sdf_pt"]),
+            "sample_pc_rot": dev(batch_data["sdf_pt_rot"]), "trans_mat": dev(batch_data["trans_mat"]),
+            "sdf": dev(batch_data["sdf_val"] - np.float32(0.003))}
+
+
+def train_one_epoch(trainer: Trainer, dataset, num_batches: int, log=print, log_every: int = 20,
+                    rank: int = 0) -> Dict[str, float]:
+    """train/train_sdf.py:349-440: fetch -> feed -> one optimizer step -> running means of the five
+    losses, a log line every `log_every` batches.  Loss scalars stay on the device until a log line
+    needs them (one host sync per log line instead of one per batch)."""
+    import time
+    sums = torch.zeros(len(LOSS_NAMES), dtype=torch.float64, device=trainer.params.device)
+    window = torch.zeros_like(sums)
+    fetch_time, tic = 0.0, time.time()
+    for batch_idx in range(num_batches):
+        t0 = time.time()
+        batch_data = dataset.fetch()
+        fetch_time += time.time() - t0
+        feed = feed_from_batch(batch_data, trainer.params.device, rank, trainer.world)
+        _, losses, lr = trainer.step(feed)
+        vals = torch.stack([losses[n] for n in LOSS_NAMES]).to(torch.float64)
+        sums += vals
+        window += vals
+        if (batch_idx + 1) % log_every == 0:
+            w = (window / log_every).tolist()
+            log("batch %d/%d lr %.3g  %s  | %.3f s/batch, fetch %.3f s" % (
+                batch_idx + 1, num_batches, lr, "  ".join("%s %.5g" % (n, v) for n, v in zip(LOSS_NAMES, w)),
+                (time.time() - tic) / log_every, fetch_time / log_every))
+            window.zero_()
+            fetch_time, tic = 0.0, time.time()
+    means = (sums / max(num_batches, 1)).tolist()
+    return dict(zip(LOSS_NAMES, means))

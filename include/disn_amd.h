@@ -326,6 +326,26 @@ int disn_resize_bilinear_backward(const float* dout, int B, int Hin, int Win, in
 int disn_gather_backward(const float* dfeat, const float* xy, int B, int N, float* dfeatmap,
                          void* stream);
 
+/* ---------------------------------------------------------------------- *
+ * Camera head: the estimated-camera source of `trans_mat`.  *
+ * models/posenet.py:91-124 get_cam_mat on the VGG embedding [B,1024]       *
+ * (towers scale 1024-64-32-1, ortho6d 1024-512-256-6, translation          *
+ * 1024-128-64-3 + const, 6-D -> rotation by Gram-Schmidt :22-36) and       *
+ * cam_est/model_cam.py:102-103 pred_trans_mat = pred_RT @ K^T.             *
+ * Weights: tf_util.fully_connected variables                               *
+ * 'cameraprediction/<tower>/fc{1,2,3}/{weights [in,out], biases [out]}'    *
+ * as they are.  K_host: 9 floats (3x3 row-major, HOST memory), NULL = the  *
+ * reference's constant (model_cam.py:28).  Outputs rotation [B,3,3],       *
+ * translation [B,3], RT [B,4,3], trans_mat [B,4,3].                        *
+ * ---------------------------------------------------------------------- */
+typedef struct disn_cam_weights {
+  const float *s_w1, *s_b1, *s_w2, *s_b2, *s_w3, *s_b3; /* scale */
+  const float *r_w1, *r_b1, *r_w2, *r_b2, *r_w3, *r_b3; /* ortho6d */
+  const float *t_w1, *t_b1, *t_w2, *t_b2, *t_w3, *t_b3; /* translation */
+} disn_cam_weights_t;
+int disn_cam_head(const disn_cam_weights_t* w, const float* embedding, const float* K_host, int B,
+                  float* rotation, float* translation, float* RT, float* trans_mat, void* stream);
+
 /* Host utility: Wavefront .obj writer ("v x y z" / "f a b c", 1-based) for HOST arrays; the
  * reference's output artefact (test/create_sdf.py:311).  Returns 0, or DISN_E_ARG on I/O error. */
 int disn_write_obj(const char* path, const float* verts_host, int64_t nv, const int32_t* faces_host,

@@ -296,3 +296,37 @@ def test_trainer_with_one_rank_rccl_group_overlapped_exchange():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_one_rank.py")], capture_output=True,
                        text=True, timeout=900, env=env)
     assert r.returncode == 0 and "DDP1_OK" in r.stdout, "\n".join(r.stderr.splitlines()[-25:])
+
+
+def test_train_one_epoch_from_the_loader(tmp_path):
+    """the reference's epoch loop (train/train_sdf.py:349-440): loader thread -> feed -> step -> running
+    means, on a synthetic on-disk dataset in the reference's directory layout"""
+    import types
+    from disn_amd import data_sdf as D
+    from disn_amd.train_sdf import LOSS_NAMES, Trainer, train_one_epoch
+    from disn_amd.weights import WeightStore
+    rng = np.random.default_rng(0)
+    info = {"rendered_dir": str(tmp_path / "img"), "sdf_dir": str(tmp_path / "sdf")}
+    listinfo = []
+    tm = O.DEMO_TRANS_MAT[0]
+    for o in range(4):
+        pts = rng.uniform(-0.5, 0.5, (600, 3)).astype(np.float32)
+        sdf = np.linalg.norm(pts, axis=1, keepdims=True) - 0.3          # a sphere
+        D.save_sample(info["sdf_dir"], "03001627", "o%d" % o, np.concatenate([pts, sdf], 1),
+                      np.concatenate([pts, sdf], 1), [0, 0, 0, 1], [-1, -1, -1, 1, 1, 1])
+        img = rng.integers(0, 256, (137, 137, 4), dtype=np.uint8)
+        D.save_view(info["rendered_dir"], "03001627", "o%d" % o, 0, img, tm, np.eye(3), tm)
+        listinfo.append(["03001627", "o%d" % o, 0])
+    flags = types.SimpleNamespace(num_points=64, num_sample_points=512, batch_size=2, img_h=137, img_w=137,
+                                  rot=False, max_epoch=3, cat_limit=100, backcolorwhite=False, alpha=False)
+    ds = D.Pt_sdf_img(flags, listinfo=listinfo, info=info, qsize=4, shuffle=True, seed=1)
+    ds.start()
+    tr = Trainer(WeightStore(O.init_weights(7, "he")), batch_size=2)
+    lines = []
+    first = train_one_epoch(tr, ds, ds.num_batches, log=lines.append, log_every=1)
+    for _ in range(2):
+        last = train_one_epoch(tr, ds, ds.num_batches, log=lines.append, log_every=1)
+    ds.shutdown()
+    tr.close()
+    assert set(first) == set(LOSS_NAMES) and tr.step_count == 6 and len(lines) == 6
+    assert all(math.isfinite(v) for v in last.values()) and last["sdf_loss"] < first["sdf_loss"]

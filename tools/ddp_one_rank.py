@@ -39,7 +39,10 @@ for _ in range(2):  # later steps see conv weights that differ in the last bits 
     a.step(feed)
     b.step(feed)
 torch.cuda.synchronize()
-assert torch.allclose(a.params, b.params, rtol=0, atol=2e-4), float((a.params - b.params).abs().max())
+# Adam moves a weight by ~lr = 1e-4 per step in the direction of sign(g): where g ~ 0 the last-bit noise
+# flips the sign, so two runs may differ by up to 2*lr per step there
+assert torch.allclose(a.params, b.params, rtol=0, atol=1e-3), float((a.params - b.params).abs().max())
+assert float((a.params - b.params).abs().mean()) < 2e-6
 a.close()
 b.close()
 dist.barrier()
