@@ -343,6 +343,20 @@ int overlap_mask() {
   const char* e = std::getenv("DISN_OVERLAP");
   return e ? std::atoi(e) : 2;
 }
+// fc6 weight prefetch (tools/overlap_sweep.py): MB to read ahead, the conv layer before which the
+// read starts, and its grid size (small: it must trickle under the convolutions)
+int prefetch_mb() {
+  static const int v = [] { const char* e = std::getenv("DISN_PREFETCH_MB"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+int prefetch_layer() {
+  static const int v = [] { const char* e = std::getenv("DISN_PREFETCH_LAYER"); return e ? std::atoi(e) : 10; }();
+  return v;
+}
+int prefetch_blocks() {
+  static const int v = [] { const char* e = std::getenv("DISN_PREFETCH_BLOCKS"); return e ? std::atoi(e) : 256; }();
+  return v;
+}
 int resize_bg_blocks() {
   const char* e = std::getenv("DISN_RESIZE_BG_BLOCKS");
   return e ? std::atoi(e) : 256;
@@ -370,6 +384,16 @@ int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, i
   const size_t gws_cap = (size_t)((char*)s.fc_ws - (char*)s.gemm_ws);
   for (int i = 0; i < 13; ++i) {
     const VggLayer& L = kVgg[i];
+    if (ctx && i == prefetch_layer() && prefetch_mb() > 0) {
+      // warm the memory-side cache with the head of the fc6 weights while the (MFMA-bound) last
+      // convolutions run: fc6 is the HBM-bound 411 MB stream that follows them on the critical path
+      size_t bytes = (size_t)prefetch_mb() << 20;
+      const size_t all = (size_t)25088 * 4096 * sizeof(float);
+      if (bytes > all) bytes = all;
+      DISN_TRY(hipEventRecord(ctx->ev[5], st));
+      DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[5], 0));
+      DISN_TRY(prefetch_launch(w->fc_w[0], bytes, s.fc6, prefetch_blocks(), ctx->aux));
+    }
     float* out = L.tap >= 0 ? taps[L.tap] : (L.hw >= 112 ? s.bufA : (toggle ? s.bufB : s.bufA));
     if (L.tap < 0 && L.hw < 112) toggle = !toggle;
     const int rc = conv3x3_impl(x, B, L.hw, L.hw, L.cin, w->conv_w[i], w->conv_b[i], L.cout, 1,

@@ -517,14 +517,14 @@ GemmPlan gemm_plan(int M, int N, int K, size_t max_ws) {
       const long per_wg = (U + W - 1) / W;          // k-steps of the busiest workgroup
       // workgroups the busiest CU executes: round-robin for a few, dynamically balanced (half a
       // workgroup of tail) once there are >= 4 per CU
-      const double cu_wgs = W >= 1024 ? (double)W / 256.0 + 0.5 : (double)((W + 255) / 256);
+      const double cu_wgs = W >= 1024 ? (double)W / 256.0 + (W % 256 ? 0.5 : 0.0) : (double)((W + 255) / 256);
       const long resident = (W + 255) / 256 < occ ? (W + 255) / 256 : occ;   // per CU at a time
       // Co-resident workgroups share the CU's MFMA pipes, so the busiest CU needs
       // cu_wgs * per_wg * unit MFMA cycles however they are scheduled.  MFMA-busy fractions fitted
       // to tools/sweep_gemm.py at B = 1 and B = 8: a wave alone on its SIMD loses ~14 % to the
       // per-step LDS/barrier bubble; bigger tiles re-use more of each staged operand, and the A
       // side (im2col gather) is the expensive one to widen.
-      const double tile_eff = tq >= 4 ? 0.93 : (tq == 1 ? 0.84 : (bm == 128 ? 0.83 : 0.86));
+      const double tile_eff = tq >= 4 ? 0.93 : (tq == 1 ? 0.84 : (bm == 128 ? 0.79 : 0.86));
       const double eff = (resident >= 2 ? 1.0 : 0.86) * tile_eff;
       double cost = cu_wgs * per_wg * unit / eff + 6000.0;
       // persistent stream-K workgroups finish together; the dispatcher balances one-tile
