@@ -91,15 +91,19 @@ SIGNATURES = {
     "disn_query_grid_ctx": (I, [P, C.POINTER(MlpWeights), P, P, P, C.POINTER(C.c_double * 6), I, L, L, F, P,
                                 P, Z, P]),
     "disn_crc32c": (C.c_uint32, [P, Z, C.c_uint32]),
+    "disn_dense_bf16_workspace_bytes": (Z, [I, I, I]),
+    "disn_dense_bf16": (I, [P, I, I, P, I, I, I, P, P, I, I, P, P, Z, P]),
+    "disn_conv3x3_bf16_workspace_bytes": (Z, [I, I, I, I, I]),
+    "disn_conv3x3_bf16": (I, [P, I, I, I, I, P, P, I, I, P, P, Z, P]),
     "disn_cam_head": (I, [C.POINTER(CamWeights), P, C.POINTER(C.c_float * 9), I, P, P, P, P, P]),
     "disn_param_layout": (I, [C.POINTER(ParamLayout)]),
     "disn_train_workspace_bytes": (Z, [I, I]),
-    "disn_train_step": (I, [P, P, P, P, P, P, P, P, I, I, F, F, F, P, P, P, P, Z, P]),
+    "disn_train_step": (I, [P, P, P, P, P, P, P, P, I, I, F, F, F, I, P, P, P, P, Z, P]),
     "disn_adam_update": (I, [P, P, P, P, L, F, F, F, F, F, P]),
     "disn_dense_backward_workspace_bytes": (Z, [I, I, I]),
-    "disn_dense_backward": (I, [P, I, I, P, P, P, I, I, F, P, P, P, P, Z, P]),
+    "disn_dense_backward": (I, [P, I, I, P, P, P, I, I, F, I, P, P, P, P, Z, P]),
     "disn_conv3x3_backward_workspace_bytes": (Z, [I, I, I, I, I]),
-    "disn_conv3x3_backward": (I, [P, I, I, I, I, P, P, P, I, F, P, P, P, P, Z, P]),
+    "disn_conv3x3_backward": (I, [P, I, I, I, I, P, P, P, I, F, I, P, P, P, P, Z, P]),
     "disn_maxpool2x2_backward": (I, [P, P, I, I, I, I, P, P]),
     "disn_resize_bilinear_backward_workspace_bytes": (Z, [I, I, I, I, I, I]),
     "disn_resize_bilinear_backward": (I, [P, I, I, I, I, I, I, I, I, P, I, P, Z, P]),

@@ -24,6 +24,7 @@ SOURCES = {
     "gemm_mfma.hip": [],
     "gemv.hip": [],
     "gemm_tn_mfma.hip": [],
+    "gemm_bf16_mfma.hip": [],
     "backward.hip": [],
     "backward_img.hip": ["-munsafe-fp-atomics", "-ffp-contract=off"],  # same lerp weights as the forward
     "train.hip": [],

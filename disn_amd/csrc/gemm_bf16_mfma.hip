@@ -1,0 +1,350 @@
+// bf16-MFMA GEMM for the mixed-precision TRAINING step (BASELINE config 5 names bf16; the
+// inference path stays on the exact fp32 MFMA: its parity bar is 1e-5).  Same two shapes as
+// gemm_mfma.hip -- the 3x3 SAME convolution as an implicit GEMM over NHWC input and the point-MLP
+// 1x1 convolutions -- with fp32 activations in HBM, fp32 accumulation and fp32 output: only the
+// multiply runs in bf16 (operands rounded to nearest-even when they are staged), i.e. "bf16 compute,
+// fp32 master" with nothing else of the step changed.
+//
+//   v_mfma_f32_32x32x16_bf16: 16x the rate of the f32-input MFMA (2.5 PFLOP/s dense peak); per lane
+//   8 consecutive k of one row (A) / one column (B): A-fragment lane (i = l&31, g = l>>5) holds
+//   A[i][8g..8g+7], B-fragment lane holds B[8g..8g+7][l&31]; C/D layout as the f32 form.
+//
+// Tiling as gemm_mfma.hip: 256 threads = 4 waves 2x2, block tile BM x BN, K step 32 (two MFMAs per
+// 32x32 accumulator).  A: coalesced float4 loads (8 lanes per 128-byte row), converted with
+// v_cvt_pk_bf16_f32 and staged in LDS as bf16 rows of 40 (80 bytes: 16 consecutive rows hit 16
+// distinct 4-bank groups, the ds_read_b128 fragment reads are conflict free), double buffered with
+// register prefetch.  B: weights pre-packed in bf16 fragment order (pack_bf16_launch), one 16-byte
+// load per lane per MFMA straight from L2.  One workgroup per tile (no stream-K: at the training
+// batch every layer has >= 200 tiles and the kernel is L2-bandwidth bound, not MFMA bound:
+// 128x128x32 moves 32 KB per 256 MFMA cycles).
+#include "kernels.hpp"
+
+namespace disn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------
+// weight packing: an [R][C] matrix (R = reduction, padded to Rpad % 32 == 0; C % 32 == 0) taken from
+// a TF-layout tensor in one of three views, to bf16 B-fragment order:
+//   packed[((r/16)*(C/32) + c/32)*512 + lane*8 + t] = M[16*(r/16) + 8*(lane>>5) + t][32*(c/32) + (lane&31)]
+// view 0: M = W [K][N]                         (forward)
+// view 1: M = W^T, W [K][N] -> M [N][K]        (dA = dZ W^T)
+// view 2: M[(t',co)][ci] = W[8-t'][ci][co]     (conv backward-data, W [3,3,Cin,Cout])
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ w, int view, int K,
+                                                        int N, int R, int Rpad, int C,
+                                                        __bf16* __restrict__ packed) {
+  const size_t total = (size_t)Rpad * C;
+  const int cb32 = C >> 5;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const size_t blk = i >> 9;
+    const int rb = (int)(blk / cb32), cb = (int)(blk - (size_t)rb * cb32);
+    const int r = rb * 16 + 8 * (lane >> 5) + t;
+    const int c = cb * 32 + (lane & 31);
+    float v = 0.f;
+    if (r < R) {
+      if (view == 0) {
+        v = w[(size_t)r * N + c];
+      } else if (view == 1) {
+        v = w[(size_t)c * N + r];
+      } else {  // K = Cin, N = Cout here
+        const int tp = r / N, co = r - tp * N;
+        v = w[((size_t)(8 - tp) * K + c) * N + co];
+      }
+    }
+    packed[i] = (__bf16)v;
+  }
+}
+
+hipError_t pack_bf16_launch(const float* w, int view, int K, int N, void* packed, hipStream_t st) {
+  int R, C;
+  if (view == 0) { R = K; C = N; }
+  else if (view == 1) { R = N; C = K; }
+  else { R = 9 * N; C = K; }
+  const int Rpad = (R + 31) & ~31;
+  const size_t total = (size_t)Rpad * C;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, view, K, N, R, Rpad, C,
+                     reinterpret_cast<__bf16*>(packed));
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+struct BfDev {
+  GemmParams p;  // p.bp unused; p.K = padded reduction length (multiple of 32)
+  const __bf16* bpk;
+  int mtiles, ntiles;
+  int S;      // split-K factor = gridDim.y; S > 1: raw partials to ws [S][M][N], splitk_reduce finishes
+  float* ws;
+};
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16_mfma(const BfDev d) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int LDA = 40;  // bf16 per staged row
+  constexpr int APASS = BM / 32;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BM * LDA];
+  const GemmParams& p = d.p;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int w = blockIdx.x;
+  {  // XCD-aware: consecutive tiles (sharing A rows) on the same XCD / L2
+    const int W = gridDim.x, q = W >> 3, r = W & 7, xcd = w & 7, idx = w >> 3;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = w / d.ntiles, nt = w - mt * d.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int KS_all = p.K >> 5;
+  const int s0 = (int)(((long)KS_all * blockIdx.y) / d.S), s1 = (int)(((long)KS_all * (blockIdx.y + 1)) / d.S);
+
+  // ---- A loader: rows (tid>>3) + 32*pass, float4 column (tid&7) ----------------------------------
+  const int arow = tid >> 3, c4 = (tid & 7) * 4;
+  const float* pa1[APASS];
+  const float* pa2[APASS];
+  unsigned vmask[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int m = m0 + arow + 32 * i;
+    const bool valid = m < p.M;
+    const size_t mm = valid ? (size_t)m : 0;
+    if (MODE == GEMM_DENSE) {
+      pa1[i] = p.a1 + mm * p.lda1 + c4;
+      pa2[i] = p.a2 ? p.a2 + mm * p.lda2 + c4 : p.a1;
+      vmask[i] = valid ? 0x1ffu : 0u;
+    } else {
+      const int hw = p.H * p.W;
+      const int rem = (int)(mm % hw);
+      const int y = rem / p.W, x = rem - y * p.W;
+      pa1[i] = p.a1 + mm * p.Cin + c4;
+      pa2[i] = p.a1;
+      unsigned vm = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (valid && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) vm |= 1u << t;
+      }
+      vmask[i] = vm;
+    }
+  }
+  float4 ra[APASS];
+  auto load_a = [&](int s) {
+    if (MODE == GEMM_DENSE) {
+      const int k0 = s * 32;
+      const bool first = k0 < p.k1;
+      const long off = first ? k0 : k0 - p.k1;
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>((first ? pa1[i] : pa2[i]) + off);
+        ra[i] = (vmask[i] & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      const int cblocks = p.Cin >> 5;
+      const int kyx = s / cblocks, ci0 = (s - kyx * cblocks) << 5;
+      const int dy = kyx / 3 - 1, dx = kyx - (kyx / 3) * 3 - 1;
+      const long delta = (long)(dy * p.W + dx) * p.Cin + ci0;
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        const bool ok = (vmask[i] >> kyx) & 1u;
+        const float4 v = *reinterpret_cast<const float4*>(pa1[i] + (ok ? delta : 0));
+        ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto store_a = [&](int buf) {
+    __bf16* la = &lds[buf * BM * LDA];
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      bf16x4 v;
+      v[0] = (__bf16)ra[i].x; v[1] = (__bf16)ra[i].y; v[2] = (__bf16)ra[i].z; v[3] = (__bf16)ra[i].w;
+      *reinterpret_cast<bf16x4*>(&la[(arow + 32 * i) * LDA + c4]) = v;
+    }
+  };
+  // ---- B loader: fragment-ordered bf16, [k16 block][n32 block][lane][8] ---------------------------
+  const int nb0 = (n0 >> 5) + wn * (BN / 64);
+  const int nblocks = p.N >> 5;
+  bf16x8 rb[2][TN];
+  auto load_b = [&](int s) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        rb[kk][j] = *reinterpret_cast<const bf16x8*>(
+            d.bpk + (((size_t)(2 * s + kk) * nblocks + nb0 + j) * 64 + lane) * 8);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_a(s0);
+  load_b(s0);
+  store_a(0);
+  __syncthreads();
+  int cur = 0;
+  for (int s = s0; s < s1; ++s) {
+    bf16x8 bcur[2][TN];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bcur[kk][j] = rb[kk][j];
+    const int sn = s + 1 < s1 ? s + 1 : s;
+    load_a(sn);
+    load_b(sn);
+    const __bf16* la = &lds[cur * BM * LDA] + (wm * (BM / 2) + (lane & 31)) * LDA + 8 * (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(la + i * 32 * LDA + kk * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bcur[kk][j], acc[i][j], 0, 0, 0);
+    }
+    store_a(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: bias, ReLU, fp32 store (32 consecutive columns per half-wave row) ----------------
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+    const float bv = d.S > 1 ? 0.f : p.bias[col];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.M) {
+          if (d.S > 1) {
+            d.ws[((size_t)blockIdx.y * p.M + row) * p.N + col] = acc[i][j][r];
+          } else {
+            float v = acc[i][j][r] + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            p.out[(size_t)row * p.ldc + col] = v;
+          }
+        }
+      }
+  }
+}
+
+template <int BM, int BN>
+static hipError_t bf_launch_mode(const BfDev& d, GemmMode mode, hipStream_t st) {
+  const dim3 grid(d.mtiles * d.ntiles, d.S);
+  if (mode == GEMM_DENSE)
+    hipLaunchKernelGGL((gemm_bf16_mfma<BM, BN, GEMM_DENSE>), grid, dim3(256), 0, st, d);
+  else
+    hipLaunchKernelGGL((gemm_bf16_mfma<BM, BN, GEMM_CONV3>), grid, dim3(256), 0, st, d);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || d.S == 1) return e;
+  return splitk_reduce_launch(d.ws, d.S, d.p.M, d.p.N, d.p.bias, 0, d.p.relu, d.p.out, d.p.ldc, st);
+}
+
+// split-K factor for a layer with few 64x64 tiles (the 14x14 / 28x28 convolutions, small point
+// sets): enough workgroups for ~3 per CU, at least 4 k-steps each, partials within ws_bytes
+static int bf_splits(long tiles, int ksteps, int M, int N, size_t ws_bytes) {
+  if (tiles >= 512) return 1;
+  int s = (int)((768 + tiles - 1) / tiles);
+  if (s > 8) s = 8;
+  while (s > 1 && (ksteps / s < 4 || (size_t)s * M * N * sizeof(float) > ws_bytes)) --s;
+  return s;
+}
+
+size_t gemm_bf16_ws_bytes(int M, int N, int K) {
+  const long tiles = (long)((M + 63) / 64) * (N / 64);
+  return (size_t)bf_splits(tiles, K / 32, M, N, ~size_t(0)) * M * N * sizeof(float);
+}
+
+// p.bp is ignored; bpk = pack_bf16_launch output for the [p.K][p.N] operand; mode DENSE or CONV3;
+// ws: gemm_bf16_ws_bytes (less is allowed: fewer splits)
+hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk, float* ws,
+                            size_t ws_bytes, hipStream_t st) {
+  BfDev d;
+  d.p = p;
+  d.bpk = reinterpret_cast<const __bf16*>(bpk);
+  d.S = 1;
+  d.ws = ws;
+  // 128x128 when that still gives every CU two tiles; otherwise the small tile (+ split-K)
+  const long t128 = (long)((p.M + 127) / 128) * (p.N / 128);
+  if (p.N % 128 == 0 && t128 >= 512) {
+    d.mtiles = (p.M + 127) / 128; d.ntiles = p.N / 128;
+    return bf_launch_mode<128, 128>(d, mode, st);
+  }
+  d.mtiles = (p.M + 63) / 64; d.ntiles = p.N / 64;
+  d.S = ws ? bf_splits((long)d.mtiles * d.ntiles, p.K / 32, p.M, p.N, ws_bytes) : 1;
+  return bf_launch_mode<64, 64>(d, mode, st);
+}
+
+}  // namespace disn
+
+// ---- C ABI: the two layer types in bf16 compute (unit-test / composition surface) -----------------
+#include "../../include/disn_amd.h"
+
+extern "C" {
+
+static size_t bf_packed_bytes(int K, int N) { return (((size_t)K * N * 2) + 255) & ~size_t(255); }
+
+size_t disn_dense_bf16_workspace_bytes(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0 || K % 32 || N % 64) return 0;
+  return bf_packed_bytes(K, N) + disn::gemm_bf16_ws_bytes(M, N, K);
+}
+
+int disn_dense_bf16(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, int M,
+                    const float* w_kn, const float* bias, int N, int relu, float* out, void* ws,
+                    size_t ws_bytes, void* stream) {
+  if (!a1 || !w_kn || !bias || !out || !ws || M <= 0 || k1 <= 0 || k2 < 0 || (k2 > 0 && !a2)) return DISN_E_ARG;
+  if (k1 % 32 || k2 % 32 || N <= 0 || N % 64 || lda1 < k1 || (k2 > 0 && lda2 < k2) || lda1 % 4 ||
+      (k2 > 0 && lda2 % 4))
+    return DISN_E_SHAPE;
+  const int K = k1 + k2;
+  if (ws_bytes < disn_dense_bf16_workspace_bytes(M, K, N)) return DISN_E_WS;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = disn::pack_bf16_launch(w_kn, 0, K, N, ws, st);
+  if (e != hipSuccess) return (int)e;
+  disn::GemmParams p{};
+  p.a1 = a1; p.lda1 = lda1; p.k1 = k1; p.a2 = a2; p.lda2 = lda2;
+  p.M = M; p.N = N; p.K = K;
+  p.bias = bias; p.out = out; p.ldc = N; p.relu = relu;
+  const size_t pb = bf_packed_bytes(K, N);
+  e = disn::gemm_bf16_launch(p, disn::GEMM_DENSE, ws, reinterpret_cast<float*>(static_cast<char*>(ws) + pb),
+                             ws_bytes - pb, st);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+size_t disn_conv3x3_bf16_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 64) return 0;
+  return bf_packed_bytes(9 * Cin, Cout) + disn::gemm_bf16_ws_bytes(B * H * W, Cout, 9 * Cin);
+}
+
+int disn_conv3x3_bf16(const float* in, int B, int H, int W, int Cin, const float* w_hwio,
+                      const float* bias, int Cout, int relu, float* out, void* ws, size_t ws_bytes,
+                      void* stream) {
+  if (!in || !w_hwio || !bias || !out || !ws || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
+  if (Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return DISN_E_SHAPE;
+  if (ws_bytes < disn_conv3x3_bf16_workspace_bytes(B, H, W, Cin, Cout)) return DISN_E_WS;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = disn::pack_bf16_launch(w_hwio, 0, 9 * Cin, Cout, ws, st);
+  if (e != hipSuccess) return (int)e;
+  disn::GemmParams p{};
+  p.a1 = in; p.H = H; p.W = W; p.Cin = Cin;
+  p.M = B * H * W; p.N = Cout; p.K = 9 * Cin;
+  p.bias = bias; p.out = out; p.ldc = Cout; p.relu = relu;
+  const size_t pb = bf_packed_bytes(9 * Cin, Cout);
+  e = disn::gemm_bf16_launch(p, disn::GEMM_CONV3, ws, reinterpret_cast<float*>(static_cast<char*>(ws) + pb),
+                             ws_bytes - pb, st);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // extern "C"

@@ -31,7 +31,15 @@ struct TnDev {
 
 __device__ __forceinline__ long tn_unit_begin(long U, int W, int w) { return (U * w) / W; }
 
-template <int BP, int BQ, bool CONV>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// BF: the multiply on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, mixed-precision step).  Both operands
+// are then staged TRANSPOSED, as bf16 T[col][32 m] rows of 40 (80 bytes), so that a fragment -- 8
+// consecutive m of one column -- is one conflict-free ds_read_b128.  The transposing LDS write is a
+// ds_write_b32 of the bf16 pair (m, m+1): a thread loads the same float4 column group of two adjacent
+// rows; lanes of a 32-lane write group are 16 row pairs x 2 column groups = 32 distinct banks.
+template <int BP, int BQ, bool CONV, bool BF>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
   constexpr int LDP = BP + 8, LDQ = BQ + 8;      // padded LDS row strides (words)
   constexpr int BUF = 32 * (LDP + LDQ);          // one stage
@@ -63,6 +71,113 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
     u += s_end - s_begin;
     const int pt = tile / d.qtiles, qt = tile - pt * d.qtiles;
     const int p0 = pt * BP, q0 = qt * BQ;
+    f32x16 acc[TP][TQ];
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+      for (int j = 0; j < TQ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (BF) {
+      // ---------------- bf16 path ----------------
+      constexpr int LDT = 40;                          // bf16 per transposed row (32 m + pad)
+      constexpr int TBUF = (BP + BQ) * LDT;            // one stage, in bf16
+      constexpr int PA = BP / 64, PB = BQ / 64;        // loader passes: 16 column groups x 16 row pairs each
+      __bf16* tl = reinterpret_cast<__bf16*>(lds);
+      const int rp = tid & 15, cg = tid >> 4;          // row pair, column group (4 per wave)
+      int tdy[PA], tdx[PA], tci[PA];
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        const int col = p0 + 4 * (cg + 16 * q);
+        tdy[q] = 0; tdx[q] = 0; tci[q] = col;
+        if (CONV) {
+          const int tap = col / p.Cin;
+          tci[q] = col - tap * p.Cin;
+          tdy[q] = tap / 3 - 1;
+          tdx[q] = tap - (tap / 3) * 3 - 1;
+        }
+      }
+      float4 xa[PA][2], xb[PB][2];
+      auto load = [&](int s) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const long m = (long)s * 32 + 2 * rp + h;
+          const bool okm = m < p.M;
+          const long mm = okm ? m : 0;
+          int y = 0, x = 0;
+          if (CONV) {
+            const int hw = p.H * p.W;
+            const int rem = (int)(mm % hw);
+            y = rem / p.W;
+            x = rem - y * p.W;
+          }
+#pragma unroll
+          for (int q = 0; q < PA; ++q) {
+            bool ok = okm;
+            const float* src;
+            if (CONV) {
+              const int yy = y + tdy[q], xx = x + tdx[q];
+              ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+              src = p.a + (size_t)(ok ? mm + tdy[q] * p.W + tdx[q] : 0) * p.Cin + tci[q];
+            } else {
+              src = p.a + (size_t)mm * p.lda + tci[q];
+            }
+            const float4 v = *reinterpret_cast<const float4*>(src);
+            xa[q][h] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int q = 0; q < PB; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(p.b + (size_t)mm * p.ldb + q0 + 4 * (cg + 16 * q));
+            xb[q][h] = okm ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      };
+      auto put = [&](__bf16* t, int colbase, const float4& lo, const float4& hi) {
+        const float l4[4] = {lo.x, lo.y, lo.z, lo.w}, h4[4] = {hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16x2 v;
+          v[0] = (__bf16)l4[j];
+          v[1] = (__bf16)h4[j];
+          *reinterpret_cast<bf16x2*>(&t[(colbase + j) * LDT + 2 * rp]) = v;
+        }
+      };
+      auto store = [&](int buf) {
+        __bf16* ta = tl + buf * TBUF;
+        __bf16* tb = ta + BP * LDT;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) put(ta, 4 * (cg + 16 * q), xa[q][0], xa[q][1]);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) put(tb, 4 * (cg + 16 * q), xb[q][0], xb[q][1]);
+      };
+      load(s_begin);
+      store(0);
+      __syncthreads();
+      int cur = 0;
+      for (int s = s_begin; s < s_end; ++s) {
+        const int sn = (s + 1 < s_end) ? s + 1 : s;
+        load(sn);
+        const __bf16* ta = tl + cur * TBUF + (wm * (BP / 2) + (lane & 31)) * LDT + 8 * (lane >> 5);
+        const __bf16* tb = tl + cur * TBUF + BP * LDT + (wn * (BQ / 2) + (lane & 31)) * LDT + 8 * (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8 af[TP], bfr[TQ];
+#pragma unroll
+          for (int i = 0; i < TP; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * LDT + kk * 16);
+#pragma unroll
+          for (int j = 0; j < TQ; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * LDT + kk * 16);
+#pragma unroll
+          for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < TQ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+      }
+    } else {
+    // ---------------- fp32 path ----------------
     // loaders: thread -> float4 column (tid % AV), rows (tid / AV) + AROWS*i
     const int arow = tid / AV, acol = (tid % AV) * 4;
     const int brow = tid / BV, bcol = (tid % BV) * 4;
@@ -113,13 +228,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
       for (int i = 0; i < BPASS; ++i)
         *reinterpret_cast<float4*>(&lb[(brow + BROWS * i) * LDQ + bcol]) = rb[i];
     };
-    f32x16 acc[TP][TQ];
-#pragma unroll
-    for (int i = 0; i < TP; ++i)
-#pragma unroll
-      for (int j = 0; j < TQ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     load(s_begin);
     store(0);
     __syncthreads();
@@ -150,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
       __syncthreads();
       cur ^= 1;
     }
+    }  // fp32 path
     const bool whole = s_begin == 0 && s_end == MS;
     float* slab = d.ws + (size_t)slot * BP * BQ;  // tile-local row-major [BP][BQ]
 #pragma unroll
@@ -213,6 +322,19 @@ size_t gemm_tn_ws_bytes(long M, int P, int Q) {
   return (size_t)2 * kTnMaxW * 128 * 128 * sizeof(float);
 }
 
+template <int BP, int BQ, bool CONV, bool BF>
+static hipError_t tn_launch_kernel(const TnDev& d, hipStream_t st) {
+  const size_t lds_bytes = BF ? (size_t)2 * (BP + BQ) * 40 * 2 : (size_t)2 * 32 * (BP + 8 + BQ + 8) * sizeof(float);
+  static bool attr_done = false;  // benign race: idempotent attribute
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_mfma<BP, BQ, CONV, BF>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_tn_f32_mfma<BP, BQ, CONV, BF>), dim3(d.W), dim3(256), lds_bytes, st, d);
+  return hipGetLastError();
+}
+
 template <int BP, int BQ>
 static hipError_t tn_launch_tile(const TnParams& p, float* ws, hipStream_t st) {
   TnDev d;
@@ -223,25 +345,11 @@ static hipError_t tn_launch_tile(const TnParams& p, float* ws, hipStream_t st) {
   d.qtiles = p.Q / BQ;
   d.units = (long)d.ptiles * d.qtiles * d.msteps;
   d.W = (int)(d.units < kTnMaxW ? d.units : kTnMaxW);
-  const size_t lds_bytes = (size_t)2 * 32 * (BP + 8 + BQ + 8) * sizeof(float);
-  if (p.Cin > 0) {
-    static bool attr_done = false;  // benign race: idempotent attribute
-    if (!attr_done) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_mfma<BP, BQ, true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL((gemm_tn_f32_mfma<BP, BQ, true>), dim3(d.W), dim3(256), lds_bytes, st, d);
-  } else {
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_mfma<BP, BQ, false>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL((gemm_tn_f32_mfma<BP, BQ, false>), dim3(d.W), dim3(256), lds_bytes, st, d);
-  }
-  hipError_t e = hipGetLastError();
+  hipError_t e;
+  if (p.Cin > 0)
+    e = p.bf16 ? tn_launch_kernel<BP, BQ, true, true>(d, st) : tn_launch_kernel<BP, BQ, true, false>(d, st);
+  else
+    e = p.bf16 ? tn_launch_kernel<BP, BQ, false, true>(d, st) : tn_launch_kernel<BP, BQ, false, false>(d, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((tn_fixup<BP, BQ>), dim3(d.ptiles * d.qtiles, BP * BQ / 1024), dim3(256), 0, st, d);
   return hipGetLastError();

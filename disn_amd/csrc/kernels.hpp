@@ -47,6 +47,15 @@ hipError_t pack_kn_launch(const float* w, int K, int N, int Kpad, float* packed,
 hipError_t splitk_reduce_launch(const float* ws, int S, int M, int N, const float* bias,
                                 int rows_per_bias, int relu, float* out, int ldc, hipStream_t st);
 
+// ---- gemm_bf16_mfma.hip: bf16-compute variant for the mixed-precision training step ---------
+// view 0: W [K][N]; 1: W^T (reduction N, columns K); 2: flipped 3x3 kernel for conv backward-data
+// (K = Cin, N = Cout: reduction 9*Cout, columns Cin).  packed: reduction padded to 32, 2 bytes each
+hipError_t pack_bf16_launch(const float* w, int view, int K, int N, void* packed, hipStream_t st);
+// as gemm_launch (DENSE or CONV3, fp32 in / fp32 out, bias + optional ReLU), multiply in bf16
+size_t gemm_bf16_ws_bytes(int M, int N, int K);  // split-K partials for layers with few tiles
+hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk, float* ws,
+                            size_t ws_bytes, hipStream_t st);
+
 // ---- gemv.hip ------------------------------------------------------------
 int gemv_splits(int K, int N);
 size_t gemv_ws_bytes(int B, int K, int N);
@@ -93,6 +102,7 @@ struct TnParams {
   int H, W, Cin;
   float l2;           // the fix-up adds l2 * wcur (weight-decay gradient); 0: nothing
   const float* wcur;  // same layout as c
+  int bf16;           // multiply on the bf16 MFMA (operands rounded when staged), fp32 accumulate
 };
 size_t gemm_tn_ws_bytes(long M, int P, int Q);
 hipError_t gemm_tn_launch(const TnParams& p, float* ws, hipStream_t st);

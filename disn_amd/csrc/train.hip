@@ -85,25 +85,34 @@ void build_layout(disn_param_layout_t* L) {
 
 int dense_fwd(const float* a1, int lda1, int k1, const float* a2, int lda2, int K, int M,
               const float* bp, const float* bias, int N, int relu, float* out, float* ws,
-              size_t ws_bytes, hipStream_t st) {
+              size_t ws_bytes, hipStream_t st, bool bf = false) {
+  // bf: bp is a pack_bf16_launch image and the multiply runs on the bf16 MFMA
   GemmParams p{};
   p.a1 = a1; p.lda1 = lda1; p.k1 = k1; p.a2 = a2; p.lda2 = lda2;
   p.M = M; p.N = N; p.K = K;
   p.bp = bp; p.bias = bias; p.rows_per_bias = 0;
   p.out = out; p.ldc = N; p.relu = relu;
+  if (bf) {
+    DISN_TRY(gemm_bf16_launch(p, GEMM_DENSE, bp, ws, ws ? ws_bytes : 0, st));
+    return 0;
+  }
   const GemmPlan pl = gemm_plan(M, N, K, ws ? ws_bytes : 0);
   DISN_TRY(gemm_launch(p, GEMM_DENSE, pl, ws, st));
   return 0;
 }
 
 int conv_fwd(const float* in, int B, int H, int W, int Cin, const float* bp, const float* bias, int Cout,
-             int relu, float* out, float* ws, size_t ws_bytes, hipStream_t st) {
+             int relu, float* out, float* ws, size_t ws_bytes, hipStream_t st, bool bf = false) {
   GemmParams p{};
   p.a1 = in;
   p.H = H; p.W = W; p.Cin = Cin;
   p.M = B * H * W; p.N = Cout; p.K = conv_kpad(Cin);
   p.bp = bp; p.bias = bias; p.rows_per_bias = 0;
   p.out = out; p.ldc = Cout; p.relu = relu;
+  if (bf && Cin != 3) {
+    DISN_TRY(gemm_bf16_launch(p, GEMM_CONV3, bp, ws, ws ? ws_bytes : 0, st));
+    return 0;
+  }
   const GemmPlan pl = gemm_plan(p.M, p.N, p.K, ws ? ws_bytes : 0);
   DISN_TRY(gemm_launch(p, Cin == 3 ? GEMM_CONV3_C3 : GEMM_CONV3, pl, ws, st));
   return 0;
@@ -115,6 +124,7 @@ size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 struct BwdWs {
   float *wT, *zero, *gemm_ws, *tn_ws, *red_ws;
   size_t gemm_ws_bytes, total;
+  bool bf16 = false;  // data-gradient GEMMs on the bf16 MFMA (mixed-precision step)
 };
 
 // capacity for: one packed transposed weight (wt_floats), GEMMs with up to max_m rows
@@ -138,12 +148,15 @@ int dense_bwd(const float* a, int lda, int K, const float* w_kn, const float* dz
               float wd, float* da, float* dw, const BwdWs& s, hipStream_t st) {
   TnParams t{};
   t.a = a; t.lda = lda; t.b = dz; t.ldb = N; t.M = M; t.P = K; t.Q = N;
-  t.c = dw; t.ldc = N; t.Cin = 0; t.l2 = wd; t.wcur = w_kn;
+  t.c = dw; t.ldc = N; t.Cin = 0; t.l2 = wd; t.wcur = w_kn; t.bf16 = s.bf16;
   DISN_TRY(gemm_tn_launch(t, s.tn_ws, st));
   if (da) {
-    DISN_TRY(pack_kn_T_launch(w_kn, K, N, s.wT, st));
+    if (s.bf16)
+      DISN_TRY(pack_bf16_launch(w_kn, 1, K, N, s.wT, st));
+    else
+      DISN_TRY(pack_kn_T_launch(w_kn, K, N, s.wT, st));
     DISN_RC(dense_fwd(dz, N, N, nullptr, 0, N, (int)M, s.wT, s.zero, K, 0, da, s.gemm_ws,
-                      s.gemm_ws_bytes, st));
+                      s.gemm_ws_bytes, st, s.bf16));
   }
   return 0;
 }
@@ -163,12 +176,15 @@ int conv_bwd(const float* x, int B, int H, int W, int Cin, const float* w, const
   } else {
     TnParams t{};
     t.a = x; t.lda = Cin; t.b = dz; t.ldb = Cout; t.M = M; t.P = 9 * Cin; t.Q = Cout;
-    t.c = dw; t.ldc = Cout; t.H = H; t.W = W; t.Cin = Cin; t.l2 = wd; t.wcur = w;
+    t.c = dw; t.ldc = Cout; t.H = H; t.W = W; t.Cin = Cin; t.l2 = wd; t.wcur = w; t.bf16 = s.bf16;
     DISN_TRY(gemm_tn_launch(t, s.tn_ws, st));
   }
   if (dx) {
-    DISN_TRY(pack_conv_bwd_launch(w, Cin, Cout, s.wT, st));
-    DISN_RC(conv_fwd(dz, B, H, W, Cout, s.wT, s.zero, Cin, 0, dx, s.gemm_ws, s.gemm_ws_bytes, st));
+    if (s.bf16)
+      DISN_TRY(pack_bf16_launch(w, 2, Cin, Cout, s.wT, st));
+    else
+      DISN_TRY(pack_conv_bwd_launch(w, Cin, Cout, s.wT, st));
+    DISN_RC(conv_fwd(dz, B, H, W, Cout, s.wT, s.zero, Cin, 0, dx, s.gemm_ws, s.gemm_ws_bytes, st, s.bf16));
   }
   return 0;
 }
@@ -195,13 +211,21 @@ size_t train_gemm_ws(int B, long M) {
     const ConvL& L = kConv[i];
     const int rows = B * L.hw * L.hw;
     m = max_sz(m, gemm_plan(rows, L.cout, conv_kpad(L.cin)).ws_bytes);
-    if (i > 0) m = max_sz(m, gemm_plan(rows, L.cin, 9 * L.cout).ws_bytes);
+    if (i > 0) {
+      m = max_sz(m, gemm_plan(rows, L.cin, 9 * L.cout).ws_bytes);
+      m = max_sz(m, gemm_bf16_ws_bytes(rows, L.cout, 9 * L.cin));  // split-K partials of the bf16 path
+      m = max_sz(m, gemm_bf16_ws_bytes(rows, L.cin, 9 * L.cout));
+    }
   }
   const int shapes[9][2] = {{256, 64}, {512, 256}, {512, 512}, {512, 1984}, {256, 512},
                             {64, 256}, {512, 256}, {1472, 512}, {256, 512}};
   for (auto& s : shapes) {
     m = max_sz(m, gemm_plan((int)M, s[0], s[1]).ws_bytes);
-    if (B > 0) m = max_sz(m, gemm_plan((int)(M / B), s[0], s[1]).ws_bytes);
+    m = max_sz(m, gemm_bf16_ws_bytes((int)M, s[0], s[1]));
+    if (B > 0) {
+      m = max_sz(m, gemm_plan((int)(M / B), s[0], s[1]).ws_bytes);
+      m = max_sz(m, gemm_bf16_ws_bytes((int)(M / B), s[0], s[1]));
+    }
   }
   return m;
 }
@@ -266,20 +290,22 @@ int disn_param_layout(disn_param_layout_t* out) {
 size_t disn_dense_backward_workspace_bytes(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0 || K % 64 || N % 64) return 0;
   Bump b(nullptr);
-  const size_t g = max_sz(gemm_plan(M, K, N).ws_bytes, 256);
+  const size_t g = max_sz(max_sz(gemm_plan(M, K, N).ws_bytes, gemm_bf16_ws_bytes(M, K, N)), 256);
   return bwd_layout(b, (size_t)K * N, M, g, colsum_ws_bytes(M, N)).total;
 }
 
 int disn_dense_backward(const float* a, int lda, int K, const float* w_kn, const float* y, float* dy,
-                        int M, int N, float wd, float* da, float* dw, float* db, void* ws,
-                        size_t ws_bytes, void* stream) {
+                        int M, int N, float wd, int compute_bf16, float* da, float* dw, float* db,
+                        void* ws, size_t ws_bytes, void* stream) {
   if (!a || !w_kn || !dy || !dw || !db || !ws || M <= 0 || K <= 0 || N <= 0) return DISN_E_ARG;
   if (K % 64 || N % 64 || lda < K || lda % 4) return DISN_E_SHAPE;
   if (ws_bytes < disn_dense_backward_workspace_bytes(M, K, N)) return DISN_E_WS;
   hipStream_t st = (hipStream_t)stream;
   Bump b(ws);
-  const BwdWs s = bwd_layout(b, (size_t)K * N, M, max_sz(gemm_plan(M, K, N).ws_bytes, 256),
-                             colsum_ws_bytes(M, N));
+  BwdWs s = bwd_layout(b, (size_t)K * N, M,
+                       max_sz(max_sz(gemm_plan(M, K, N).ws_bytes, gemm_bf16_ws_bytes(M, K, N)), 256),
+                       colsum_ws_bytes(M, N));
+  s.bf16 = compute_bf16 != 0;
   DISN_TRY(hipMemsetAsync(s.zero, 0, 4096 * sizeof(float), st));
   DISN_TRY(relu_bwd_colsum_launch(dy, y, M, N, y != nullptr, db, s.red_ws, st));
   return dense_bwd(a, lda, K, w_kn, dy, M, N, wd, da, dw, s, st);
@@ -289,14 +315,16 @@ size_t disn_conv3x3_backward_workspace_bytes(int B, int H, int W, int Cin, int C
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 64 || !(Cin == 3 || Cin % 64 == 0)) return 0;
   Bump b(nullptr);
   const int M = B * H * W;
-  const size_t g = Cin == 3 ? 256 : max_sz(gemm_plan(M, Cin, 9 * Cout).ws_bytes, 256);
+  const size_t g = Cin == 3 ? 256
+                            : max_sz(max_sz(gemm_plan(M, Cin, 9 * Cout).ws_bytes,
+                                            gemm_bf16_ws_bytes(M, Cin, 9 * Cout)), 256);
   if (Cin == 3) b.take((size_t)M * 64);
   return bwd_layout(b, (size_t)9 * (Cin == 3 ? 64 : Cin) * Cout, M, g, colsum_ws_bytes(M, Cout)).total;
 }
 
 int disn_conv3x3_backward(const float* x, int B, int H, int W, int Cin, const float* w_hwio,
-                          const float* y, float* dy, int Cout, float wd, float* dx, float* dw,
-                          float* db, void* ws, size_t ws_bytes, void* stream) {
+                          const float* y, float* dy, int Cout, float wd, int compute_bf16, float* dx,
+                          float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !w_hwio || !dy || !dw || !db || !ws || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
   if (Cout % 64 || !(Cin == 3 || Cin % 64 == 0) || (Cin == 3 && dx)) return DISN_E_SHAPE;
   if (ws_bytes < disn_conv3x3_backward_workspace_bytes(B, H, W, Cin, Cout)) return DISN_E_WS;
@@ -304,8 +332,11 @@ int disn_conv3x3_backward(const float* x, int B, int H, int W, int Cin, const fl
   Bump b(ws);
   const int M = B * H * W;
   float* col = Cin == 3 ? b.take((size_t)M * 64) : nullptr;
-  const size_t g = Cin == 3 ? 256 : max_sz(gemm_plan(M, Cin, 9 * Cout).ws_bytes, 256);
-  const BwdWs s = bwd_layout(b, (size_t)9 * (Cin == 3 ? 64 : Cin) * Cout, M, g, colsum_ws_bytes(M, Cout));
+  const size_t g = Cin == 3 ? 256
+                            : max_sz(max_sz(gemm_plan(M, Cin, 9 * Cout).ws_bytes,
+                                            gemm_bf16_ws_bytes(M, Cin, 9 * Cout)), 256);
+  BwdWs s = bwd_layout(b, (size_t)9 * (Cin == 3 ? 64 : Cin) * Cout, M, g, colsum_ws_bytes(M, Cout));
+  s.bf16 = compute_bf16 != 0 && Cin != 3;
   DISN_TRY(hipMemsetAsync(s.zero, 0, 4096 * sizeof(float), st));
   DISN_TRY(relu_bwd_colsum_launch(dy, y, M, Cout, y != nullptr, db, s.red_ws, st));
   return conv_bwd(x, B, H, W, Cin, w_hwio, dy, Cout, wd, dx, dw, col, s, st);
@@ -364,8 +395,8 @@ size_t disn_train_workspace_bytes(int B, int N) {
 
 int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const float* img,
                     const float* trans_mat, const float* pts, const float* pts_rot, const float* gt, int B,
-                    int N, float wd, float sdf_weight, float mask_weight, float* pred, float* losses,
-                    void* head_ready_event, void* ws, size_t ws_bytes, void* stream) {
+                    int N, float wd, float sdf_weight, float mask_weight, int compute_bf16, float* pred,
+                    float* losses, void* head_ready_event, void* ws, size_t ws_bytes, void* stream) {
   if (!params || !grads || !img || !trans_mat || !pts || !pts_rot || !gt || !pred || !losses || !ws ||
       B <= 0 || N <= 0)
     return DISN_E_ARG;
@@ -381,22 +412,27 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
   auto P = [&](int idx) { return params + L.offset[idx]; };
   auto G = [&](int idx) { return grads + L.offset[idx]; };
   const long M = (long)B * N;
-  const BwdWs& s = t.bw;
+  BwdWs s = t.bw;
+  const bool bf = compute_bf16 != 0;
+  s.bf16 = bf;
   float* gws = s.gemm_ws;
   const size_t gwb = s.gemm_ws_bytes;
 
   // ---------------- forward ----------------
-  for (int i = 0; i < 13; ++i)
-    DISN_TRY(pack_kn_launch(P(2 * i), 9 * kConv[i].cin, kConv[i].cout, conv_kpad(kConv[i].cin),
-                            t.conv_p[i], st));
-  DISN_TRY(pack_kn_launch(P(V_G + 2), 64, 256, 64, t.g_p2, st));
-  DISN_TRY(pack_kn_launch(P(V_G + 4), 256, 512, 256, t.g_p3, st));
-  DISN_TRY(pack_kn_launch(P(V_G + 6), 512, 512, 512, t.g_p4, st));  // rows 0..511: point part
-  DISN_TRY(pack_kn_launch(P(V_G + 8), 512, 256, 512, t.g_p5, st));
-  DISN_TRY(pack_kn_launch(P(V_L + 2), 64, 256, 64, t.l_p2, st));
-  DISN_TRY(pack_kn_launch(P(V_L + 4), 256, 512, 256, t.l_p3, st));
-  DISN_TRY(pack_kn_launch(P(V_L + 6), 1984, 512, 1984, t.l_p4, st));
-  DISN_TRY(pack_kn_launch(P(V_L + 8), 512, 256, 512, t.l_p5, st));
+  // weights in MFMA fragment order (they change every step): fp32, or bf16 in the same storage
+  auto pack = [&](const float* src, int K, int Nc, float* dst) -> hipError_t {
+    return bf ? pack_bf16_launch(src, 0, K, Nc, dst, st) : pack_kn_launch(src, K, Nc, (K + 31) & ~31, dst, st);
+  };
+  DISN_TRY(pack_kn_launch(P(0), 27, 64, 32, t.conv_p[0], st));  // conv1_1 (K = 27) stays on the fp32 path
+  for (int i = 1; i < 13; ++i) DISN_TRY(pack(P(2 * i), 9 * kConv[i].cin, kConv[i].cout, t.conv_p[i]));
+  DISN_TRY(pack(P(V_G + 2), 64, 256, t.g_p2));
+  DISN_TRY(pack(P(V_G + 4), 256, 512, t.g_p3));
+  DISN_TRY(pack(P(V_G + 6), 512, 512, t.g_p4));  // rows 0..511: point part
+  DISN_TRY(pack(P(V_G + 8), 512, 256, t.g_p5));
+  DISN_TRY(pack(P(V_L + 2), 64, 256, t.l_p2));
+  DISN_TRY(pack(P(V_L + 4), 256, 512, t.l_p3));
+  DISN_TRY(pack(P(V_L + 6), 1984, 512, t.l_p4));
+  DISN_TRY(pack(P(V_L + 8), 512, 256, t.l_p5));
   DISN_TRY(hipMemsetAsync(s.zero, 0, 4096 * sizeof(float), st));
   if (ctx) {
     DISN_TRY(hipEventRecord(ctx->ev[0], st));
@@ -418,7 +454,7 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
   const float* x = t.resized;
   for (int i = 0; i < 13; ++i) {
     const ConvL& c = kConv[i];
-    DISN_RC(conv_fwd(x, B, c.hw, c.hw, c.cin, t.conv_p[i], P(2 * i + 1), c.cout, 1, t.act[i], gws, gwb, st));
+    DISN_RC(conv_fwd(x, B, c.hw, c.hw, c.cin, t.conv_p[i], P(2 * i + 1), c.cout, 1, t.act[i], gws, gwb, st, bf));
     x = t.act[i];
     if (c.tap >= 0)
       DISN_TRY(resize_bilinear_launch(t.act[i], B, c.hw, c.hw, c.cout, t.featmap, DISN_IMG_H,
@@ -443,19 +479,19 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
   DISN_TRY(project_launch(pts, trans_mat, B, N, t.xy, st));
   DISN_TRY(gather_launch(t.featmap, t.xy, B, N, t.feat, st));
   DISN_TRY(pt_embed_launch(pts_rot, M, P(V_G), P(V_G + 1), P(V_L), P(V_L + 1), t.g1, t.l1, st));
-  DISN_RC(dense_fwd(t.l1, 64, 64, nullptr, 0, 64, (int)M, t.l_p2, P(V_L + 3), 256, 1, t.l2, gws, gwb, st));
-  DISN_RC(dense_fwd(t.l2, 256, 256, nullptr, 0, 256, (int)M, t.l_p3, P(V_L + 5), 512, 1, t.l3, gws, gwb, st));
-  DISN_RC(dense_fwd(t.l3, 512, 512, t.feat, DISN_FEAT_DIM, 1984, (int)M, t.l_p4, P(V_L + 7), 512, 1, t.l4, gws, gwb, st));
-  DISN_RC(dense_fwd(t.l4, 512, 512, nullptr, 0, 512, (int)M, t.l_p5, P(V_L + 9), 256, 1, t.l5, gws, gwb, st));
-  DISN_RC(dense_fwd(t.g1, 64, 64, nullptr, 0, 64, (int)M, t.g_p2, P(V_G + 3), 256, 1, t.g2, gws, gwb, st));
-  DISN_RC(dense_fwd(t.g2, 256, 256, nullptr, 0, 256, (int)M, t.g_p3, P(V_G + 5), 512, 1, t.g3, gws, gwb, st));
+  DISN_RC(dense_fwd(t.l1, 64, 64, nullptr, 0, 64, (int)M, t.l_p2, P(V_L + 3), 256, 1, t.l2, gws, gwb, st, bf));
+  DISN_RC(dense_fwd(t.l2, 256, 256, nullptr, 0, 256, (int)M, t.l_p3, P(V_L + 5), 512, 1, t.l3, gws, gwb, st, bf));
+  DISN_RC(dense_fwd(t.l3, 512, 512, t.feat, DISN_FEAT_DIM, 1984, (int)M, t.l_p4, P(V_L + 7), 512, 1, t.l4, gws, gwb, st, bf));
+  DISN_RC(dense_fwd(t.l4, 512, 512, nullptr, 0, 512, (int)M, t.l_p5, P(V_L + 9), 256, 1, t.l5, gws, gwb, st, bf));
+  DISN_RC(dense_fwd(t.g1, 64, 64, nullptr, 0, 64, (int)M, t.g_p2, P(V_G + 3), 256, 1, t.g2, gws, gwb, st, bf));
+  DISN_RC(dense_fwd(t.g2, 256, 256, nullptr, 0, 256, (int)M, t.g_p3, P(V_G + 5), 512, 1, t.g3, gws, gwb, st, bf));
   if (ctx) DISN_TRY(hipStreamWaitEvent(st, ctx->ev[2], 0));  // embedding, gbias, regularization
   for (int b = 0; b < B; ++b) {
     const size_t o = (size_t)b * N * 512;
     DISN_RC(dense_fwd(t.g3 + o, 512, 512, nullptr, 0, 512, N, t.g_p4, t.gbias + (size_t)b * 512, 512, 1,
-                      t.g4 + o, gws, gwb, st));
+                      t.g4 + o, gws, gwb, st, bf));
   }
-  DISN_RC(dense_fwd(t.g4, 512, 512, nullptr, 0, 512, (int)M, t.g_p5, P(V_G + 9), 256, 1, t.g5, gws, gwb, st));
+  DISN_RC(dense_fwd(t.g4, 512, 512, nullptr, 0, 512, (int)M, t.g_p5, P(V_G + 9), 256, 1, t.g5, gws, gwb, st, bf));
   DISN_TRY(final_dot_launch(t.g5, t.l5, M, P(V_G + 10), P(V_G + 11), P(V_L + 10), P(V_L + 11), pred,
                             nullptr, nullptr, 1.0f, st));
 

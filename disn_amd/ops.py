@@ -304,7 +304,7 @@ def param_layout() -> _lib.ParamLayout:
 
 
 def dense_backward(a: torch.Tensor, w_kn: torch.Tensor, y: Optional[torch.Tensor], dy: torch.Tensor,
-                   wd: float = 0.0, need_da: bool = True):
+                   wd: float = 0.0, need_da: bool = True, compute_bf16: bool = False):
     """backward of out = act(a @ w + b): -> (da or None, dw, db); dy is masked IN PLACE when y is given"""
     a, w_kn, dy = _chk(a, "a"), _chk(w_kn, "w_kn"), _chk(dy, "dy")
     M, K = a.shape
@@ -316,13 +316,14 @@ def dense_backward(a: torch.Tensor, w_kn: torch.Tensor, y: Optional[torch.Tensor
     ws = _ws(lib().disn_dense_backward_workspace_bytes(M, K, N), dev)
     check("disn_dense_backward", lib().disn_dense_backward(
         a.data_ptr(), K, K, w_kn.data_ptr(), _chk(y, "y").data_ptr() if y is not None else None,
-        dy.data_ptr(), M, N, float(wd), da.data_ptr() if need_da else None, dw.data_ptr(), db.data_ptr(),
+        dy.data_ptr(), M, N, float(wd), int(compute_bf16), da.data_ptr() if need_da else None, dw.data_ptr(),
+        db.data_ptr(),
         ws.data_ptr(), ws.numel(), _stream()))
     return da, dw, db
 
 
 def conv3x3_backward(x: torch.Tensor, w_hwio: torch.Tensor, y: Optional[torch.Tensor], dy: torch.Tensor,
-                     wd: float = 0.0, need_dx: bool = True):
+                     wd: float = 0.0, need_dx: bool = True, compute_bf16: bool = False):
     """backward of a SAME 3x3 conv (+ReLU when y is given): -> (dx or None, dw [3,3,Cin,Cout], db)"""
     x, w_hwio, dy = _chk(x, "x"), _chk(w_hwio, "w_hwio"), _chk(dy, "dy")
     B, H, W, Cin = x.shape
@@ -334,7 +335,8 @@ def conv3x3_backward(x: torch.Tensor, w_hwio: torch.Tensor, y: Optional[torch.Te
     ws = _ws(lib().disn_conv3x3_backward_workspace_bytes(B, H, W, Cin, Cout), dev)
     check("disn_conv3x3_backward", lib().disn_conv3x3_backward(
         x.data_ptr(), B, H, W, Cin, w_hwio.data_ptr(), _chk(y, "y").data_ptr() if y is not None else None,
-        dy.data_ptr(), Cout, float(wd), dx.data_ptr() if need_dx else None, dw.data_ptr(), db.data_ptr(),
+        dy.data_ptr(), Cout, float(wd), int(compute_bf16), dx.data_ptr() if need_dx else None, dw.data_ptr(),
+        db.data_ptr(),
         ws.data_ptr(), ws.numel(), _stream()))
     return dx, dw, db
 
@@ -376,7 +378,8 @@ def gather_backward(dfeat: torch.Tensor, xy: torch.Tensor) -> torch.Tensor:
 def train_step(params: torch.Tensor, grads: torch.Tensor, img: torch.Tensor, trans_mat: torch.Tensor,
                pts: torch.Tensor, pts_rot: torch.Tensor, gt: torch.Tensor, wd: float = 1e-5,
                sdf_weight: float = 10.0, mask_weight: float = 4.0, ws: Optional[torch.Tensor] = None,
-               ctx: Optional[int] = None, head_ready: Optional[torch.cuda.Event] = None):
+               ctx: Optional[int] = None, head_ready: Optional[torch.cuda.Event] = None,
+               compute_bf16: bool = False):
     """forward + get_loss + gradients into `grads`: -> (pred [B,N], losses [5] device tensor).
     ctx: concurrency context (ctx_create); head_ready: a torch.cuda.Event (already recorded once, so
     that its handle exists) recorded when the fc/MLP part of `grads` is final."""
@@ -393,7 +396,7 @@ def train_step(params: torch.Tensor, grads: torch.Tensor, img: torch.Tensor, tra
         ctx, _chk(params, "params").data_ptr(), _chk(grads, "grads").data_ptr(), _chk(img, "img").data_ptr(),
         _chk(trans_mat, "trans_mat").data_ptr(), _chk(pts, "pts").data_ptr(),
         _chk(pts_rot, "pts_rot").data_ptr(), _chk(gt, "gt").data_ptr(), B, N, float(wd),
-        float(sdf_weight), float(mask_weight), pred.data_ptr(), losses.data_ptr(),
+        float(sdf_weight), float(mask_weight), int(bool(compute_bf16)), pred.data_ptr(), losses.data_ptr(),
         head_ready.cuda_event if head_ready is not None else None, ws.data_ptr(), ws.numel(), _stream()))
     return pred, losses
 
@@ -404,3 +407,31 @@ def adam_update(params: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: t
         _chk(params, "params").data_ptr(), _chk(grads, "grads").data_ptr(), _chk(m, "m").data_ptr(),
         _chk(v, "v").data_ptr(), params.numel(), float(lr_t), float(beta1), float(beta2), float(eps),
         float(grad_scale), _stream()))
+
+
+def dense_bf16(a1: torch.Tensor, w_kn: torch.Tensor, bias: torch.Tensor, relu: bool = True,
+               a2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act([a1|a2] @ w_kn + bias) with the multiply in bf16 (raw fp32 weights, packed on the fly)"""
+    a1, w_kn = _chk(a1, "a1"), _chk(w_kn, "w_kn")
+    M, k1 = a1.shape
+    k2 = a2.shape[1] if a2 is not None else 0
+    N = w_kn.shape[1]
+    out = torch.empty((M, N), dtype=torch.float32, device=a1.device)
+    ws = _ws(lib().disn_dense_bf16_workspace_bytes(M, k1 + k2, N), a1.device)
+    check("disn_dense_bf16", lib().disn_dense_bf16(
+        a1.data_ptr(), k1, k1, _chk(a2, "a2").data_ptr() if a2 is not None else None, k2, k2, M,
+        w_kn.data_ptr(), _chk(bias, "bias").data_ptr(), N, int(relu), out.data_ptr(), ws.data_ptr(),
+        ws.numel(), _stream()))
+    return out
+
+
+def conv3x3_bf16(x: torch.Tensor, w_hwio: torch.Tensor, bias: torch.Tensor, relu: bool = True) -> torch.Tensor:
+    x, w_hwio = _chk(x, "x"), _chk(w_hwio, "w_hwio")
+    B, H, W, Cin = x.shape
+    Cout = w_hwio.shape[-1]
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().disn_conv3x3_bf16_workspace_bytes(B, H, W, Cin, Cout), x.device)
+    check("disn_conv3x3_bf16", lib().disn_conv3x3_bf16(
+        x.data_ptr(), B, H, W, Cin, w_hwio.data_ptr(), _chk(bias, "bias").data_ptr(), Cout, int(relu),
+        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return out

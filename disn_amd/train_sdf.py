@@ -73,7 +73,10 @@ class Trainer:
     def __init__(self, store: WeightStore, device="cuda:0", batch_size: int = 20, base_lr: float = 1e-4,
                  decay_step: int = 200000, decay_rate: float = 0.9, wd: float = 1e-5,
                  sdf_weight: float = 10.0, mask_weight: float = 4.0, beta1: float = 0.5,
-                 beta2: float = 0.999, eps: float = 1e-8, process_group=None):
+                 beta2: float = 0.999, eps: float = 1e-8, process_group=None, compute_bf16: bool = False):
+        # compute_bf16: mixed precision (bf16 multiply, fp32 accumulate / master / optimizer) for the
+        # forward and data-gradient GEMMs; False = the reference's fp32 everywhere
+        self.compute_bf16 = bool(compute_bf16)
         self.flat = FlatParams(torch.device(device))
         self.params = self.flat.from_store(store)
         self.grads = self.flat.zeros()
@@ -118,7 +121,8 @@ class Trainer:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.params.device)
         out = ops.train_step(self.params, self.grads, feed["imgs"], feed["trans_mat"], feed["sample_pc"],
                              feed["sample_pc_rot"], feed["sdf"], self.wd, self.sdf_weight,
-                             self.mask_weight, ws=self._ws, ctx=self.ctx, head_ready=self.head_ready)
+                             self.mask_weight, ws=self._ws, ctx=self.ctx, head_ready=self.head_ready,
+                             compute_bf16=self.compute_bf16)
         self.reducer.start_head(self.grads, self.head_ready)
         return out
 

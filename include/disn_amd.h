@@ -277,6 +277,11 @@ int disn_param_layout(disn_param_layout_t* out);
  * gt [B,N] = the fed 'sdf' (sdf_val - 0.003, train/train_sdf.py:375).
  * pred [B,N] = pred_sdf (un-divided).  losses: 5 device floats =
  * {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}.
+ * compute_bf16: 0 = every product on the exact fp32 MFMA (the reference's precision); 1 = mixed
+ *   precision as BASELINE config 5 names it: the forward and data-gradient GEMMs of the convolutions
+ *   (conv1_1 excepted) and of the point MLPs multiply in bf16 with fp32 accumulation; parameters,
+ *   activations, gradients and the optimizer stay fp32 ("fp32 master"); weight gradients stay on
+ *   the fp32 MFMA.
  * ctx (may be NULL): the HBM-bound side work (weight-norm sum, fc6-fc8 forward and backward) runs on
  *   the context's auxiliary stream under the MFMA-bound GEMMs; the caller still sees one
  *   asynchronous operation on `stream`.
@@ -288,8 +293,8 @@ int disn_param_layout(disn_param_layout_t* out);
 size_t disn_train_workspace_bytes(int B, int N);
 int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const float* img,
                     const float* trans_mat, const float* pts, const float* pts_rot, const float* gt, int B,
-                    int N, float wd, float sdf_weight, float mask_weight, float* pred, float* losses,
-                    void* head_ready_event, void* ws, size_t ws_bytes, void* stream);
+                    int N, float wd, float sdf_weight, float mask_weight, int compute_bf16, float* pred,
+                    float* losses, void* head_ready_event, void* ws, size_t ws_bytes, void* stream);
 
 /* tf.train.AdamOptimizer update (train/train_sdf.py:251) on n floats (n % 4 == 0):
  * g = grads*grad_scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
@@ -303,15 +308,29 @@ int disn_adam_update(float* params, const float* grads, float* m, float* v, int6
  *   pre-activation gradient first.  Outputs db [N], dw [K][N] (+ wd*w), da [M][K] (NULL: skipped).
  *   a [M][lda] (first K columns), w_kn raw [K][N]; K, N multiples of 64.
  * disn_conv3x3_backward: same for a SAME 3x3 conv, x [B,H,W,Cin], w_hwio [3,3,Cin,Cout],
- *   Cin == 3 (dx must be NULL) or a multiple of 64, Cout a multiple of 64. */
+ *   Cin == 3 (dx must be NULL) or a multiple of 64, Cout a multiple of 64.
+ * compute_bf16 != 0: both GEMMs of the block multiply in bf16 (fp32 accumulate), as in the
+ *   mixed-precision step (ignored for Cin == 3). */
 size_t disn_dense_backward_workspace_bytes(int M, int K, int N);
 int disn_dense_backward(const float* a, int lda, int K, const float* w_kn, const float* y, float* dy,
-                        int M, int N, float wd, float* da, float* dw, float* db, void* ws,
-                        size_t ws_bytes, void* stream);
+                        int M, int N, float wd, int compute_bf16, float* da, float* dw, float* db,
+                        void* ws, size_t ws_bytes, void* stream);
 size_t disn_conv3x3_backward_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int disn_conv3x3_backward(const float* x, int B, int H, int W, int Cin, const float* w_hwio,
-                          const float* y, float* dy, int Cout, float wd, float* dx, float* dw,
-                          float* db, void* ws, size_t ws_bytes, void* stream);
+                          const float* y, float* dy, int Cout, float wd, int compute_bf16, float* dx,
+                          float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
+/* bf16-compute forms of disn_dense / disn_conv3x3 used by the mixed-precision training step
+ * (fp32 tensors in HBM, operands rounded to bf16 when staged, fp32 accumulate, fp32 out;
+ * v_mfma_f32_32x32x16_bf16).  They take the RAW TF weights ([K][N] / [3,3,Cin,Cout]) and pack them
+ * into `ws`.  k1, k2, Cin multiples of 32; N, Cout multiples of 64. */
+size_t disn_dense_bf16_workspace_bytes(int M, int K, int N);
+int disn_dense_bf16(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, int M,
+                    const float* w_kn, const float* bias, int N, int relu, float* out, void* ws,
+                    size_t ws_bytes, void* stream);
+size_t disn_conv3x3_bf16_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int disn_conv3x3_bf16(const float* in, int B, int H, int W, int Cin, const float* w_hwio,
+                      const float* bias, int Cout, int relu, float* out, void* ws, size_t ws_bytes,
+                      void* stream);
 /* dx [B,H,W,C]: dy routed to the first maximum of each 2x2 window of x, zero elsewhere (H, W even) */
 int disn_maxpool2x2_backward(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
                              void* stream);

@@ -1,0 +1,151 @@
+"""bf16-compute GEMM / convolution of the mixed-precision training step.  The kernel rounds both
+operands to bf16 (nearest-even) and accumulates in fp32: against a float64 product of the SAME
+bf16-rounded operands only the fp32 accumulation order remains (2e-6 of the output scale)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fnn
+
+from conftest import report_close
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from disn_amd import ops as _ops
+    return _ops
+
+
+def test_fragment_layout_identity_times_asymmetric(ops):
+    """A = I picks rows of an asymmetric B: catches a transposed or permuted fragment mapping"""
+    K = N = 128
+    a = np.eye(K, dtype=np.float32)
+    w = (np.arange(K)[:, None] * 3 + np.arange(N)[None, :] * 0.5 + 1).astype(np.float32)   # exact in bf16? not all
+    w = bf16_round(w).astype(np.float32)
+    got = ops.dense_bf16(dev(a), dev(w), dev(np.zeros(N)), relu=False).cpu().numpy()
+    assert np.array_equal(got, w)
+
+
+@pytest.mark.parametrize("M,k1,k2,N,relu", [(1000, 64, 0, 256, True), (4096, 512, 0, 512, True),
+                                            (777, 512, 1472, 512, True), (70000, 256, 0, 512, False),
+                                            (33, 512, 0, 64, True), (16384, 512, 1472, 512, True)])
+def test_dense_bf16(ops, M, k1, k2, N, relu):
+    rng = np.random.default_rng(M + k1 + N)
+    a1 = rng.standard_normal((M, k1)).astype(np.float32)
+    a2 = rng.standard_normal((M, k2)).astype(np.float32) if k2 else None
+    w = (rng.standard_normal((k1 + k2, N)) / math.sqrt(k1 + k2)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    a = np.concatenate([a1, a2], 1) if k2 else a1
+    ref = bf16_round(a) @ bf16_round(w) + b.astype(np.float64)
+    if relu:
+        ref = np.maximum(ref, 0)
+    got = ops.dense_bf16(dev(a1), dev(w), dev(b), relu, dev(a2) if k2 else None).cpu().numpy()
+    report_close("dense_bf16", got, ref, atol=2e-6 * np.abs(ref).max(), rtol=2e-6)
+    # and the distance to the un-rounded product is what bf16 operands cost: ~2^-9 relative per term
+    full = a.astype(np.float64) @ w.astype(np.float64) + b
+    if relu:
+        full = np.maximum(full, 0)
+    assert np.abs(got - full).max() < 3e-2 * np.abs(full).max()
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 64, 256), (4096, 512, 512), (777, 1472, 512), (20000, 512, 256)])
+def test_dense_backward_bf16(ops, M, K, N):
+    rng = np.random.default_rng(M + K + N)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / math.sqrt(K)).astype(np.float32)
+    y = np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32)      # the saved activations: the mask
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    wd = 1e-3
+    dz = np.where(y > 0, dy, 0).astype(np.float32)
+    ref_da = bf16_round(dz) @ bf16_round(w).T
+    ref_dw = bf16_round(a).T @ bf16_round(dz) + wd * w.astype(np.float64)
+    da, dw, db = ops.dense_backward(dev(a), dev(w), dev(y), dev(dy), wd=wd, compute_bf16=True)
+    report_close("da", da.cpu().numpy(), ref_da, atol=2e-6 * np.abs(ref_da).max())
+    report_close("dw", dw.cpu().numpy(), ref_dw, atol=2e-6 * np.abs(ref_dw).max())
+    report_close("db", db.cpu().numpy(), dz.astype(np.float64).sum(0), atol=2e-6 * np.abs(dz.sum(0)).max())
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 64, 128), (1, 28, 128, 64), (2, 56, 64, 64), (8, 14, 512, 512)])
+def test_conv3x3_backward_bf16(ops, B, H, Cin, Cout):
+    rng = np.random.default_rng(B * 1000 + H + Cin)
+    x = rng.standard_normal((B, H, H, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / math.sqrt(9 * Cin)).astype(np.float32)
+    y = np.maximum(rng.standard_normal((B, H, H, Cout)), 0).astype(np.float32)
+    dy = rng.standard_normal((B, H, H, Cout)).astype(np.float32)
+    wd = 1e-3
+    dz = np.where(y > 0, dy, 0).astype(np.float32)
+    # the two gradients are linear in their operands: autograd on the bf16-rounded copies
+    xt = torch.tensor(bf16_round(x), requires_grad=True)
+    wt = torch.tensor(bf16_round(w), requires_grad=True)
+    out = Fnn.conv2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), None, padding=1).permute(0, 2, 3, 1)
+    (out * torch.tensor(bf16_round(dz))).sum().backward()
+    dx, dw, db = ops.conv3x3_backward(dev(x), dev(w), dev(y), dev(dy), wd=wd, compute_bf16=True)
+    report_close("dx", dx.cpu().numpy(), xt.grad.numpy(), atol=2e-6 * np.abs(xt.grad.numpy()).max())
+    ref_dw = wt.grad.numpy() + wd * w.astype(np.float64)
+    report_close("dw", dw.cpu().numpy(), ref_dw, atol=2e-6 * np.abs(ref_dw).max())
+
+
+def test_mixed_precision_step_tracks_the_fp32_step():
+    """same parameters, same batch: the bf16-compute step against the fp32 step.  bf16 operands carry
+    2^-9 relative rounding per factor; through 13 + 6 layers the prediction moves by ~1e-2 of its
+    scale and every gradient stays aligned with its fp32 counterpart (cosine > 0.9; measured 0.95 for
+    conv1_1, the end of the longest back-propagation chain, 0.99+ for the MLPs and the fc layers)."""
+    from oracle import disn_oracle as O
+    from disn_amd.train_sdf import LOSS_NAMES, Trainer
+    from disn_amd.weights import WeightStore
+    B, N = 2, 512
+    store = WeightStore(O.init_weights(3, "he"))
+    feed_np = O.synth_inputs(seed=21, batch=B, n_points=N)
+    rng = np.random.default_rng(22)
+    feed_np["sdf"] = (0.05 * rng.standard_normal((B, N, 1))).astype(np.float32)
+    feed = {k: dev(feed_np[k]) for k in ("imgs", "trans_mat", "sample_pc", "sample_pc_rot", "sdf")}
+    a = Trainer(store, batch_size=B)
+    b = Trainer(store, batch_size=B, compute_bf16=True)
+    pa, la = a.forward_backward(feed)
+    pb, lb = b.forward_backward(feed)
+    torch.cuda.synchronize()
+    scale = float(pa.abs().max())
+    assert float((pa - pb).abs().max()) < 3e-2 * scale, (float((pa - pb).abs().max()), scale)
+    la, lb = la.cpu().numpy(), lb.cpu().numpy()
+    assert abs(lb[2] - la[2]) < 2e-2 * abs(la[2]) and lb[3] == la[3], (la, lb)   # sdf_loss close, weight norm identical
+    ga, gb = a.flat.to_arrays(a.grads), b.flat.to_arrays(b.grads)
+    cos = {}
+    for name in ga:
+        x, y = ga[name].ravel().astype(np.float64), gb[name].ravel().astype(np.float64)
+        cos[name] = float(x @ y / max(np.linalg.norm(x) * np.linalg.norm(y), 1e-30))
+    worst = sorted(cos.items(), key=lambda kv: kv[1])[:5]
+    print("lowest gradient cosines bf16 vs fp32:", worst)
+    assert worst[0][1] > 0.9, worst
+    # and it trains
+    first = None
+    for _ in range(10):
+        _, losses, _ = b.step(feed)
+        first = float(losses["sdf_loss"]) if first is None else first
+    assert float(losses["sdf_loss"]) < 0.8 * first
+    assert set(losses) == set(LOSS_NAMES)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 64, 128), (1, 28, 128, 64), (2, 56, 64, 64), (2, 14, 512, 512),
+                                          (8, 28, 256, 512), (1, 37, 32, 64)])
+def test_conv3x3_bf16(ops, B, H, Cin, Cout):
+    rng = np.random.default_rng(B * 100 + H + Cin)
+    x = rng.standard_normal((B, H, H, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / math.sqrt(9 * Cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    xt = torch.from_numpy(bf16_round(x)).permute(0, 3, 1, 2)
+    wt = torch.from_numpy(bf16_round(w)).permute(3, 2, 0, 1)
+    ref = torch.relu(Fnn.conv2d(xt, wt, torch.from_numpy(b.astype(np.float64)), padding=1)).permute(0, 2, 3, 1).numpy()
+    got = ops.conv3x3_bf16(dev(x), dev(w), dev(b), True).cpu().numpy()
+    report_close("conv3x3_bf16", got, ref, atol=2e-6 * np.abs(ref).max(), rtol=2e-6)
