@@ -74,6 +74,82 @@ hipError_t pack_bf16_launch(const float* w, int view, int K, int N, void* packed
   return hipGetLastError();
 }
 
+// All the weight re-packs of one training step in ONE launch (41 of them, 5-7 us each as separate
+// launches): a job list in the kernel arguments, one grid-stride loop over the concatenated element
+// space.  T = 8: bf16 fragment order (above); T = 4: the fp32 order of disn_pack_kn.
+// A "slot" = one lane of one fragment block = T consecutive output elements (16 bytes); slots of all
+// jobs are concatenated (begin counts slots); a workgroup covers 1024 consecutive slots (4 per
+// thread), finds its first job once, and a thread only steps forward over job borders.
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
+  __shared__ int s_job;
+  const long base = (long)blockIdx.x * 1024;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = jobs.n - 1;  // last job with begin <= base
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs.j[mid].begin <= base) lo = mid; else hi = mid - 1;
+    }
+    s_job = lo;
+  }
+  __syncthreads();
+  int ji = s_job;
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const long g = base + k * 256 + threadIdx.x;
+    if (g >= jobs.total) return;
+    while (ji + 1 < jobs.n && jobs.j[ji + 1].begin <= g) ++ji;
+    const PackJob& J = jobs.j[ji];
+    const long slot = g - J.begin;
+    const int T = J.T, lane = (int)(slot & 63);
+    const long blk = slot >> 6;
+    const int cb32 = J.C >> 5;
+    const int rb = (int)(blk / cb32), cb = (int)(blk - (long)rb * cb32);
+    const int r0 = rb * 2 * T + T * (lane >> 5);
+    const int c = cb * 32 + (lane & 31);
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int r = r0 + t;
+      v[t] = 0.f;
+      if (t < T && r < J.R) {
+        if (J.view == 0) {
+          v[t] = J.src[(size_t)r * J.N + c];
+        } else if (J.view == 1) {
+          v[t] = J.src[(size_t)c * J.N + r];
+        } else {
+          const int tp = r / J.N, co = r - tp * J.N;
+          v[t] = J.src[((size_t)(8 - tp) * J.K + c) * J.N + co];
+        }
+      }
+    }
+    if (T == 8) {
+      bf16x8 o;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) o[t] = (__bf16)v[t];
+      reinterpret_cast<bf16x8*>(J.dst)[slot] = o;
+    } else {
+      reinterpret_cast<float4*>(J.dst)[slot] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+void pack_job_add(PackJobs& jobs, const float* src, void* dst, int view, int K, int N, bool bf16) {
+  PackJob& J = jobs.j[jobs.n++];
+  J.src = src; J.dst = dst; J.view = view; J.K = K; J.N = N; J.T = bf16 ? 8 : 4;
+  if (view == 0) { J.R = K; J.C = N; }
+  else if (view == 1) { J.R = N; J.C = K; }
+  else { J.R = 9 * N; J.C = K; }
+  J.begin = jobs.total;  // in slots of T elements
+  jobs.total += (long)((J.R + 31) & ~31) * J.C / J.T;
+}
+
+hipError_t pack_multi_launch(const PackJobs& jobs, hipStream_t st) {
+  if (jobs.n == 0) return hipSuccess;
+  const long blocks = (jobs.total + 1023) / 1024;
+  hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, jobs);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 struct BfDev {
   GemmParams p;  // p.bp unused; p.K = padded reduction length (multiple of 32)
@@ -276,7 +352,9 @@ hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk,
   d.bpk = reinterpret_cast<const __bf16*>(bpk);
   d.S = 1;
   d.ws = ws;
-  // 128x128 when that still gives every CU two tiles; otherwise the small tile (+ split-K)
+  // 128x128 when that still gives every CU two tiles; otherwise the small tile (+ split-K).
+  // Measured at the B = 8 training shapes: 128x128 with 256..511 tiles and a 128x64 tile for the
+  // 64-channel layers are both SLOWER than 64x64 (2.33 vs 2.13 ms over the 24 conv launches).
   const long t128 = (long)((p.M + 127) / 128) * (p.N / 128);
   if (p.N % 128 == 0 && t128 >= 512) {
     d.mtiles = (p.M + 127) / 128; d.ntiles = p.N / 128;

@@ -145,17 +145,22 @@ BwdWs bwd_layout(Bump& b, size_t wt_floats, long max_m, size_t gemm_ws_bytes, si
 // (already ReLU-masked); computes dW [K][N] (+ wd W) with a [M][lda] (K columns), and, when da != null,
 // dA [M][K] = dz W^T.  W raw [K][N].
 int dense_bwd(const float* a, int lda, int K, const float* w_kn, const float* dz, long M, int N,
-              float wd, float* da, float* dw, const BwdWs& s, hipStream_t st) {
+              float wd, float* da, float* dw, const BwdWs& s, hipStream_t st,
+              const float* prepacked = nullptr) {
   TnParams t{};
   t.a = a; t.lda = lda; t.b = dz; t.ldb = N; t.M = M; t.P = K; t.Q = N;
   t.c = dw; t.ldc = N; t.Cin = 0; t.l2 = wd; t.wcur = w_kn; t.bf16 = s.bf16;
   DISN_TRY(gemm_tn_launch(t, s.tn_ws, st));
   if (da) {
-    if (s.bf16)
-      DISN_TRY(pack_bf16_launch(w_kn, 1, K, N, s.wT, st));
-    else
-      DISN_TRY(pack_kn_T_launch(w_kn, K, N, s.wT, st));
-    DISN_RC(dense_fwd(dz, N, N, nullptr, 0, N, (int)M, s.wT, s.zero, K, 0, da, s.gemm_ws,
+    const float* wt = prepacked;  // W^T in fragment order: packed at the start of the step, or here
+    if (!wt) {
+      if (s.bf16)
+        DISN_TRY(pack_bf16_launch(w_kn, 1, K, N, s.wT, st));
+      else
+        DISN_TRY(pack_kn_T_launch(w_kn, K, N, s.wT, st));
+      wt = s.wT;
+    }
+    DISN_RC(dense_fwd(dz, N, N, nullptr, 0, N, (int)M, wt, s.zero, K, 0, da, s.gemm_ws,
                       s.gemm_ws_bytes, st, s.bf16));
   }
   return 0;
@@ -164,7 +169,8 @@ int dense_bwd(const float* a, int lda, int K, const float* w_kn, const float* dz
 // 3x3 conv backward; dz [B,H,W,Cout] already ReLU-masked; x [B,H,W,Cin]; w raw [3,3,Cin,Cout]
 // col: [B*H*W][64] scratch, only for Cin == 3
 int conv_bwd(const float* x, int B, int H, int W, int Cin, const float* w, const float* dz, int Cout,
-             float wd, float* dx, float* dw, float* col, const BwdWs& s, hipStream_t st) {
+             float wd, float* dx, float* dw, float* col, const BwdWs& s, hipStream_t st,
+             const float* prepacked = nullptr) {
   const long M = (long)B * H * W;
   if (Cin == 3) {
     DISN_TRY(im2col_c3_launch(x, B, H, W, col, st));
@@ -180,11 +186,15 @@ int conv_bwd(const float* x, int B, int H, int W, int Cin, const float* w, const
     DISN_TRY(gemm_tn_launch(t, s.tn_ws, st));
   }
   if (dx) {
-    if (s.bf16)
-      DISN_TRY(pack_bf16_launch(w, 2, Cin, Cout, s.wT, st));
-    else
-      DISN_TRY(pack_conv_bwd_launch(w, Cin, Cout, s.wT, st));
-    DISN_RC(conv_fwd(dz, B, H, W, Cout, s.wT, s.zero, Cin, 0, dx, s.gemm_ws, s.gemm_ws_bytes, st, s.bf16));
+    const float* wt = prepacked;
+    if (!wt) {
+      if (s.bf16)
+        DISN_TRY(pack_bf16_launch(w, 2, Cin, Cout, s.wT, st));
+      else
+        DISN_TRY(pack_conv_bwd_launch(w, Cin, Cout, s.wT, st));
+      wt = s.wT;
+    }
+    DISN_RC(conv_fwd(dz, B, H, W, Cout, wt, s.zero, Cin, 0, dx, s.gemm_ws, s.gemm_ws_bytes, st, s.bf16));
   }
   return 0;
 }
@@ -194,6 +204,9 @@ struct TrainWs {
   // packed forward weights
   float* conv_p[13];
   float *g_p2, *g_p3, *g_p4, *g_p5, *l_p2, *l_p3, *l_p4, *l_p5;
+  // packed weights of the data-gradient GEMMs (flipped conv kernels, transposed MLP weights)
+  float* conv_bT[13];
+  float *g_t2, *g_t3, *g_t4, *g_t5, *l_t2, *l_t3, *l_t4, *l_t4f, *l_t5;
   // activations
   float *resized, *act[13], *pooled[13], *h6, *h7, *emb, *gbias, *featmap, *xy, *feat;
   float *g1, *l1, *g2, *l2, *g3, *l3, *g4, *l4, *g5, *l5;
@@ -237,6 +250,11 @@ TrainWs train_layout(void* ws, int B, int N) {
   for (int i = 0; i < 13; ++i) t.conv_p[i] = b.take((size_t)conv_kpad(kConv[i].cin) * kConv[i].cout);
   t.g_p2 = b.take(64 * 256); t.g_p3 = b.take(256 * 512); t.g_p4 = b.take(512 * 512); t.g_p5 = b.take(512 * 256);
   t.l_p2 = b.take(64 * 256); t.l_p3 = b.take(256 * 512); t.l_p4 = b.take(1984 * 512); t.l_p5 = b.take(512 * 256);
+  t.conv_bT[0] = nullptr;
+  for (int i = 1; i < 13; ++i) t.conv_bT[i] = b.take((size_t)9 * kConv[i].cin * kConv[i].cout);
+  t.g_t2 = b.take(64 * 256); t.g_t3 = b.take(256 * 512); t.g_t4 = b.take(512 * 512); t.g_t5 = b.take(512 * 256);
+  t.l_t2 = b.take(64 * 256); t.l_t3 = b.take(256 * 512); t.l_t4 = b.take(512 * 512);
+  t.l_t4f = b.take(1472 * 512); t.l_t5 = b.take(512 * 256);
   t.resized = b.take((size_t)B * 224 * 224 * 3);
   for (int i = 0; i < 13; ++i) {
     const ConvL& L = kConv[i];
@@ -269,7 +287,10 @@ TrainWs train_layout(void* ws, int B, int N) {
   t.fc_ws = b.take(fws / sizeof(float) + 1);
   t.sumsq_ws = b.take(32 * 256);
   t.red_aux = b.take(colsum_ws_bytes(B, 4096) / sizeof(float) + 1);
-  size_t red = max_sz(colsum_ws_bytes((long)B * 224 * 224, 64), colsum_ws_bytes(M, 512));
+  size_t red = colsum_ws_bytes(M, 512);
+  for (int i = 0; i < 13; ++i)  // bias-gradient partials of every conv layer (chunks x Cout)
+    red = max_sz(red, colsum_ws_bytes((long)B * kConv[i].hw * kConv[i].hw, kConv[i].cout));
+  red = max_sz(red, colsum_ws_bytes(B, 4096));
   red = max_sz(red, max_sz(final_bwd_ws_bytes(M), colsum_ws_bytes(M, DISN_FEAT_DIM)));
   t.bw = bwd_layout(b, (size_t)9 * 512 * 512, M, train_gemm_ws(B, M), red);
   t.total = (b.off + 255) & ~size_t(255);
@@ -420,19 +441,35 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
 
   // ---------------- forward ----------------
   // weights in MFMA fragment order (they change every step): fp32, or bf16 in the same storage
-  auto pack = [&](const float* src, int K, int Nc, float* dst) -> hipError_t {
-    return bf ? pack_bf16_launch(src, 0, K, Nc, dst, st) : pack_kn_launch(src, K, Nc, (K + 31) & ~31, dst, st);
-  };
-  DISN_TRY(pack_kn_launch(P(0), 27, 64, 32, t.conv_p[0], st));  // conv1_1 (K = 27) stays on the fp32 path
-  for (int i = 1; i < 13; ++i) DISN_TRY(pack(P(2 * i), 9 * kConv[i].cin, kConv[i].cout, t.conv_p[i]));
-  DISN_TRY(pack(P(V_G + 2), 64, 256, t.g_p2));
-  DISN_TRY(pack(P(V_G + 4), 256, 512, t.g_p3));
-  DISN_TRY(pack(P(V_G + 6), 512, 512, t.g_p4));  // rows 0..511: point part
-  DISN_TRY(pack(P(V_G + 8), 512, 256, t.g_p5));
-  DISN_TRY(pack(P(V_L + 2), 64, 256, t.l_p2));
-  DISN_TRY(pack(P(V_L + 4), 256, 512, t.l_p3));
-  DISN_TRY(pack(P(V_L + 6), 1984, 512, t.l_p4));
-  DISN_TRY(pack(P(V_L + 8), 512, 256, t.l_p5));
+  // all 41 re-packs (forward + data-gradient views) in one launch
+  {
+    PackJobs jobs{};
+    pack_job_add(jobs, P(0), t.conv_p[0], 0, 27, 64, false);  // conv1_1 (K = 27) stays on the fp32 path
+    for (int i = 1; i < 13; ++i) {
+      pack_job_add(jobs, P(2 * i), t.conv_p[i], 0, 9 * kConv[i].cin, kConv[i].cout, bf);
+      pack_job_add(jobs, P(2 * i), t.conv_bT[i], 2, kConv[i].cin, kConv[i].cout, bf);
+    }
+    const float* gw4 = P(V_G + 6);  // rows 0..511 point part, 512..1535 global part
+    const float* lw4 = P(V_L + 6);  // rows 0..511 point part, 512..1983 image-feature part
+    pack_job_add(jobs, P(V_G + 2), t.g_p2, 0, 64, 256, bf);
+    pack_job_add(jobs, P(V_G + 4), t.g_p3, 0, 256, 512, bf);
+    pack_job_add(jobs, gw4, t.g_p4, 0, 512, 512, bf);
+    pack_job_add(jobs, P(V_G + 8), t.g_p5, 0, 512, 256, bf);
+    pack_job_add(jobs, P(V_L + 2), t.l_p2, 0, 64, 256, bf);
+    pack_job_add(jobs, P(V_L + 4), t.l_p3, 0, 256, 512, bf);
+    pack_job_add(jobs, lw4, t.l_p4, 0, 1984, 512, bf);
+    pack_job_add(jobs, P(V_L + 8), t.l_p5, 0, 512, 256, bf);
+    pack_job_add(jobs, P(V_G + 2), t.g_t2, 1, 64, 256, bf);
+    pack_job_add(jobs, P(V_G + 4), t.g_t3, 1, 256, 512, bf);
+    pack_job_add(jobs, gw4, t.g_t4, 1, 512, 512, bf);
+    pack_job_add(jobs, P(V_G + 8), t.g_t5, 1, 512, 256, bf);
+    pack_job_add(jobs, P(V_L + 2), t.l_t2, 1, 64, 256, bf);
+    pack_job_add(jobs, P(V_L + 4), t.l_t3, 1, 256, 512, bf);
+    pack_job_add(jobs, lw4, t.l_t4, 1, 512, 512, bf);
+    pack_job_add(jobs, lw4 + (size_t)512 * 512, t.l_t4f, 1, 1472, 512, bf);
+    pack_job_add(jobs, P(V_L + 8), t.l_t5, 1, 512, 256, bf);
+    DISN_TRY(pack_multi_launch(jobs, st));
+  }
   DISN_TRY(hipMemsetAsync(s.zero, 0, 4096 * sizeof(float), st));
   if (ctx) {
     DISN_TRY(hipEventRecord(ctx->ev[0], st));
@@ -509,14 +546,14 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
     DISN_TRY(final_bwd_launch(h5, t.dpred, M, P(V + 10), t.d5, G(V + 10), G(V + 11), G(V + 9), wd,
                               s.red_ws, st));
     // fold2/conv2 (512 -> 256)
-    DISN_RC(dense_bwd(h4, 512, 512, P(V + 8), t.d5, M, 256, wd, t.d4, G(V + 8), s, st));
+    DISN_RC(dense_bwd(h4, 512, 512, P(V + 8), t.d5, M, 256, wd, t.d4, G(V + 8), s, st, loc ? t.l_t5 : t.g_t5));
     DISN_TRY(relu_bwd_colsum_launch(t.d4, h4, M, 512, 1, G(V + 7), s.red_ws, st));
     // fold2/conv1: rows 0..511 of W multiply the point feature, the rest the image feature
-    DISN_RC(dense_bwd(h3, 512, 512, P(V + 6), t.d4, M, 512, wd, t.d3, G(V + 6), s, st));
+    DISN_RC(dense_bwd(h3, 512, 512, P(V + 6), t.d4, M, 512, wd, t.d3, G(V + 6), s, st, loc ? t.l_t4 : t.g_t4));
     if (loc) {
       const float* wf = P(V + 6) + (size_t)512 * 512;
       DISN_RC(dense_bwd(t.feat, DISN_FEAT_DIM, DISN_FEAT_DIM, wf, t.d4, M, 512, wd, t.dfeat,
-                        G(V + 6) + (size_t)512 * 512, s, st));
+                        G(V + 6) + (size_t)512 * 512, s, st, t.l_t4f));
     } else {
       const float* wg = P(V + 6) + (size_t)512 * 512;  // [1024][512]
       DISN_TRY(image_colsum_launch(t.d4, B, N, 512, t.dgbias, s.red_ws, st));
@@ -526,9 +563,9 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
     }
     DISN_TRY(relu_bwd_colsum_launch(t.d3, h3, M, 512, 1, G(V + 5), s.red_ws, st));
     // fold1/conv3 (256 -> 512), conv2 (64 -> 256), conv1 (3 -> 64)
-    DISN_RC(dense_bwd(h2, 256, 256, P(V + 4), t.d3, M, 512, wd, t.d2, G(V + 4), s, st));
+    DISN_RC(dense_bwd(h2, 256, 256, P(V + 4), t.d3, M, 512, wd, t.d2, G(V + 4), s, st, loc ? t.l_t3 : t.g_t3));
     DISN_TRY(relu_bwd_colsum_launch(t.d2, h2, M, 256, 1, G(V + 3), s.red_ws, st));
-    DISN_RC(dense_bwd(h1, 64, 64, P(V + 2), t.d2, M, 256, wd, t.d1, G(V + 2), s, st));
+    DISN_RC(dense_bwd(h1, 64, 64, P(V + 2), t.d2, M, 256, wd, t.d1, G(V + 2), s, st, loc ? t.l_t2 : t.g_t2));
     DISN_TRY(relu_bwd_colsum_launch(t.d1, h1, M, 64, 1, G(V + 1), s.red_ws, st));
     DISN_TRY(embed_bwd_launch(pts_rot, t.d1, M, G(V), P(V), wd, s.red_ws, st));
     if (!loc) {
@@ -585,7 +622,8 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
       dx = bufs[which];
       if (dx == dy) dx = bufs[which ^ 1];
     }
-    DISN_RC(conv_bwd(xin, B, c.hw, c.hw, c.cin, P(2 * i), dy, c.cout, wd, dx, G(2 * i), t.col, s, st));
+    DISN_RC(conv_bwd(xin, B, c.hw, c.hw, c.cin, P(2 * i), dy, c.cout, wd, dx, G(2 * i), t.col, s, st,
+                     t.conv_bT[i]));
     if (dx) {
       which = (dx == bufs[0]) ? 1 : 0;
       dcur = dx;
