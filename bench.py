@@ -77,7 +77,8 @@ def train_bench(args, torch, dist, dev, world, rank, launched):
     from disn_amd.train_sdf import Trainer
     from disn_amd.weights import WeightStore
     B = args.train_batch
-    tr = Trainer(WeightStore.random_init(0, mode="he"), dev, batch_size=B * world)
+    bf = args.train_dtype == "bf16"
+    tr = Trainer(WeightStore.random_init(0, mode="he"), dev, batch_size=B * world, compute_bf16=bf)
     feed = train_feed(torch, dev, B, 1000 + rank)
     for _ in range(args.warmup):
         tr.step(feed)
@@ -104,9 +105,11 @@ def train_bench(args, torch, dist, dev, world, rank, launched):
                       "all variables trained, Adam)",
             "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 5 shape in fp32: data-parallel training step, %d samples x %d "
-                                   "points per GPU, random-init (he) weights" % (B, N_POINTS),
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5 shape, %s: data-parallel training step, %d samples x %d "
+                                   "points per GPU, random-init (he) weights" % (
+                                       "bf16 multiply / fp32 accumulate, master weights and optimizer" if bf
+                                       else "fp32 (the reference's precision)", B, N_POINTS),
                        "global_batch": B * world, "points_per_sample": N_POINTS,
                        "parallelism": "dp%d (one sum all-reduce of the flat gradient buffer in two buckets, the "
                                       "fc+MLP bucket under the conv backward)" % world},
@@ -123,6 +126,9 @@ def main():
     ap.add_argument("--workload", choices=("query", "train"), default="query",
                     help="query: BASELINE.json metric (default); train: config-5 training step")
     ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step")
+    ap.add_argument("--train-dtype", choices=("f32", "bf16"), default="f32",
+                    help="--workload train: f32 = the reference's precision; bf16 = mixed precision "
+                         "(bf16 multiply, fp32 accumulate / master weights / optimizer)")
     args = ap.parse_args()
 
     import torch
@@ -304,7 +310,19 @@ def main():
                                   "note": "forward + get_loss + gradient of all 56 variables + TF Adam; "
                                           "python bench.py --workload train [--gpus N] times it as the main line"}
             tr.close()
-            del tr, tfeed
+            del tr
+            torch.cuda.empty_cache()
+            tb = Trainer(WeightStore.random_init(0, mode="he"), dev, batch_size=8, compute_bf16=True)
+            for _ in range(2):
+                tb.step(tfeed)
+            ms_b = ev_time_ms(lambda: tb.step(tfeed), 5, torch)
+            line["train_step"]["mixed_precision"] = {
+                "ms_step": ms_b, "samples_per_s": 8 / ms_b * 1e3, "dtype": "bf16",
+                "note": "bf16 multiply (v_mfma_f32_32x32x16_bf16) with fp32 accumulate in the conv / MLP "
+                        "forward, data-gradient and 128-tile weight-gradient GEMMs; fp32 activations, "
+                        "master weights, gradients and Adam; --workload train --train-dtype bf16"}
+            tb.close()
+            del tb, tfeed
             torch.cuda.empty_cache()
         except Exception as e:  # the north-star line must survive a failure of this leg
             line["train_step"] = {"error": repr(e)}

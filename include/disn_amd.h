@@ -280,8 +280,8 @@ int disn_param_layout(disn_param_layout_t* out);
  * compute_bf16: 0 = every product on the exact fp32 MFMA (the reference's precision); 1 = mixed
  *   precision as BASELINE config 5 names it: the forward and data-gradient GEMMs of the convolutions
  *   (conv1_1 excepted) and of the point MLPs multiply in bf16 with fp32 accumulation; parameters,
- *   activations, gradients and the optimizer stay fp32 ("fp32 master"); weight gradients stay on
- *   the fp32 MFMA.
+ *   activations, gradients and the optimizer stay fp32 ("fp32 master"); weight gradients use bf16
+ *   where the 128x128 tile applies and the fp32 MFMA otherwise.
  * ctx (may be NULL): the HBM-bound side work (weight-norm sum, fc6-fc8 forward and backward) runs on
  *   the context's auxiliary stream under the MFMA-bound GEMMs; the caller still sees one
  *   asynchronous operation on `stream`.
