@@ -13,7 +13,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libdisn_amd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -32,7 +32,8 @@ class DisnError(RuntimeError):
 
 class VggWeights(C.Structure):  # disn_vgg_weights_t
     _fields_ = [("conv_w", C.c_void_p * 13), ("conv_b", C.c_void_p * 13),
-                ("fc_w", C.c_void_p * 3), ("fc_b", C.c_void_p * 3), ("num_classes", C.c_int)]
+                ("fc_w", C.c_void_p * 3), ("fc_b", C.c_void_p * 3), ("num_classes", C.c_int),
+                ("conv_w_x3", C.c_void_p * 13)]   # optional three-term bf16 images (disn_pack_kn_x3)
 
 
 MLP_FIELDS = ("g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3", "g_w4_point", "g_w4_global", "g_b4",
@@ -40,8 +41,11 @@ MLP_FIELDS = ("g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3", "g_w4_point", "g_w
               "l_w4", "l_b4", "l_w5", "l_b5", "l_w6", "l_b6")
 
 
+MLP_X3_FIELDS = ("g_x2", "g_x3", "g_x4_point", "g_x5", "l_x2", "l_x3", "l_x4", "l_x5")   # optional
+
+
 class MlpWeights(C.Structure):  # disn_mlp_weights_t
-    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS]
+    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS + MLP_X3_FIELDS]
 
 
 CAM_FIELDS = tuple("%s_%s%d" % (t, k, i) for t in "srt" for i in (1, 2, 3) for k in "wb")
@@ -63,6 +67,8 @@ I, Z, P, F, L = C.c_int, C.c_size_t, C.c_void_p, C.c_float, C.c_int64
 SIGNATURES = {
     "disn_abi_version": (I, []),
     "disn_pack_kn": (I, [P, I, I, I, P, P]),
+    "disn_pack_kn_x3_bytes": (Z, [I, I]),
+    "disn_pack_kn_x3": (I, [P, I, I, P, P]),
     "disn_resize_bilinear": (I, [P, I, I, I, I, P, I, I, I, I, P]),
     "disn_vgg16_workspace_bytes": (Z, [I]),
     "disn_vgg16_forward": (I, [C.POINTER(VggWeights), P, I, P, C.POINTER(C.c_void_p * 5), P, P, Z, P]),
@@ -92,9 +98,9 @@ SIGNATURES = {
                                 P, Z, P]),
     "disn_crc32c": (C.c_uint32, [P, Z, C.c_uint32]),
     "disn_dense_bf16_workspace_bytes": (Z, [I, I, I]),
-    "disn_dense_bf16": (I, [P, I, I, P, I, I, I, P, P, I, I, P, P, Z, P]),
+    "disn_dense_bf16": (I, [P, I, I, P, I, I, I, P, P, I, I, I, P, P, Z, P]),
     "disn_conv3x3_bf16_workspace_bytes": (Z, [I, I, I, I, I]),
-    "disn_conv3x3_bf16": (I, [P, I, I, I, I, P, P, I, I, P, P, Z, P]),
+    "disn_conv3x3_bf16": (I, [P, I, I, I, I, P, P, I, I, I, P, P, Z, P]),
     "disn_cam_head": (I, [C.POINTER(CamWeights), P, C.POINTER(C.c_float * 9), I, P, P, P, P, P]),
     "disn_param_layout": (I, [C.POINTER(ParamLayout)]),
     "disn_train_workspace_bytes": (Z, [I, I]),

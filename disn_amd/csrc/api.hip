@@ -60,6 +60,10 @@ VggWs vgg_layout(void* ws, int B, int num_classes) {
   for (const VggLayer& L : kVgg) {
     const GemmPlan pl = gemm_plan(B * L.hw * L.hw, L.cout, conv_k(L.cin));
     if (pl.ws_bytes > gws) gws = pl.ws_bytes;
+    if (L.cin != 3) {
+      const size_t bw = gemm_bf16_ws_bytes(B * L.hw * L.hw, L.cout, 9 * L.cin);
+      if (bw > gws) gws = bw;
+    }
   }
   w.gemm_ws = b.take(gws);
   size_t fws = gemv_ws_bytes(B, 25088, 4096);
@@ -73,9 +77,11 @@ VggWs vgg_layout(void* ws, int B, int num_classes) {
   return w;
 }
 
+bool x3_enabled();
+
 int conv3x3_impl(const float* in, int B, int H, int W, int Cin, const float* w_packed,
                  const float* bias, int Cout, int relu, float* out, float* ws, size_t ws_bytes,
-                 hipStream_t st) {
+                 hipStream_t st, const void* x3 = nullptr) {
   if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
   if (!(Cin == 3 || Cin % 32 == 0) || Cout % 64 != 0 || H >= 32768 || W >= 32768)
     return DISN_E_SHAPE;
@@ -85,6 +91,12 @@ int conv3x3_impl(const float* in, int B, int H, int W, int Cin, const float* w_p
   p.M = B * H * W; p.N = Cout; p.K = conv_k(Cin);
   p.bp = w_packed; p.bias = bias; p.rows_per_bias = 0;
   p.out = out; p.ldc = Cout; p.relu = relu;
+  // measured at B = 1 (tools/bf16_time.py, prepacked): the three-term kernel wins on every layer but
+  // 112x112 64->128; at B = 8 on all of them
+  if (x3 && Cin != 3 && x3_enabled() && !(B == 1 && Cin == 64 && Cout == 128)) {
+    DISN_TRY(gemm_bf16_launch(p, GEMM_CONV3, x3, ws, ws ? ws_bytes : 0, st, 3));
+    return 0;
+  }
   const GemmPlan pl = gemm_plan(p.M, p.N, p.K, ws ? ws_bytes : 0);
   DISN_TRY(gemm_launch(p, Cin == 3 ? GEMM_CONV3_C3 : GEMM_CONV3, pl, ws, st));
   return 0;
@@ -111,6 +123,8 @@ size_t mlp_gemm_ws(int n) {
     for (auto& s : shapes) {
       const GemmPlan pl = gemm_plan(r, s[0], s[1]);
       if (pl.ws_bytes > m) m = pl.ws_bytes;
+      const size_t bw = gemm_bf16_ws_bytes(r, s[0], s[1]);  // split-K partials of the 3xBF16 kernel
+      if (bw > m) m = bw;
     }
     if (rows >= n) break;
   }
@@ -138,19 +152,30 @@ MlpWs mlp_layout(Bump& b, int n) {
 bool mlp_weights_ok(const disn_mlp_weights_t* w) {
   if (!w) return false;
   const float* const* p = reinterpret_cast<const float* const*>(w);
-  for (size_t i = 0; i < sizeof(disn_mlp_weights_t) / sizeof(const float*); ++i)
+  for (size_t i = 0; i < 25; ++i)  // g_w1 .. l_b6; the *_x* images that follow are optional
     if (!p[i]) return false;
   return true;
 }
 
+// fp32-accurate products on the bf16 MFMA pipes (three bf16 terms per operand, gemm_bf16_mfma.hip)
+// wherever the caller supplied the 3-plane weight image; DISN_X3=0 forces the f32-input MFMA
+bool x3_enabled() {
+  static const bool v = [] { const char* e = std::getenv("DISN_X3"); return !e || std::atoi(e) != 0; }();
+  return v;
+}
+
 int dense_layer(const float* a1, int lda1, int k1, const float* a2, int lda2, int K, int n,
                 const float* bp, const float* bias, int N, float* out, float* ws, size_t ws_bytes,
-                hipStream_t st) {
+                hipStream_t st, const void* x3 = nullptr) {
   GemmParams p{};
   p.a1 = a1; p.lda1 = lda1; p.k1 = k1; p.a2 = a2; p.lda2 = lda2;
   p.M = n; p.N = N; p.K = K;
   p.bp = bp; p.bias = bias; p.rows_per_bias = 0;
   p.out = out; p.ldc = N; p.relu = 1;
+  if (x3 && x3_enabled()) {
+    DISN_TRY(gemm_bf16_launch(p, GEMM_DENSE, x3, ws, ws ? ws_bytes : 0, st, 3));
+    return 0;
+  }
   const GemmPlan pl = gemm_plan(n, N, K, ws ? ws_bytes : 0);
   DISN_TRY(gemm_launch(p, GEMM_DENSE, pl, ws, st));
   return 0;
@@ -165,18 +190,18 @@ int mlp_phase0(const disn_mlp_weights_t* w, const float* pts_rot, int n, const M
                hipStream_t st) {
   int rc;
   DISN_TRY(pt_embed_launch(pts_rot, n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g, s.e1l, st));
-  if ((rc = dense_layer(s.e1l, 64, 64, nullptr, 0, 64, n, w->l_w2, w->l_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->l_w3, w->l_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.e1g, 64, 64, nullptr, 0, 64, n, w->g_w2, w->g_b2, 256, s.g256, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.g256, 256, 256, nullptr, 0, 256, n, w->g_w3, w->g_b3, 512, s.g512, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.e1l, 64, 64, nullptr, 0, 64, n, w->l_w2, w->l_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st, w->l_x2))) return rc;
+  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->l_w3, w->l_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st, w->l_x3))) return rc;
+  if ((rc = dense_layer(s.e1g, 64, 64, nullptr, 0, 64, n, w->g_w2, w->g_b2, 256, s.g256, s.gemm_ws, s.gemm_ws_bytes, st, w->g_x2))) return rc;
+  if ((rc = dense_layer(s.g256, 256, 256, nullptr, 0, 256, n, w->g_w3, w->g_b3, 512, s.g512, s.gemm_ws, s.gemm_ws_bytes, st, w->g_x3))) return rc;
   return 0;
 }
 
 int mlp_phase1(const disn_mlp_weights_t* w, int n, const float* feat, const MlpWs& s,
                hipStream_t st) {
   int rc;
-  if ((rc = dense_layer(s.h512a, 512, 512, feat, DISN_FEAT_DIM, 512 + DISN_FEAT_DIM, n, w->l_w4, w->l_b4, 512, s.h512b, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
-  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->l_w5, w->l_b5, 256, s.l5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h512a, 512, 512, feat, DISN_FEAT_DIM, 512 + DISN_FEAT_DIM, n, w->l_w4, w->l_b4, 512, s.h512b, s.gemm_ws, s.gemm_ws_bytes, st, w->l_x4))) return rc;
+  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->l_w5, w->l_b5, 256, s.l5, s.gemm_ws, s.gemm_ws_bytes, st, w->l_x5))) return rc;
   return 0;
 }
 
@@ -188,11 +213,11 @@ int mlp_phase2(const disn_mlp_weights_t* w, int B, int N, const float* gbias, fl
     const size_t o = (size_t)b * N;
     if ((rc = dense_layer(s.g512 + o * 512, 512, 512, nullptr, 0, 512, N, w->g_w4_point,
                           gbias + (size_t)b * 512, 512, s.h512b + o * 512, s.gemm_ws,
-                          s.gemm_ws_bytes, st)))
+                          s.gemm_ws_bytes, st, w->g_x4_point)))
       return rc;
   }
   const int n = B * N;
-  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->g_w5, w->g_b5, 256, s.g5, s.gemm_ws, s.gemm_ws_bytes, st))) return rc;
+  if ((rc = dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->g_w5, w->g_b5, 256, s.g5, s.gemm_ws, s.gemm_ws_bytes, st, w->g_x5))) return rc;
   DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, sdf_g, sdf_l,
                             out_div, st));
   return 0;
@@ -244,6 +269,18 @@ bool grid_spec(const double* p, int R, GridSpec* g) {
 extern "C" {
 
 int disn_abi_version(void) { return DISN_ABI_VERSION; }
+
+size_t disn_pack_kn_x3_bytes(int K, int N) {
+  if (K <= 0 || N <= 0 || N % 32) return 0;
+  return (size_t)3 * ((K + 31) & ~31) * N * 2;
+}
+
+int disn_pack_kn_x3(const float* w_kn, int K, int N, void* packed, void* stream) {
+  if (!w_kn || !packed || K <= 0 || N <= 0) return DISN_E_ARG;
+  if (N % 32) return DISN_E_SHAPE;
+  DISN_TRY(pack_bf16_launch(w_kn, 0, K, N, packed, (hipStream_t)stream, 3));
+  return 0;
+}
 
 int disn_pack_kn(const float* w_kn, int K, int N, int Kpad, float* packed, void* stream) {
   if (!w_kn || !packed || K <= 0 || N <= 0) return DISN_E_ARG;
@@ -397,7 +434,7 @@ int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, i
     float* out = L.tap >= 0 ? taps[L.tap] : (L.hw >= 112 ? s.bufA : (toggle ? s.bufB : s.bufA));
     if (L.tap < 0 && L.hw < 112) toggle = !toggle;
     const int rc = conv3x3_impl(x, B, L.hw, L.hw, L.cin, w->conv_w[i], w->conv_b[i], L.cout, 1,
-                                out, s.gemm_ws, gws_cap, st);
+                                out, s.gemm_ws, gws_cap, st, w->conv_w_x3[i]);
     if (rc) return rc;
     x = out;
     if (L.tap >= 0 && featmap) {

@@ -19,6 +19,8 @@
 // 128x128x32 moves 32 KB per 256 MFMA cycles).
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace disn {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -34,7 +36,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // view 2: M[(t',co)][ci] = W[8-t'][ci][co]     (conv backward-data, W [3,3,Cin,Cout])
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ w, int view, int K,
-                                                        int N, int R, int Rpad, int C,
+                                                        int N, int R, int Rpad, int C, int nsplit,
                                                         __bf16* __restrict__ packed) {
   const size_t total = (size_t)Rpad * C;
   const int cb32 = C >> 5;
@@ -56,11 +58,16 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
         v = w[((size_t)(8 - tp) * K + c) * N + co];
       }
     }
-    packed[i] = (__bf16)v;
+    for (int pl = 0; pl < nsplit; ++pl) {  // nsplit = 3: planes h, m, l with h + m + l == v exactly
+      const __bf16 h = (__bf16)v;
+      packed[(size_t)pl * total + i] = h;
+      v -= (float)h;
+    }
   }
 }
 
-hipError_t pack_bf16_launch(const float* w, int view, int K, int N, void* packed, hipStream_t st) {
+hipError_t pack_bf16_launch(const float* w, int view, int K, int N, void* packed, hipStream_t st,
+                            int nsplit) {
   int R, C;
   if (view == 0) { R = K; C = N; }
   else if (view == 1) { R = N; C = K; }
@@ -70,7 +77,7 @@ hipError_t pack_bf16_launch(const float* w, int view, int K, int N, void* packed
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(pack_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, view, K, N, R, Rpad, C,
-                     reinterpret_cast<__bf16*>(packed));
+                     nsplit == 3 ? 3 : 1, reinterpret_cast<__bf16*>(packed));
   return hipGetLastError();
 }
 
@@ -157,14 +164,21 @@ struct BfDev {
   int mtiles, ntiles;
   int S;      // split-K factor = gridDim.y; S > 1: raw partials to ws [S][M][N], splitk_reduce finishes
   float* ws;
+  int nsplit;  // 1: bf16 product; 3: fp32-accurate product from three bf16 terms per operand
 };
 
-template <int BM, int BN, int MODE>
+// NS = 1: plain bf16 multiply.  NS = 3: fp32-accurate product on the bf16 pipes ("3xBF16"): every
+// fp32 operand is split into three bf16 terms x = h + m + l (8 + 8 + 8 mantissa bits: exact), and
+// a*b is accumulated from the six largest cross terms hh, hm, mh, hl, lh, mm (the dropped ones are
+// below 2^-24 relative, the size of an fp32 rounding): 6 MFMAs of 32 cycles instead of 8 f32-input
+// MFMAs of 64 cycles for the same 32x32x16 block.
+template <int BM, int BN, int MODE, int NS>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16_mfma(const BfDev d) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int LDA = 40;  // bf16 per staged row
   constexpr int APASS = BM / 32;
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BM * LDA];
+  constexpr int PLANE = BM * LDA;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NS * PLANE];
   const GemmParams& p = d.p;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -233,25 +247,36 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
     }
   };
   auto store_a = [&](int buf) {
-    __bf16* la = &lds[buf * BM * LDA];
+    __bf16* la = &lds[buf * NS * PLANE];
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      bf16x4 v;
-      v[0] = (__bf16)ra[i].x; v[1] = (__bf16)ra[i].y; v[2] = (__bf16)ra[i].z; v[3] = (__bf16)ra[i].w;
-      *reinterpret_cast<bf16x4*>(&la[(arow + 32 * i) * LDA + c4]) = v;
+      float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (__bf16)x[e];
+          x[e] -= (float)v[e];  // exact: the residual of a nearest-even bf16 rounding fits in fp32
+        }
+        *reinterpret_cast<bf16x4*>(&la[pl * PLANE + (arow + 32 * i) * LDA + c4]) = v;
+      }
     }
   };
   // ---- B loader: fragment-ordered bf16, [k16 block][n32 block][lane][8] ---------------------------
   const int nb0 = (n0 >> 5) + wn * (BN / 64);
   const int nblocks = p.N >> 5;
-  bf16x8 rb[2][TN];
+  bf16x8 rb[NS][2][TN];
+  const size_t bplane = (size_t)p.K * p.N;  // bf16 elements per split plane of the packed weights
   auto load_b = [&](int s) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        rb[kk][j] = *reinterpret_cast<const bf16x8*>(
-            d.bpk + (((size_t)(2 * s + kk) * nblocks + nb0 + j) * 64 + lane) * 8);
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          rb[pl][kk][j] = *reinterpret_cast<const bf16x8*>(
+              d.bpk + pl * bplane + (((size_t)(2 * s + kk) * nblocks + nb0 + j) * 64 + lane) * 8);
   };
 
   f32x16 acc[TM][TN];
@@ -268,25 +293,38 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
   __syncthreads();
   int cur = 0;
   for (int s = s0; s < s1; ++s) {
-    bf16x8 bcur[2][TN];
+    bf16x8 bcur[NS][2][TN];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bcur[kk][j] = rb[kk][j];
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bcur[pl][kk][j] = rb[pl][kk][j];
     const int sn = s + 1 < s1 ? s + 1 : s;
     load_a(sn);
     load_b(sn);
-    const __bf16* la = &lds[cur * BM * LDA] + (wm * (BM / 2) + (lane & 31)) * LDA + 8 * (lane >> 5);
+    const __bf16* la = &lds[cur * NS * PLANE] + (wm * (BM / 2) + (lane & 31)) * LDA + 8 * (lane >> 5);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[TM];
+      bf16x8 af[NS][TM];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(la + i * 32 * LDA + kk * 16);
+      for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[pl][i] = *reinterpret_cast<const bf16x8*>(la + pl * PLANE + i * 32 * LDA + kk * 16);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bcur[kk][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          if (NS == 3) {  // small terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bcur[1][kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bcur[2][kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bcur[0][kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bcur[1][kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bcur[0][kk][j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bcur[0][kk][j], acc[i][j], 0, 0, 0);
+        }
     }
     store_a(cur ^ 1);
     __syncthreads();
@@ -319,10 +357,15 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
 template <int BM, int BN>
 static hipError_t bf_launch_mode(const BfDev& d, GemmMode mode, hipStream_t st) {
   const dim3 grid(d.mtiles * d.ntiles, d.S);
-  if (mode == GEMM_DENSE)
-    hipLaunchKernelGGL((gemm_bf16_mfma<BM, BN, GEMM_DENSE>), grid, dim3(256), 0, st, d);
+  if (d.nsplit == 3) {
+    if (mode == GEMM_DENSE)
+      hipLaunchKernelGGL((gemm_bf16_mfma<BM, BN, GEMM_DENSE, 3>), grid, dim3(256), 0, st, d);
+    else
+      hipLaunchKernelGGL((gemm_bf16_mfma<BM, BN, GEMM_CONV3, 3>), grid, dim3(256), 0, st, d);
+  } else if (mode == GEMM_DENSE)
+    hipLaunchKernelGGL((gemm_bf16_mfma<BM, BN, GEMM_DENSE, 1>), grid, dim3(256), 0, st, d);
   else
-    hipLaunchKernelGGL((gemm_bf16_mfma<BM, BN, GEMM_CONV3>), grid, dim3(256), 0, st, d);
+    hipLaunchKernelGGL((gemm_bf16_mfma<BM, BN, GEMM_CONV3, 1>), grid, dim3(256), 0, st, d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || d.S == 1) return e;
   return splitk_reduce_launch(d.ws, d.S, d.p.M, d.p.N, d.p.bias, 0, d.p.relu, d.p.out, d.p.ldc, st);
@@ -346,9 +389,10 @@ size_t gemm_bf16_ws_bytes(int M, int N, int K) {
 // p.bp is ignored; bpk = pack_bf16_launch output for the [p.K][p.N] operand; mode DENSE or CONV3;
 // ws: gemm_bf16_ws_bytes (less is allowed: fewer splits)
 hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk, float* ws,
-                            size_t ws_bytes, hipStream_t st) {
+                            size_t ws_bytes, hipStream_t st, int nsplit) {
   BfDev d;
   d.p = p;
+  d.nsplit = nsplit == 3 ? 3 : 1;
   d.bpk = reinterpret_cast<const __bf16*>(bpk);
   d.S = 1;
   d.ws = ws;
@@ -372,7 +416,7 @@ hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk,
 
 extern "C" {
 
-static size_t bf_packed_bytes(int K, int N) { return (((size_t)K * N * 2) + 255) & ~size_t(255); }
+static size_t bf_packed_bytes(int K, int N) { return (((size_t)3 * K * N * 2) + 255) & ~size_t(255); }
 
 size_t disn_dense_bf16_workspace_bytes(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0 || K % 32 || N % 64) return 0;
@@ -380,7 +424,7 @@ size_t disn_dense_bf16_workspace_bytes(int M, int K, int N) {
 }
 
 int disn_dense_bf16(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, int M,
-                    const float* w_kn, const float* bias, int N, int relu, float* out, void* ws,
+                    const float* w_kn, const float* bias, int N, int relu, int nsplit, float* out, void* ws,
                     size_t ws_bytes, void* stream) {
   if (!a1 || !w_kn || !bias || !out || !ws || M <= 0 || k1 <= 0 || k2 < 0 || (k2 > 0 && !a2)) return DISN_E_ARG;
   if (k1 % 32 || k2 % 32 || N <= 0 || N % 64 || lda1 < k1 || (k2 > 0 && lda2 < k2) || lda1 % 4 ||
@@ -389,7 +433,7 @@ int disn_dense_bf16(const float* a1, int lda1, int k1, const float* a2, int lda2
   const int K = k1 + k2;
   if (ws_bytes < disn_dense_bf16_workspace_bytes(M, K, N)) return DISN_E_WS;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = disn::pack_bf16_launch(w_kn, 0, K, N, ws, st);
+  hipError_t e = disn::pack_bf16_launch(w_kn, 0, K, N, ws, st, nsplit);
   if (e != hipSuccess) return (int)e;
   disn::GemmParams p{};
   p.a1 = a1; p.lda1 = lda1; p.k1 = k1; p.a2 = a2; p.lda2 = lda2;
@@ -397,7 +441,7 @@ int disn_dense_bf16(const float* a1, int lda1, int k1, const float* a2, int lda2
   p.bias = bias; p.out = out; p.ldc = N; p.relu = relu;
   const size_t pb = bf_packed_bytes(K, N);
   e = disn::gemm_bf16_launch(p, disn::GEMM_DENSE, ws, reinterpret_cast<float*>(static_cast<char*>(ws) + pb),
-                             ws_bytes - pb, st);
+                             ws_bytes - pb, st, nsplit);
   return e == hipSuccess ? 0 : (int)e;
 }
 
@@ -407,13 +451,15 @@ size_t disn_conv3x3_bf16_workspace_bytes(int B, int H, int W, int Cin, int Cout)
 }
 
 int disn_conv3x3_bf16(const float* in, int B, int H, int W, int Cin, const float* w_hwio,
-                      const float* bias, int Cout, int relu, float* out, void* ws, size_t ws_bytes,
-                      void* stream) {
+                      const float* bias, int Cout, int relu, int nsplit, float* out, void* ws,
+                      size_t ws_bytes, void* stream) {
   if (!in || !w_hwio || !bias || !out || !ws || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
   if (Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return DISN_E_SHAPE;
   if (ws_bytes < disn_conv3x3_bf16_workspace_bytes(B, H, W, Cin, Cout)) return DISN_E_WS;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = disn::pack_bf16_launch(w_hwio, 0, 9 * Cin, Cout, ws, st);
+  // DISN_BF16_SKIP_PACK (timing only): reuse the packed image a previous call left in ws
+  static const bool skip_pack = std::getenv("DISN_BF16_SKIP_PACK") != nullptr;
+  hipError_t e = skip_pack ? hipSuccess : disn::pack_bf16_launch(w_hwio, 0, 9 * Cin, Cout, ws, st, nsplit);
   if (e != hipSuccess) return (int)e;
   disn::GemmParams p{};
   p.a1 = in; p.H = H; p.W = W; p.Cin = Cin;
@@ -421,7 +467,7 @@ int disn_conv3x3_bf16(const float* in, int B, int H, int W, int Cin, const float
   p.bias = bias; p.out = out; p.ldc = Cout; p.relu = relu;
   const size_t pb = bf_packed_bytes(9 * Cin, Cout);
   e = disn::gemm_bf16_launch(p, disn::GEMM_CONV3, ws, reinterpret_cast<float*>(static_cast<char*>(ws) + pb),
-                             ws_bytes - pb, st);
+                             ws_bytes - pb, st, nsplit);
   return e == hipSuccess ? 0 : (int)e;
 }
 

@@ -50,7 +50,9 @@ hipError_t splitk_reduce_launch(const float* ws, int S, int M, int N, const floa
 // ---- gemm_bf16_mfma.hip: bf16-compute variant for the mixed-precision training step ---------
 // view 0: W [K][N]; 1: W^T (reduction N, columns K); 2: flipped 3x3 kernel for conv backward-data
 // (K = Cin, N = Cout: reduction 9*Cout, columns Cin).  packed: reduction padded to 32, 2 bytes each
-hipError_t pack_bf16_launch(const float* w, int view, int K, int N, void* packed, hipStream_t st);
+// nsplit = 3: three planes (h, m, l: w == h + m + l) for the fp32-accurate 3xBF16 product
+hipError_t pack_bf16_launch(const float* w, int view, int K, int N, void* packed, hipStream_t st,
+                            int nsplit = 1);
 // many re-packs in one launch: views as pack_bf16_launch; bf16 = false gives the fp32 disn_pack_kn
 // order (view 1 == pack_kn_T_launch, view 2 == pack_conv_bwd_launch)
 struct PackJob {
@@ -69,7 +71,7 @@ hipError_t pack_multi_launch(const PackJobs& jobs, hipStream_t st);
 // as gemm_launch (DENSE or CONV3, fp32 in / fp32 out, bias + optional ReLU), multiply in bf16
 size_t gemm_bf16_ws_bytes(int M, int N, int K);  // split-K partials for layers with few tiles
 hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk, float* ws,
-                            size_t ws_bytes, hipStream_t st);
+                            size_t ws_bytes, hipStream_t st, int nsplit = 1);
 
 // ---- gemv.hip ------------------------------------------------------------
 int gemv_splits(int K, int N);

@@ -35,8 +35,11 @@ class DeviceWeights:
         for i, nm in enumerate(VGG_CONV_NAMES):
             w = store[nm + "/weights"]                     # [3,3,Cin,Cout] HWIO
             kh, kw, ci, co = w.shape
-            packed = self._hold(ops.pack_kn(dev(w.reshape(kh * kw * ci, co))))
+            wd = dev(w.reshape(kh * kw * ci, co))
+            packed = self._hold(ops.pack_kn(wd))
             v.conv_w[i] = packed.data_ptr()
+            if ci != 3:   # three-term bf16 image: same fp32 accuracy on the 16x faster bf16 MFMA pipes
+                v.conv_w_x3[i] = self._hold(ops.pack_kn_x3(wd)).data_ptr()
             v.conv_b[i] = dev(store[nm + "/biases"]).data_ptr()
         for i, nm in enumerate(("fc6", "fc7", "fc8")):
             w = store["vgg_16/%s/weights" % nm]
@@ -55,25 +58,28 @@ class DeviceWeights:
         def Bv(scope, layer):
             return store["%s/%s/biases" % (scope, layer)]
 
-        def pk(a):
-            return self._hold(ops.pack_kn(dev(a))).data_ptr()
+        def pk(a, x3_field=None):
+            d = dev(a)
+            if x3_field:
+                setattr(m, x3_field, self._hold(ops.pack_kn_x3(d)).data_ptr())
+            return self._hold(ops.pack_kn(d)).data_ptr()
 
         for pre, scope in (("g", g), ("l", l)):
             setattr(m, pre + "_w1", dev(W(scope, "fold1/conv1")).data_ptr())       # [3,64] as is
             setattr(m, pre + "_b1", dev(Bv(scope, "fold1/conv1")).data_ptr())
-            setattr(m, pre + "_w2", pk(W(scope, "fold1/conv2")))
+            setattr(m, pre + "_w2", pk(W(scope, "fold1/conv2"), pre + "_x2"))
             setattr(m, pre + "_b2", dev(Bv(scope, "fold1/conv2")).data_ptr())
-            setattr(m, pre + "_w3", pk(W(scope, "fold1/conv3")))
+            setattr(m, pre + "_w3", pk(W(scope, "fold1/conv3"), pre + "_x3"))
             setattr(m, pre + "_b3", dev(Bv(scope, "fold1/conv3")).data_ptr())
             setattr(m, pre + "_b4", dev(Bv(scope, "fold2/conv1")).data_ptr())
-            setattr(m, pre + "_w5", pk(W(scope, "fold2/conv2")))
+            setattr(m, pre + "_w5", pk(W(scope, "fold2/conv2"), pre + "_x5"))
             setattr(m, pre + "_b5", dev(Bv(scope, "fold2/conv2")).data_ptr())
             setattr(m, pre + "_w6", dev(W(scope, "fold2/conv5").reshape(-1)).data_ptr())   # [256]
             setattr(m, pre + "_b6", dev(Bv(scope, "fold2/conv5")).data_ptr())
         w4g = W(g, "fold2/conv1")                          # [512+1024, 512]: rows 0-511 point, rest global
-        m.g_w4_point = pk(w4g[:512])
+        m.g_w4_point = pk(w4g[:512], "g_x4_point")
         m.g_w4_global = dev(w4g[512:]).data_ptr()          # folded into a per-image bias by the library
-        m.l_w4 = pk(W(l, "fold2/conv1"))                   # [512+1472, 512]
+        m.l_w4 = pk(W(l, "fold2/conv1"), "l_x4")           # [512+1472, 512]
         for f in MLP_FIELDS:
             assert getattr(m, f), f
         self.mlp = m

@@ -44,6 +44,15 @@ def pack_kn(w_kn: torch.Tensor, kpad: Optional[int] = None) -> torch.Tensor:
     return out
 
 
+def pack_kn_x3(w_kn: torch.Tensor) -> torch.Tensor:
+    """[K,N] -> the three-term bf16 image (disn_pack_kn_x3) of the fp32-accurate bf16-MFMA path"""
+    w_kn = _chk(w_kn, "w_kn")
+    K, N = w_kn.shape
+    out = torch.empty(lib().disn_pack_kn_x3_bytes(K, N), dtype=torch.uint8, device=w_kn.device)
+    check("disn_pack_kn_x3", lib().disn_pack_kn_x3(w_kn.data_ptr(), K, N, out.data_ptr(), _stream()))
+    return out
+
+
 def resize_bilinear(x: torch.Tensor, out_h: int, out_w: int, out: Optional[torch.Tensor] = None,
                     out_coff: int = 0) -> torch.Tensor:
     """tf.image.resize_bilinear (legacy) on NHWC."""
@@ -410,7 +419,7 @@ def adam_update(params: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: t
 
 
 def dense_bf16(a1: torch.Tensor, w_kn: torch.Tensor, bias: torch.Tensor, relu: bool = True,
-               a2: Optional[torch.Tensor] = None) -> torch.Tensor:
+               a2: Optional[torch.Tensor] = None, nsplit: int = 1) -> torch.Tensor:
     """act([a1|a2] @ w_kn + bias) with the multiply in bf16 (raw fp32 weights, packed on the fly)"""
     a1, w_kn = _chk(a1, "a1"), _chk(w_kn, "w_kn")
     M, k1 = a1.shape
@@ -420,12 +429,13 @@ def dense_bf16(a1: torch.Tensor, w_kn: torch.Tensor, bias: torch.Tensor, relu: b
     ws = _ws(lib().disn_dense_bf16_workspace_bytes(M, k1 + k2, N), a1.device)
     check("disn_dense_bf16", lib().disn_dense_bf16(
         a1.data_ptr(), k1, k1, _chk(a2, "a2").data_ptr() if a2 is not None else None, k2, k2, M,
-        w_kn.data_ptr(), _chk(bias, "bias").data_ptr(), N, int(relu), out.data_ptr(), ws.data_ptr(),
+        w_kn.data_ptr(), _chk(bias, "bias").data_ptr(), N, int(relu), int(nsplit), out.data_ptr(), ws.data_ptr(),
         ws.numel(), _stream()))
     return out
 
 
-def conv3x3_bf16(x: torch.Tensor, w_hwio: torch.Tensor, bias: torch.Tensor, relu: bool = True) -> torch.Tensor:
+def conv3x3_bf16(x: torch.Tensor, w_hwio: torch.Tensor, bias: torch.Tensor, relu: bool = True,
+                 nsplit: int = 1) -> torch.Tensor:
     x, w_hwio = _chk(x, "x"), _chk(w_hwio, "w_hwio")
     B, H, W, Cin = x.shape
     Cout = w_hwio.shape[-1]
@@ -433,5 +443,5 @@ def conv3x3_bf16(x: torch.Tensor, w_hwio: torch.Tensor, bias: torch.Tensor, relu
     ws = _ws(lib().disn_conv3x3_bf16_workspace_bytes(B, H, W, Cin, Cout), x.device)
     check("disn_conv3x3_bf16", lib().disn_conv3x3_bf16(
         x.data_ptr(), B, H, W, Cin, w_hwio.data_ptr(), _chk(bias, "bias").data_ptr(), Cout, int(relu),
-        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        int(nsplit), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
     return out

@@ -38,7 +38,7 @@ extern "C" {
 #define DISN_E_WS (-3)    /* workspace too small */
 
 /* ABI version of this header; disn_abi_version() returns the library's. */
-#define DISN_ABI_VERSION 1
+#define DISN_ABI_VERSION 2
 int disn_abi_version(void);
 
 /* ---------------------------------------------------------------------- *
@@ -50,6 +50,12 @@ int disn_abi_version(void);
  * `packed` holds Kpad*N floats.                                            *
  * ---------------------------------------------------------------------- */
 int disn_pack_kn(const float* w_kn, int K, int N, int Kpad, float* packed, void* stream);
+/* Three-term bf16 image of the same [K][N] matrix for the fp32-accurate path on the bf16 MFMA pipes:
+ * planes h, m, l (w == h + m + l exactly), each in bf16 B-fragment order
+ * plane[((k/16)*(N/32) + n/32)*512 + lane*8 + t] = W[16*(k/16) + 8*(lane>>5) + t][32*(n/32) + (lane&31)],
+ * K zero-padded to a multiple of 32.  `packed` holds disn_pack_kn_x3_bytes(K, N) bytes. */
+size_t disn_pack_kn_x3_bytes(int K, int N);
+int disn_pack_kn_x3(const float* w_kn, int K, int N, void* packed, void* stream);
 
 /* ---------------------------------------------------------------------- *
  * Row A / E: tf.image.resize_bilinear, TF1 legacy (align_corners=False,    *
@@ -75,6 +81,11 @@ typedef struct disn_vgg_weights {
   const float* fc_w[3]; /* fc6, fc7, fc8 : [K][N] row-major */
   const float* fc_b[3];
   int num_classes; /* 1024 on this path */
+  /* optional (NULL = not used): disn_pack_kn_x3 of the same conv weights (index 0 is ignored).  With
+   * it a layer runs as a three-term bf16 split on the bf16 MFMA pipes -- the same fp32 accuracy
+   * (every fp32 operand is the exact sum of three bf16 terms; six cross products accumulated in
+   * fp32), 1.1-1.5x the speed of the f32-input MFMA. */
+  const void* conv_w_x3[13];
 } disn_vgg_weights_t;
 
 size_t disn_vgg16_workspace_bytes(int B);
@@ -144,6 +155,9 @@ typedef struct disn_mlp_weights {
   const float *g_w4_point, *g_w4_global, *g_b4, *g_w5, *g_b5, *g_w6, *g_b6;
   const float *l_w1, *l_b1, *l_w2, *l_b2, *l_w3, *l_b3;
   const float *l_w4, *l_b4, *l_w5, *l_b5, *l_w6, *l_b6;
+  /* optional (NULL = not used): disn_pack_kn_x3 images of g_w2, g_w3, g_w4_point, g_w5, l_w2, l_w3,
+   * l_w4, l_w5 (same matrices as the fp32 packs); see disn_vgg_weights_t.conv_w_x3 */
+  const void *g_x2, *g_x3, *g_x4_point, *g_x5, *l_x2, *l_x3, *l_x4, *l_x5;
 } disn_mlp_weights_t;
 
 /* scratch for one launch over B images x N points (N per image) */
@@ -322,15 +336,17 @@ int disn_conv3x3_backward(const float* x, int B, int H, int W, int Cin, const fl
 /* bf16-compute forms of disn_dense / disn_conv3x3 used by the mixed-precision training step
  * (fp32 tensors in HBM, operands rounded to bf16 when staged, fp32 accumulate, fp32 out;
  * v_mfma_f32_32x32x16_bf16).  They take the RAW TF weights ([K][N] / [3,3,Cin,Cout]) and pack them
- * into `ws`.  k1, k2, Cin multiples of 32; N, Cout multiples of 64. */
+ * into `ws`.  k1, k2, Cin multiples of 32; N, Cout multiples of 64.
+ * nsplit = 1: plain bf16 product.  nsplit = 3: fp32-accurate product on the bf16 pipes (each operand
+ * split into three bf16 terms, six of the nine cross terms accumulated: error ~ one fp32 rounding). */
 size_t disn_dense_bf16_workspace_bytes(int M, int K, int N);
 int disn_dense_bf16(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, int M,
-                    const float* w_kn, const float* bias, int N, int relu, float* out, void* ws,
+                    const float* w_kn, const float* bias, int N, int relu, int nsplit, float* out, void* ws,
                     size_t ws_bytes, void* stream);
 size_t disn_conv3x3_bf16_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int disn_conv3x3_bf16(const float* in, int B, int H, int W, int Cin, const float* w_hwio,
-                      const float* bias, int Cout, int relu, float* out, void* ws, size_t ws_bytes,
-                      void* stream);
+                      const float* bias, int Cout, int relu, int nsplit, float* out, void* ws,
+                      size_t ws_bytes, void* stream);
 /* dx [B,H,W,C]: dy routed to the first maximum of each 2x2 window of x, zero elsewhere (H, W even) */
 int disn_maxpool2x2_backward(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
                              void* stream);

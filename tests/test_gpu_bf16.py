@@ -59,6 +59,65 @@ def test_dense_bf16(ops, M, k1, k2, N, relu):
     assert np.abs(got - full).max() < 3e-2 * np.abs(full).max()
 
 
+def test_pack_kn_x3_planes_sum_to_the_fp32_weights_exactly(ops):
+    rng = np.random.default_rng(0)
+    K, N = 1984, 512
+    w = (rng.standard_normal((K, N)) * np.exp(rng.uniform(-12, 3, (K, N)))).astype(np.float32)
+    raw = ops.pack_kn_x3(dev(w))
+    planes = raw.view(torch.bfloat16).to(torch.float32).cpu().numpy().reshape(3, K // 16, N // 32, 64, 8)
+    lane = np.arange(64)
+    rec = np.zeros((3, K, N), np.float32)
+    for t in range(8):
+        k = np.arange(K // 16)[:, None, None] * 16 + 8 * (lane >> 5)[None, None, :] + t
+        n = np.arange(N // 32)[None, :, None] * 32 + (lane & 31)[None, None, :]
+        for pl in range(3):
+            rec[pl][k, n] = planes[pl][:, :, :, t]
+    # three 8-bit pieces carry all 24 mantissa bits (down to the bf16 subnormal range)
+    total = rec[0].astype(np.float64) + rec[1].astype(np.float64) + rec[2].astype(np.float64)
+    big = np.abs(w) > 1e-30
+    assert np.array_equal(total[big].astype(np.float32), w[big])
+    assert np.array_equal(rec[0], torch.from_numpy(w).to(torch.bfloat16).to(torch.float32).numpy())
+
+
+@pytest.mark.parametrize("M,k1,k2,N", [(2048, 512, 1472, 512), (65536, 256, 0, 512), (700, 64, 0, 256)])
+def test_dense_three_term_split_is_fp32_accurate(ops, M, k1, k2, N):
+    rng = np.random.default_rng(M + k1)
+    a1 = np.maximum(rng.standard_normal((M, k1)), 0).astype(np.float32)
+    a2 = rng.standard_normal((M, k2)).astype(np.float32) if k2 else None
+    w = (rng.standard_normal((k1 + k2, N)) / math.sqrt(k1 + k2)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    a = np.concatenate([a1, a2], 1) if k2 else a1
+    ref = np.maximum(a.astype(np.float64) @ w.astype(np.float64) + b, 0)
+    got3 = ops.dense_bf16(dev(a1), dev(w), dev(b), True, dev(a2) if k2 else None, nsplit=3).cpu().numpy()
+    got32 = ops.dense(dev(a1), ops.pack_kn(dev(w)), dev(b), N, True, dev(a2) if k2 else None).cpu().numpy()
+    scale = np.abs(ref).max()
+    e3, e32 = np.abs(got3 - ref).max() / scale, np.abs(got32 - ref).max() / scale
+    print("max err / scale: 3xbf16 %.3g, fp32 mfma %.3g" % (e3, e32))
+    report_close("dense 3xbf16", got3, ref, atol=2e-6 * scale)
+    assert e3 < 4 * e32 + 2e-7
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(1, 56, 256, 256), (1, 14, 512, 512), (2, 28, 128, 64), (1, 112, 64, 128)])
+def test_conv3x3_three_term_split_is_fp32_accurate(ops, B, H, Cin, Cout):
+    """nsplit = 3: every fp32 operand as three bf16 terms, six cross products on the bf16 MFMA: the
+    result must be as close to the float64 convolution of the UNROUNDED inputs as the fp32-MFMA
+    kernel is (both are compared here; bar 2e-6 of the output scale)."""
+    rng = np.random.default_rng(B * 7 + H + Cin)
+    x = np.maximum(rng.standard_normal((B, H, H, Cin)), 0).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / math.sqrt(4.5 * Cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    ref = torch.relu(Fnn.conv2d(torch.from_numpy(x.astype(np.float64)).permute(0, 3, 1, 2),
+                                torch.from_numpy(w.astype(np.float64)).permute(3, 2, 0, 1),
+                                torch.from_numpy(b.astype(np.float64)), padding=1)).permute(0, 2, 3, 1).numpy()
+    got3 = ops.conv3x3_bf16(dev(x), dev(w), dev(b), True, nsplit=3).cpu().numpy()
+    got32 = ops.conv3x3(dev(x), ops.pack_kn(dev(w.reshape(9 * Cin, Cout))), dev(b), Cout, True).cpu().numpy()
+    scale = np.abs(ref).max()
+    e3, e32 = np.abs(got3 - ref).max() / scale, np.abs(got32 - ref).max() / scale
+    print("max err / scale: 3xbf16 %.3g, fp32 mfma %.3g" % (e3, e32))
+    report_close("conv 3xbf16", got3, ref, atol=2e-6 * scale)
+    assert e3 < 4 * e32 + 2e-7
+
+
 @pytest.mark.parametrize("M,K,N", [(1000, 64, 256), (4096, 512, 512), (777, 1472, 512), (20000, 512, 256)])
 def test_dense_backward_bf16(ops, M, K, N):
     rng = np.random.default_rng(M + K + N)

@@ -31,7 +31,7 @@ def ops():
 def test_extension_is_loaded_native():
     from disn_amd import _lib
     h = _lib.lib()
-    assert os.path.basename(_lib.LIB_PATH) == "libdisn_amd.so" and h.disn_abi_version() == 1
+    assert os.path.basename(_lib.LIB_PATH) == "libdisn_amd.so" and h.disn_abi_version() == _lib.ABI_VERSION
     maps = open("/proc/self/maps").read()
     assert "libdisn_amd.so" in maps
 
