@@ -78,7 +78,7 @@ def train_bench(args, torch, dist, dev, world, rank, launched):
     from disn_amd.weights import WeightStore
     B = args.train_batch
     bf = args.train_dtype == "bf16"
-    tr = Trainer(WeightStore.random_init(0, mode="he"), dev, batch_size=B * world, compute_bf16=bf)
+    tr = Trainer(WeightStore.random_init(0, mode="he"), dev, batch_size=B * world, precision=args.train_dtype)
     feed = train_feed(torch, dev, B, 1000 + rank)
     for _ in range(args.warmup):
         tr.step(feed)
@@ -109,7 +109,8 @@ def train_bench(args, torch, dist, dev, world, rank, launched):
             "config": {"workload": "BASELINE config 5 shape, %s: data-parallel training step, %d samples x %d "
                                    "points per GPU, random-init (he) weights" % (
                                        "bf16 multiply / fp32 accumulate, master weights and optimizer" if bf
-                                       else "fp32 (the reference's precision)", B, N_POINTS),
+                                       else "fp32 accuracy (the reference's precision; precision=%s)" % args.train_dtype,
+                                       B, N_POINTS),
                        "global_batch": B * world, "points_per_sample": N_POINTS,
                        "parallelism": "dp%d (one sum all-reduce of the flat gradient buffer in two buckets, the "
                                       "fc+MLP bucket under the conv backward)" % world},
@@ -126,9 +127,11 @@ def main():
     ap.add_argument("--workload", choices=("query", "train"), default="query",
                     help="query: BASELINE.json metric (default); train: config-5 training step")
     ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step")
-    ap.add_argument("--train-dtype", choices=("f32", "bf16"), default="f32",
-                    help="--workload train: f32 = the reference's precision; bf16 = mixed precision "
-                         "(bf16 multiply, fp32 accumulate / master weights / optimizer)")
+    ap.add_argument("--train-dtype", choices=("f32", "f32_mfma", "bf16"), default="f32",
+                    help="--workload train: f32 = the reference's precision (forward / data-gradient GEMMs as "
+                         "a three-term bf16 split on the bf16 MFMA pipes, same error as f32_mfma = everything "
+                         "on the f32-input MFMA); bf16 = mixed precision (bf16 multiply, fp32 accumulate / "
+                         "master weights / optimizer)")
     args = ap.parse_args()
 
     import torch
@@ -312,7 +315,7 @@ def main():
             tr.close()
             del tr
             torch.cuda.empty_cache()
-            tb = Trainer(WeightStore.random_init(0, mode="he"), dev, batch_size=8, compute_bf16=True)
+            tb = Trainer(WeightStore.random_init(0, mode="he"), dev, batch_size=8, precision="bf16")
             for _ in range(2):
                 tb.step(tfeed)
             ms_b = ev_time_ms(lambda: tb.step(tfeed), 5, torch)

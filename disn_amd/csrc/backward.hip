@@ -325,10 +325,10 @@ __global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ x,
       acc.x += xv * d.x; acc.y += xv * d.y; acc.z += xv * d.z; acc.w += xv * d.w;
     }
     if (l2 != 0.f) {
-      const float4 wv = *reinterpret_cast<const float4*>(wcur + k * N + n);
+      const float4 wv = nt_load4(wcur + k * N + n);
       acc.x += l2 * wv.x; acc.y += l2 * wv.y; acc.z += l2 * wv.z; acc.w += l2 * wv.w;
     }
-    *reinterpret_cast<float4*>(c + k * N + n) = acc;
+    nt_store4(c + k * N + n, acc);
   }
 }
 
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(const float* __restrict__ w
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
     const float* wr = w + (size_t)k * N;
     for (int n = lane * 4; n < N; n += 256) {
-      const float4 wv = *reinterpret_cast<const float4*>(wr + n);
+      const float4 wv = nt_load4(wr + n);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)(b0 + b) * N + n);
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
   const long n4 = segs.cnt[seg] >> 2;
   float a = 0.f, b = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 256L * 256) {
-    const float4 v = p[i];
+    const float4 v = nt_load4(reinterpret_cast<const float*>(p + i));
     a += v.x * v.x + v.y * v.y;
     b += v.z * v.z + v.w * v.w;
   }
@@ -513,9 +513,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
   const float c1 = 1.0f - b1, c2 = 1.0f - b2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (size_t)gridDim.x * blockDim.x) {
-    float4 wv = reinterpret_cast<float4*>(w)[i];
-    const float4 gv = reinterpret_cast<const float4*>(g)[i];
-    float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float4 wv = nt_load4(w + 4 * i);
+    const float4 gv = nt_load4(g + 4 * i);
+    float4 mv = nt_load4(m + 4 * i), vv = nt_load4(v + 4 * i);
 #define DISN_ADAM(f)                                   \
   {                                                    \
     const float gg = gv.f * gscale;                    \
@@ -525,9 +525,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
   }
     DISN_ADAM(x) DISN_ADAM(y) DISN_ADAM(z) DISN_ADAM(w)
 #undef DISN_ADAM
-    reinterpret_cast<float4*>(w)[i] = wv;
-    reinterpret_cast<float4*>(m)[i] = mv;
-    reinterpret_cast<float4*>(v)[i] = vv;
+    nt_store4(w + 4 * i, wv);
+    nt_store4(m + 4 * i, mv);
+    nt_store4(v + 4 * i, vv);
   }
 }
 

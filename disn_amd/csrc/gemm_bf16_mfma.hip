@@ -130,24 +130,30 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
       }
     }
     if (T == 8) {
-      bf16x8 o;
+      for (int pl = 0; pl < J.ns; ++pl) {  // ns = 3: planes h, m, l with h + m + l == v
+        bf16x8 o;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) o[t] = (__bf16)v[t];
-      reinterpret_cast<bf16x8*>(J.dst)[slot] = o;
+        for (int t = 0; t < 8; ++t) {
+          o[t] = (__bf16)v[t];
+          v[t] -= (float)o[t];
+        }
+        reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(J.dst) + (size_t)pl * J.plane)[slot] = o;
+      }
     } else {
       reinterpret_cast<float4*>(J.dst)[slot] = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
 }
 
-void pack_job_add(PackJobs& jobs, const float* src, void* dst, int view, int K, int N, bool bf16) {
+void pack_job_add(PackJobs& jobs, const float* src, void* dst, int view, int K, int N, int ns) {
   PackJob& J = jobs.j[jobs.n++];
-  J.src = src; J.dst = dst; J.view = view; J.K = K; J.N = N; J.T = bf16 ? 8 : 4;
+  J.src = src; J.dst = dst; J.view = view; J.K = K; J.N = N; J.T = ns ? 8 : 4; J.ns = ns ? ns : 1;
   if (view == 0) { J.R = K; J.C = N; }
   else if (view == 1) { J.R = N; J.C = K; }
   else { J.R = 9 * N; J.C = K; }
+  J.plane = (long)((J.R + 31) & ~31) * J.C;
   J.begin = jobs.total;  // in slots of T elements
-  jobs.total += (long)((J.R + 31) & ~31) * J.C / J.T;
+  jobs.total += J.plane / J.T;
 }
 
 hipError_t pack_multi_launch(const PackJobs& jobs, hipStream_t st) {

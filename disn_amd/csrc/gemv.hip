@@ -26,7 +26,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
   const float* wp = w + col;
 #pragma unroll 8
   for (int k = kbeg + wave; k < kend; k += 4) {
-    const float4 wv = *reinterpret_cast<const float4*>(wp + (size_t)k * N);
+    // streamed once: non-temporal, so the 411 MB of fc6 do not evict the activations from L2 / MALL
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f wt = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(wp + (size_t)k * N));
+    const float4 wv = make_float4(wt[0], wt[1], wt[2], wt[3]);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const float xv = x[(size_t)(b0 + b) * K + k];

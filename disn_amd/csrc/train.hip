@@ -85,15 +85,15 @@ void build_layout(disn_param_layout_t* L) {
 
 int dense_fwd(const float* a1, int lda1, int k1, const float* a2, int lda2, int K, int M,
               const float* bp, const float* bias, int N, int relu, float* out, float* ws,
-              size_t ws_bytes, hipStream_t st, bool bf = false) {
-  // bf: bp is a pack_bf16_launch image and the multiply runs on the bf16 MFMA
+              size_t ws_bytes, hipStream_t st, int ns = 0) {
+  // ns != 0: bp is a pack_bf16_launch image; 1 = bf16 multiply, 3 = three-term split (fp32-accurate)
   GemmParams p{};
   p.a1 = a1; p.lda1 = lda1; p.k1 = k1; p.a2 = a2; p.lda2 = lda2;
   p.M = M; p.N = N; p.K = K;
   p.bp = bp; p.bias = bias; p.rows_per_bias = 0;
   p.out = out; p.ldc = N; p.relu = relu;
-  if (bf) {
-    DISN_TRY(gemm_bf16_launch(p, GEMM_DENSE, bp, ws, ws ? ws_bytes : 0, st));
+  if (ns) {
+    DISN_TRY(gemm_bf16_launch(p, GEMM_DENSE, bp, ws, ws ? ws_bytes : 0, st, ns));
     return 0;
   }
   const GemmPlan pl = gemm_plan(M, N, K, ws ? ws_bytes : 0);
@@ -102,15 +102,15 @@ int dense_fwd(const float* a1, int lda1, int k1, const float* a2, int lda2, int 
 }
 
 int conv_fwd(const float* in, int B, int H, int W, int Cin, const float* bp, const float* bias, int Cout,
-             int relu, float* out, float* ws, size_t ws_bytes, hipStream_t st, bool bf = false) {
+             int relu, float* out, float* ws, size_t ws_bytes, hipStream_t st, int ns = 0) {
   GemmParams p{};
   p.a1 = in;
   p.H = H; p.W = W; p.Cin = Cin;
   p.M = B * H * W; p.N = Cout; p.K = conv_kpad(Cin);
   p.bp = bp; p.bias = bias; p.rows_per_bias = 0;
   p.out = out; p.ldc = Cout; p.relu = relu;
-  if (bf && Cin != 3) {
-    DISN_TRY(gemm_bf16_launch(p, GEMM_CONV3, bp, ws, ws ? ws_bytes : 0, st));
+  if (ns && Cin != 3) {
+    DISN_TRY(gemm_bf16_launch(p, GEMM_CONV3, bp, ws, ws ? ws_bytes : 0, st, ns));
     return 0;
   }
   const GemmPlan pl = gemm_plan(p.M, p.N, p.K, ws ? ws_bytes : 0);
@@ -124,13 +124,13 @@ size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 struct BwdWs {
   float *wT, *zero, *gemm_ws, *tn_ws, *red_ws;
   size_t gemm_ws_bytes, total;
-  bool bf16 = false;  // data-gradient GEMMs on the bf16 MFMA (mixed-precision step)
+  int ns = 0;  // GEMM arithmetic: 0 f32-input MFMA; 1 bf16 multiply; 3 three-term bf16 split (fp32-accurate)
 };
 
 // capacity for: one packed transposed weight (wt_floats), GEMMs with up to max_m rows
 BwdWs bwd_layout(Bump& b, size_t wt_floats, long max_m, size_t gemm_ws_bytes, size_t red_bytes) {
   BwdWs w;
-  w.wT = b.take(wt_floats);
+  w.wT = b.take(wt_floats * 3 / 2);  // room for the 6-byte three-term image
   w.zero = b.take(4096);
   w.gemm_ws_bytes = gemm_ws_bytes;
   w.gemm_ws = b.take(gemm_ws_bytes / sizeof(float) + 1);
@@ -149,19 +149,19 @@ int dense_bwd(const float* a, int lda, int K, const float* w_kn, const float* dz
               const float* prepacked = nullptr) {
   TnParams t{};
   t.a = a; t.lda = lda; t.b = dz; t.ldb = N; t.M = M; t.P = K; t.Q = N;
-  t.c = dw; t.ldc = N; t.Cin = 0; t.l2 = wd; t.wcur = w_kn; t.bf16 = s.bf16;
+  t.c = dw; t.ldc = N; t.Cin = 0; t.l2 = wd; t.wcur = w_kn; t.bf16 = s.ns == 1;
   DISN_TRY(gemm_tn_launch(t, s.tn_ws, st));
   if (da) {
     const float* wt = prepacked;  // W^T in fragment order: packed at the start of the step, or here
     if (!wt) {
-      if (s.bf16)
-        DISN_TRY(pack_bf16_launch(w_kn, 1, K, N, s.wT, st));
+      if (s.ns)
+        DISN_TRY(pack_bf16_launch(w_kn, 1, K, N, s.wT, st, s.ns));
       else
         DISN_TRY(pack_kn_T_launch(w_kn, K, N, s.wT, st));
       wt = s.wT;
     }
     DISN_RC(dense_fwd(dz, N, N, nullptr, 0, N, (int)M, wt, s.zero, K, 0, da, s.gemm_ws,
-                      s.gemm_ws_bytes, st, s.bf16));
+                      s.gemm_ws_bytes, st, s.ns));
   }
   return 0;
 }
@@ -182,19 +182,19 @@ int conv_bwd(const float* x, int B, int H, int W, int Cin, const float* w, const
   } else {
     TnParams t{};
     t.a = x; t.lda = Cin; t.b = dz; t.ldb = Cout; t.M = M; t.P = 9 * Cin; t.Q = Cout;
-    t.c = dw; t.ldc = Cout; t.H = H; t.W = W; t.Cin = Cin; t.l2 = wd; t.wcur = w; t.bf16 = s.bf16;
+    t.c = dw; t.ldc = Cout; t.H = H; t.W = W; t.Cin = Cin; t.l2 = wd; t.wcur = w; t.bf16 = s.ns == 1;
     DISN_TRY(gemm_tn_launch(t, s.tn_ws, st));
   }
   if (dx) {
     const float* wt = prepacked;
     if (!wt) {
-      if (s.bf16)
-        DISN_TRY(pack_bf16_launch(w, 2, Cin, Cout, s.wT, st));
+      if (s.ns)
+        DISN_TRY(pack_bf16_launch(w, 2, Cin, Cout, s.wT, st, s.ns));
       else
         DISN_TRY(pack_conv_bwd_launch(w, Cin, Cout, s.wT, st));
       wt = s.wT;
     }
-    DISN_RC(conv_fwd(dz, B, H, W, Cout, wt, s.zero, Cin, 0, dx, s.gemm_ws, s.gemm_ws_bytes, st, s.bf16));
+    DISN_RC(conv_fwd(dz, B, H, W, Cout, wt, s.zero, Cin, 0, dx, s.gemm_ws, s.gemm_ws_bytes, st, s.ns));
   }
   return 0;
 }
@@ -247,14 +247,15 @@ TrainWs train_layout(void* ws, int B, int N) {
   Bump b(ws);
   TrainWs t;
   const long M = (long)B * N;
-  for (int i = 0; i < 13; ++i) t.conv_p[i] = b.take((size_t)conv_kpad(kConv[i].cin) * kConv[i].cout);
-  t.g_p2 = b.take(64 * 256); t.g_p3 = b.take(256 * 512); t.g_p4 = b.take(512 * 512); t.g_p5 = b.take(512 * 256);
-  t.l_p2 = b.take(64 * 256); t.l_p3 = b.take(256 * 512); t.l_p4 = b.take(1984 * 512); t.l_p5 = b.take(512 * 256);
+  // (x 3/2: the three-term bf16 image is 6 bytes per weight)
+  for (int i = 0; i < 13; ++i) t.conv_p[i] = b.take((size_t)conv_kpad(kConv[i].cin) * kConv[i].cout * 3 / 2);
+  t.g_p2 = b.take(64 * 256 * 3 / 2); t.g_p3 = b.take(256 * 512 * 3 / 2); t.g_p4 = b.take(512 * 512 * 3 / 2); t.g_p5 = b.take(512 * 256 * 3 / 2);
+  t.l_p2 = b.take(64 * 256 * 3 / 2); t.l_p3 = b.take(256 * 512 * 3 / 2); t.l_p4 = b.take(1984 * 512 * 3 / 2); t.l_p5 = b.take(512 * 256 * 3 / 2);
   t.conv_bT[0] = nullptr;
-  for (int i = 1; i < 13; ++i) t.conv_bT[i] = b.take((size_t)9 * kConv[i].cin * kConv[i].cout);
-  t.g_t2 = b.take(64 * 256); t.g_t3 = b.take(256 * 512); t.g_t4 = b.take(512 * 512); t.g_t5 = b.take(512 * 256);
-  t.l_t2 = b.take(64 * 256); t.l_t3 = b.take(256 * 512); t.l_t4 = b.take(512 * 512);
-  t.l_t4f = b.take(1472 * 512); t.l_t5 = b.take(512 * 256);
+  for (int i = 1; i < 13; ++i) t.conv_bT[i] = b.take((size_t)9 * kConv[i].cin * kConv[i].cout * 3 / 2);
+  t.g_t2 = b.take(64 * 256 * 3 / 2); t.g_t3 = b.take(256 * 512 * 3 / 2); t.g_t4 = b.take(512 * 512 * 3 / 2); t.g_t5 = b.take(512 * 256 * 3 / 2);
+  t.l_t2 = b.take(64 * 256 * 3 / 2); t.l_t3 = b.take(256 * 512 * 3 / 2); t.l_t4 = b.take(512 * 512 * 3 / 2);
+  t.l_t4f = b.take(1472 * 512 * 3 / 2); t.l_t5 = b.take(512 * 256 * 3 / 2);
   t.resized = b.take((size_t)B * 224 * 224 * 3);
   for (int i = 0; i < 13; ++i) {
     const ConvL& L = kConv[i];
@@ -326,7 +327,7 @@ int disn_dense_backward(const float* a, int lda, int K, const float* w_kn, const
   BwdWs s = bwd_layout(b, (size_t)K * N, M,
                        max_sz(max_sz(gemm_plan(M, K, N).ws_bytes, gemm_bf16_ws_bytes(M, K, N)), 256),
                        colsum_ws_bytes(M, N));
-  s.bf16 = compute_bf16 != 0;
+  s.ns = compute_bf16 == 2 ? 3 : (compute_bf16 ? 1 : 0);
   DISN_TRY(hipMemsetAsync(s.zero, 0, 4096 * sizeof(float), st));
   DISN_TRY(relu_bwd_colsum_launch(dy, y, M, N, y != nullptr, db, s.red_ws, st));
   return dense_bwd(a, lda, K, w_kn, dy, M, N, wd, da, dw, s, st);
@@ -357,7 +358,7 @@ int disn_conv3x3_backward(const float* x, int B, int H, int W, int Cin, const fl
                             : max_sz(max_sz(gemm_plan(M, Cin, 9 * Cout).ws_bytes,
                                             gemm_bf16_ws_bytes(M, Cin, 9 * Cout)), 256);
   BwdWs s = bwd_layout(b, (size_t)9 * (Cin == 3 ? 64 : Cin) * Cout, M, g, colsum_ws_bytes(M, Cout));
-  s.bf16 = compute_bf16 != 0 && Cin != 3;
+  s.ns = Cin == 3 ? 0 : (compute_bf16 == 2 ? 3 : (compute_bf16 ? 1 : 0));
   DISN_TRY(hipMemsetAsync(s.zero, 0, 4096 * sizeof(float), st));
   DISN_TRY(relu_bwd_colsum_launch(dy, y, M, Cout, y != nullptr, db, s.red_ws, st));
   return conv_bwd(x, B, H, W, Cin, w_hwio, dy, Cout, wd, dx, dw, col, s, st);
@@ -434,8 +435,8 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
   auto G = [&](int idx) { return grads + L.offset[idx]; };
   const long M = (long)B * N;
   BwdWs s = t.bw;
-  const bool bf = compute_bf16 != 0;
-  s.bf16 = bf;
+  const int bf = compute_bf16 == 2 ? 3 : (compute_bf16 ? 1 : 0);  // planes of the weight images
+  s.ns = bf;
   float* gws = s.gemm_ws;
   const size_t gwb = s.gemm_ws_bytes;
 
@@ -444,7 +445,7 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
   // all 41 re-packs (forward + data-gradient views) in one launch
   {
     PackJobs jobs{};
-    pack_job_add(jobs, P(0), t.conv_p[0], 0, 27, 64, false);  // conv1_1 (K = 27) stays on the fp32 path
+    pack_job_add(jobs, P(0), t.conv_p[0], 0, 27, 64, 0);  // conv1_1 (K = 27) stays on the fp32 path
     for (int i = 1; i < 13; ++i) {
       pack_job_add(jobs, P(2 * i), t.conv_p[i], 0, 9 * kConv[i].cin, kConv[i].cout, bf);
       pack_job_add(jobs, P(2 * i), t.conv_bT[i], 2, kConv[i].cin, kConv[i].cout, bf);

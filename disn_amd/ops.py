@@ -391,7 +391,9 @@ def train_step(params: torch.Tensor, grads: torch.Tensor, img: torch.Tensor, tra
                compute_bf16: bool = False):
     """forward + get_loss + gradients into `grads`: -> (pred [B,N], losses [5] device tensor).
     ctx: concurrency context (ctx_create); head_ready: a torch.cuda.Event (already recorded once, so
-    that its handle exists) recorded when the fc/MLP part of `grads` is final."""
+    that its handle exists) recorded when the fc/MLP part of `grads` is final.
+    compute_bf16: 0 f32-input MFMA everywhere; 1 bf16 multiply (mixed precision); 2 fp32-accurate
+    three-term bf16 split for the forward / data-gradient GEMMs."""
     B, N = pts.shape[0], pts.shape[1]
     dev = params.device
     need = lib().disn_train_workspace_bytes(B, N)
@@ -405,7 +407,7 @@ def train_step(params: torch.Tensor, grads: torch.Tensor, img: torch.Tensor, tra
         ctx, _chk(params, "params").data_ptr(), _chk(grads, "grads").data_ptr(), _chk(img, "img").data_ptr(),
         _chk(trans_mat, "trans_mat").data_ptr(), _chk(pts, "pts").data_ptr(),
         _chk(pts_rot, "pts_rot").data_ptr(), _chk(gt, "gt").data_ptr(), B, N, float(wd),
-        float(sdf_weight), float(mask_weight), int(bool(compute_bf16)), pred.data_ptr(), losses.data_ptr(),
+        float(sdf_weight), float(mask_weight), int(compute_bf16), pred.data_ptr(), losses.data_ptr(),
         head_ready.cuda_event if head_ready is not None else None, ws.data_ptr(), ws.numel(), _stream()))
     return pred, losses
 

@@ -25,6 +25,7 @@ from .weights import WeightStore, variable_shapes
 
 LOSS_NAMES = ("accuracy", "sdf_loss_realvalue", "sdf_loss", "regularization", "overall_loss")
 VARIABLE_ORDER = tuple(variable_shapes())  # == the order of disn_param_layout
+PRECISIONS = {"f32_mfma": 0, "bf16": 1, "f32": 2}   # -> compute_bf16 of disn_train_step
 HEAD_FIRST_VAR = 26  # vgg_16/fc6/weights: everything from here on is final before the conv backward
 
 
@@ -73,10 +74,20 @@ class Trainer:
     def __init__(self, store: WeightStore, device="cuda:0", batch_size: int = 20, base_lr: float = 1e-4,
                  decay_step: int = 200000, decay_rate: float = 0.9, wd: float = 1e-5,
                  sdf_weight: float = 10.0, mask_weight: float = 4.0, beta1: float = 0.5,
-                 beta2: float = 0.999, eps: float = 1e-8, process_group=None, compute_bf16: bool = False):
-        # compute_bf16: mixed precision (bf16 multiply, fp32 accumulate / master / optimizer) for the
-        # forward and data-gradient GEMMs; False = the reference's fp32 everywhere
-        self.compute_bf16 = bool(compute_bf16)
+                 beta2: float = 0.999, eps: float = 1e-8, process_group=None, compute_bf16: bool = False,
+                 precision: Optional[str] = None):
+        # precision of the conv / MLP GEMMs (everything else is fp32 in every mode):
+        #   "f32"       fp32-accurate, the reference's precision: forward and data-gradient GEMMs as a
+        #               three-term bf16 split on the bf16 MFMA pipes (same error as the f32-input MFMA,
+        #               faster), weight gradients on the f32-input MFMA            [default]
+        #   "f32_mfma"  every product on the f32-input MFMA
+        #   "bf16"      mixed precision: bf16 multiply, fp32 accumulate / master weights / optimizer
+        if precision is None:
+            precision = "bf16" if compute_bf16 else "f32"
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (tuple(PRECISIONS),))
+        self.precision = precision
+        self.compute_bf16 = PRECISIONS[precision]
         self.flat = FlatParams(torch.device(device))
         self.params = self.flat.from_store(store)
         self.grads = self.flat.zeros()

@@ -291,7 +291,8 @@ int disn_param_layout(disn_param_layout_t* out);
  * gt [B,N] = the fed 'sdf' (sdf_val - 0.003, train/train_sdf.py:375).
  * pred [B,N] = pred_sdf (un-divided).  losses: 5 device floats =
  * {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}.
- * compute_bf16: 0 = every product on the exact fp32 MFMA (the reference's precision); 1 = mixed
+ * compute_bf16: 0 = every product on the f32-input MFMA; 2 = the same fp32 accuracy, forward and
+ *   data-gradient GEMMs as a three-term bf16 split on the bf16 MFMA pipes (faster); 1 = mixed
  *   precision as BASELINE config 5 names it: the forward and data-gradient GEMMs of the convolutions
  *   (conv1_1 excepted) and of the point MLPs multiply in bf16 with fp32 accumulation; parameters,
  *   activations, gradients and the optimizer stay fp32 ("fp32 master"); weight gradients use bf16

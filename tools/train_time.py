@@ -14,9 +14,9 @@ from disn_amd.weights import WeightStore  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-bf16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
+precision = sys.argv[4] if len(sys.argv) > 4 else "f32"   # f32 | f32_mfma | bf16
 rng = np.random.default_rng(0)
-tr = Trainer(WeightStore.random_init(seed=0, mode="he"), batch_size=B, compute_bf16=bf16)
+tr = Trainer(WeightStore.random_init(seed=0, mode="he"), batch_size=B, precision=precision)
 dev = tr.params.device
 feed = {"imgs": torch.rand((B, 137, 137, 3), device=dev),
         "sample_pc": torch.rand((B, N, 3), device=dev) * 2 - 1,
