@@ -214,14 +214,28 @@ def main():
         print("[bench] main line: %.4g points/s, %.4f ms/step" % (value, line["ms_per_step"]), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_extras:   # roofline / cpu legs: N=1 only (bench contract)
         # ---- roofline of the dominant kernel family: the 13 implicit-GEMM conv launches ----------
+        # Each layer is timed through the kernel the step runs for it at B = 1: the three-term bf16
+        # split ("x3": fp32-accurate, bf16 MFMA pipes) wherever api.hip selects it, else the
+        # f32-input MFMA kernel (conv1_1, K = 27).
         layers, tot_ms, tot_flop = [], 0.0, 0.0
+        x3_off = os.environ.get("DISN_X3", "1") == "0"
         for cin, cout, hw in VGG_LAYERS:
             x = torch.rand((1, hw, hw, cin), device=dev)
-            w = ops.pack_kn(torch.randn((9 * cin, cout), device=dev) * (2.0 / (9 * cin)) ** 0.5)
+            wraw = torch.randn((9 * cin, cout), device=dev) * (2.0 / (9 * cin)) ** 0.5
             b = torch.zeros(cout, device=dev)
-            ms = ev_time_ms(lambda: ops.conv3x3(x, w, b, cout, True), 20, torch)
+            use_x3 = cin != 3 and not x3_off
+            if use_x3:
+                w3 = ops.pack_kn_x3(wraw)
+                wsb = torch.empty(max(ops.lib().disn_conv3x3_x3_workspace_bytes(1, hw, hw, cin, cout), 256),
+                                  dtype=torch.uint8, device=dev)
+                o = torch.empty((1, hw, hw, cout), device=dev)
+                ms = ev_time_ms(lambda: ops.conv3x3_x3(x, w3, b, cout, True, wsb, o), 20, torch)
+            else:
+                w = ops.pack_kn(wraw)
+                ms = ev_time_ms(lambda: ops.conv3x3(x, w, b, cout, True), 20, torch)
             fl = 2.0 * hw * hw * cout * 9 * cin
-            layers.append({"cin": cin, "cout": cout, "hw": hw, "ms": round(ms, 5), "tflops": round(fl / ms / 1e9, 2)})
+            layers.append({"cin": cin, "cout": cout, "hw": hw, "ms": round(ms, 5), "tflops": round(fl / ms / 1e9, 2),
+                           "kernel": "gemm_bf16_mfma<*,*,CONV3,3>" if use_x3 else "gemm_f32_mfma<*,*,CONV3*>"})
             tot_ms += ms
             tot_flop += fl
         ach = tot_flop / tot_ms / 1e9
@@ -234,11 +248,19 @@ def main():
             traffic = pmc["conv_family_per_step"]["hbm_bytes"]
         except Exception:
             pass
-        line["roofline"] = {"kernel": "gemm_f32_mfma<*,*,CONV3> (13 conv launches of one VGG-16 forward, B=1)",
+        # fp32-equivalent ceiling of the three-term method: 6 bf16 MFMAs (2.5 PFLOP/s dense) per product block
+        peak_x3 = 2500.0 / 6.0
+        line["roofline"] = {"kernel": "13 conv launches of one VGG-16 forward, B=1: gemm_bf16_mfma<64,64,CONV3,3> "
+                                      "(three-term bf16 split, fp32-accurate) for 12 layers, gemm_f32_mfma for conv1_1",
                             "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                            "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                            "peak_note": "peak = dense f32-input MFMA (157.3), the arithmetic type of the result; "
+                                         "the three-term kernels issue bf16 MFMAs whose fp32-equivalent ceiling is "
+                                         "2500/6 = 417 TFLOP/s",
+                            "frac_of_three_term_ceiling": ach / peak_x3, "traffic": traffic,
                             "traffic_note": "HBM-side bytes per step of the 13 conv launches (+ fix-ups), PMC pass "
-                                            "profiles/pmc_traffic.json; algorithmic ~150 MB (weights 59 + inputs 36 + outputs 54)",
+                                            "profiles/pmc_traffic.json (taken on the f32-MFMA build); algorithmic "
+                                            "~150 MB (weights 59 + inputs 36 + outputs 54)",
                             "flop_per_step": tot_flop, "ms_per_step": tot_ms, "layers": layers}
         # ---- gather (HBM bound) -----------------------------------------------------------------
         enc = eng.encode(img)

@@ -91,9 +91,9 @@ int conv3x3_impl(const float* in, int B, int H, int W, int Cin, const float* w_p
   p.M = B * H * W; p.N = Cout; p.K = conv_k(Cin);
   p.bp = w_packed; p.bias = bias; p.rows_per_bias = 0;
   p.out = out; p.ldc = Cout; p.relu = relu;
-  // measured at B = 1 (tools/bf16_time.py, prepacked): the three-term kernel wins on every layer but
-  // 112x112 64->128; at B = 8 on all of them
-  if (x3 && Cin != 3 && x3_enabled() && !(B == 1 && Cin == 64 && Cout == 128)) {
+  // measured at B = 1 and B = 8 (tools/bf16_time.py, prepacked): the three-term kernel wins on every
+  // layer with Cin >= 64
+  if (x3 && Cin != 3 && x3_enabled()) {
     DISN_TRY(gemm_bf16_launch(p, GEMM_CONV3, x3, ws, ws ? ws_bytes : 0, st, 3));
     return 0;
   }
@@ -172,7 +172,10 @@ int dense_layer(const float* a1, int lda1, int k1, const float* a2, int lda2, in
   p.M = n; p.N = N; p.K = K;
   p.bp = bp; p.bias = bias; p.rows_per_bias = 0;
   p.out = out; p.ldc = N; p.relu = 1;
-  if (x3 && x3_enabled()) {
+  // measured in the step (profiles/r01k_infer_step_trace.txt): at a 2048-point batch the 64..512-deep
+  // layers are launch-latency bound and the f32-input kernel's stream-K plan is faster (14.6 vs 23 us);
+  // the three-term kernel wins from ~8k rows on, and on the 1984-deep layer always (42 vs 54 us)
+  if (x3 && x3_enabled() && (n >= 8192 || K >= 1024)) {
     DISN_TRY(gemm_bf16_launch(p, GEMM_DENSE, x3, ws, ws ? ws_bytes : 0, st, 3));
     return 0;
   }

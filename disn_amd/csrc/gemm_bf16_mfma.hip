@@ -380,10 +380,15 @@ static hipError_t bf_launch_mode(const BfDev& d, GemmMode mode, hipStream_t st) 
 // split-K factor for a layer with few 64x64 tiles (the 14x14 / 28x28 convolutions, small point
 // sets): enough workgroups for ~3 per CU, at least 4 k-steps each, partials within ws_bytes
 static int bf_splits(long tiles, int ksteps, int M, int N, size_t ws_bytes) {
-  if (tiles >= 512) return 1;
-  int s = (int)((768 + tiles - 1) / tiles);
-  if (s > 8) s = 8;
-  while (s > 1 && (ksteps / s < 4 || (size_t)s * M * N * sizeof(float) > ws_bytes)) --s;
+  static const int forced = [] { const char* e = std::getenv("DISN_BF_SPLITS"); return e ? std::atoi(e) : 0; }();
+  if (tiles >= 512 && !forced) return 1;
+  // measured per layer at B = 1 (DISN_BF_SPLITS sweep): ~1200 workgroups in flight and at least
+  // 12 k-steps per workgroup (a shorter loop does not amortise its prologue and the reduce pass)
+  int s = forced ? forced : (int)((1176 + tiles / 2) / tiles);  // DISN_BF_SPLITS: tuning only
+  if (s < 1) s = 1;
+  if (s > 16) s = 16;
+  const int min_steps = forced ? 1 : 12;
+  while (s > 1 && (ksteps / s < min_steps || (size_t)s * M * N * sizeof(float) > ws_bytes)) --s;
   return s;
 }
 
@@ -448,6 +453,26 @@ int disn_dense_bf16(const float* a1, int lda1, int k1, const float* a2, int lda2
   const size_t pb = bf_packed_bytes(K, N);
   e = disn::gemm_bf16_launch(p, disn::GEMM_DENSE, ws, reinterpret_cast<float*>(static_cast<char*>(ws) + pb),
                              ws_bytes - pb, st, nsplit);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+// the product form of the three-term path: weights already in disn_pack_kn_x3 order
+size_t disn_conv3x3_x3_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 64) return 0;
+  const size_t b = disn::gemm_bf16_ws_bytes(B * H * W, Cout, 9 * Cin);
+  return b > 256 ? b : 256;
+}
+
+int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w_x3, const float* bias,
+                    int Cout, int relu, float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!in || !w_x3 || !bias || !out || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
+  if (Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return DISN_E_SHAPE;
+  disn::GemmParams p{};
+  p.a1 = in; p.H = H; p.W = W; p.Cin = Cin;
+  p.M = B * H * W; p.N = Cout; p.K = 9 * Cin;
+  p.bias = bias; p.out = out; p.ldc = Cout; p.relu = relu;
+  const hipError_t e = disn::gemm_bf16_launch(p, disn::GEMM_CONV3, w_x3, static_cast<float*>(ws),
+                                              ws ? ws_bytes : 0, (hipStream_t)stream, 3);
   return e == hipSuccess ? 0 : (int)e;
 }
 

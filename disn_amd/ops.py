@@ -79,6 +79,21 @@ def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: i
     return out
 
 
+def conv3x3_x3(x: torch.Tensor, w_x3: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool = True,
+               ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """disn_conv3x3 through the three-term bf16 image (pack_kn_x3): fp32-accurate, bf16 MFMA pipes"""
+    x = _chk(x, "x")
+    B, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    if ws is None:
+        ws = _ws(lib().disn_conv3x3_x3_workspace_bytes(B, H, W, Cin, cout), x.device)
+    check("disn_conv3x3_x3", lib().disn_conv3x3_x3(x.data_ptr(), B, H, W, Cin, w_x3.data_ptr(), bias.data_ptr(),
+                                                   cout, int(relu), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   _stream()))
+    return out
+
+
 def maxpool2x2(x: torch.Tensor) -> torch.Tensor:
     x = _chk(x, "x")
     B, H, W, Cc = x.shape

@@ -56,6 +56,11 @@ int disn_pack_kn(const float* w_kn, int K, int N, int Kpad, float* packed, void*
  * K zero-padded to a multiple of 32.  `packed` holds disn_pack_kn_x3_bytes(K, N) bytes. */
 size_t disn_pack_kn_x3_bytes(int K, int N);
 int disn_pack_kn_x3(const float* w_kn, int K, int N, void* packed, void* stream);
+/* disn_conv3x3 on that image (Cin a multiple of 32): what disn_vgg16_forward / disn_encode* run for a
+ * layer whose conv_w_x3 entry is set.  Same result as disn_conv3x3 to fp32 rounding. */
+size_t disn_conv3x3_x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w_x3, const float* bias,
+                    int Cout, int relu, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------- *
  * Row A / E: tf.image.resize_bilinear, TF1 legacy (align_corners=False,    *
