@@ -258,9 +258,10 @@ def main():
                                          "the three-term kernels issue bf16 MFMAs whose fp32-equivalent ceiling is "
                                          "2500/6 = 417 TFLOP/s",
                             "frac_of_three_term_ceiling": ach / peak_x3, "traffic": traffic,
-                            "traffic_note": "HBM-side bytes per step of the 13 conv launches (+ fix-ups), PMC pass "
-                                            "profiles/pmc_traffic.json (taken on the f32-MFMA build); algorithmic "
-                                            "~150 MB (weights 59 + inputs 36 + outputs 54)",
+                            "traffic_note": "memory-side bytes per step of the 13 conv launches + their split-K "
+                                            "reduces (FETCH_SIZE x2 + calibrated WRITE_SIZE; L2 misses served by MALL "
+                                            "count), PMC passes tools/gpu_pmc_traffic.sh -> profiles/pmc_traffic.json; "
+                                            "algorithmic ~180 MB (three-plane bf16 weights 88 + inputs 36 + outputs 54)",
                             "flop_per_step": tot_flop, "ms_per_step": tot_ms, "layers": layers}
         # ---- gather (HBM bound) -----------------------------------------------------------------
         enc = eng.encode(img)

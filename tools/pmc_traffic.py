@@ -1,0 +1,68 @@
+"""profiles/pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over
+tools/prof_kernels.py (PROF_STEPS=1): HBM-side bytes of the conv family of ONE step (every conv GEMM
+launch + the split-K reduce / stream-K fix-up that directly follows it) and of the stand-alone
+gathers.  Corrections as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB) x2 for wide
+coalesced reads; WRITE_SIZE calibrated on the gather at N = 262144, whose output bytes are known.
+usage: python tools/pmc_traffic.py <dir with pmc_FETCH_SIZE.csv pmc_WRITE_SIZE.csv> > profiles/pmc_traffic.json"""
+import collections
+import csv
+import json
+import os
+import sys
+
+d = sys.argv[1]
+
+
+def load(name, counter):
+    out = collections.OrderedDict()
+    for r in csv.DictReader(open(os.path.join(d, name))):
+        if r["Counter_Name"] != counter:
+            continue
+        k = int(r["Dispatch_Id"])
+        e = out.setdefault(k, {"name": r["Kernel_Name"], "grid": r["Grid_Size"], "v": 0.0})
+        e["v"] += float(r["Counter_Value"])
+    return out
+
+
+fetch = load("pmc_FETCH_SIZE.csv", "FETCH_SIZE")
+write = load("pmc_WRITE_SIZE.csv", "WRITE_SIZE")
+ids = sorted(fetch)
+
+
+def is_conv(n):
+    return ("gemm_bf16_mfma" in n and ", 1, " in n) or ("gemm_f32_mfma" in n and (", 1, 0>" in n or ", 2, 0>" in n))
+
+
+# the first step = from the first conv GEMM to the 13th
+conv, taken, count = [], set(), 0
+for pos, i in enumerate(ids):
+    if is_conv(fetch[i]["name"]) and count < 13:
+        conv.append(i)
+        count += 1
+        if pos + 1 < len(ids):
+            nxt = fetch[ids[pos + 1]]["name"]
+            if "splitk_reduce" in nxt or "streamk_fixup" in nxt:
+                conv.append(ids[pos + 1])
+gathers = [i for i in ids if "gather_kernel" in fetch[i]["name"] and "project" not in fetch[i]["name"]]
+g_small = [i for i in gathers if int(fetch[i]["grid"]) < 1_000_000][-1]
+g_big = [i for i in gathers if int(fetch[i]["grid"]) >= 1_000_000][-1]
+cal = 262144 * 5888 / 1024.0 / write[g_big]["v"]
+
+
+def hbm(idl):
+    f = sum(fetch[i]["v"] for i in idl)
+    w = sum(write[i]["v"] for i in idl if i in write)
+    return {"launches": len(idl), "fetch_kb": f, "fetch_corrected_kb": 2 * f, "write_kb": w,
+            "hbm_bytes": (2 * f + cal * w) * 1024.0}
+
+
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_kernels.py workload (PROF_STEPS=1)",
+       "note": "KB as reported; gfx950: FETCH_SIZE x2 for wide coalesced reads; WRITE_SIZE calibrated on the gather",
+       "conv_family_per_step": dict(hbm(conv), kernels=sorted({fetch[i]["name"].split("(")[0] for i in conv}),
+                                    algorithmic_bytes_note="weights 88 MB (three bf16 planes, 6 B/weight) + layer inputs "
+                                    "~36 MB + outputs ~54 MB + split-K partials; the 3x3 taps re-read every input row "
+                                    "through L2/MALL (hits there are counted by FETCH_SIZE)"),
+       "gather_n2048": dict(hbm([g_small]), algorithmic_bytes=2048 * 29440),
+       "gather_n262144": dict(hbm([g_big]), algorithmic_bytes=262144 * 29440),
+       "write_calibration": {"factor": cal, "basis": "gather_kernel at N=262144 writes exactly 262144*5888 B"}}
+print(json.dumps(out, indent=1))
