@@ -573,7 +573,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
                       float* embedding, float* featmap, float* sdf, void* ws, size_t ws_bytes,
                       void* stream) {
   if (!ctx || !vgg_weights_ok(vw) || !mlp_weights_ok(mw) || !img || !trans_mat || !pts || !pts_rot ||
-      !taps || !embedding || !featmap || !sdf || !ws || B <= 0 || N <= 0)
+      !taps || !embedding || !sdf || !ws || B <= 0 || N <= 0)
     return DISN_E_ARG;
   for (int i = 0; i < 5; ++i)
     if (!taps[i]) return DISN_E_ARG;
@@ -608,10 +608,18 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
   const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
-  for (int b = 0; b < B; ++b)
-    DISN_TRY(project_gather_launch(featmap + b * map_stride, trans_mat + (size_t)b * 12,
-                                   pts + (size_t)b * N * 3, N,
-                                   e.q.feat + (size_t)b * N * DISN_FEAT_DIM, ms));
+  for (int b = 0; b < B; ++b) {
+    float* feat_b = e.q.feat + (size_t)b * N * DISN_FEAT_DIM;
+    if (featmap) {
+      DISN_TRY(project_gather_launch(featmap + b * map_stride, trans_mat + (size_t)b * 12,
+                                     pts + (size_t)b * N * 3, N, feat_b, ms));
+    } else {  // no map: up-sample the taps at the touched pixels (bit-identical)
+      const float* tb[5];
+      for (int k = 0; k < 5; ++k) tb[k] = taps[k] + (size_t)b * kTapHw[k] * kTapHw[k] * kTapCh[k];
+      DISN_TRY(project_gather_taps_launch(tb, trans_mat + (size_t)b * 12, pts + (size_t)b * N * 3, N,
+                                          feat_b, ms));
+    }
+  }
   if ((rc = mlp_phase1(mw, B * N, e.q.feat, e.q.mlp, ms))) return rc;
   DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
   if (mlp_aux && (rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;

@@ -269,6 +269,106 @@ hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_
 }
 
 // ---------------------------------------------------------------------------
+// project + gather straight from the five taps (no 110 MB feature map): every feature-map pixel
+// the resampler touches is recomputed from its four tap pixels with resize_kernel's exact
+// expression, so the result is bit-identical to resize -> gather.  16 tap reads per output
+// float4 instead of 4 map reads, but the taps (24 MB per image) stay in L2 / MALL and nothing
+// is written but the [n,1472] rows: the right trade below ~10^4 points per image, where the
+// map would be written (110 MB) to be read once (29 KB per point).
+// ---------------------------------------------------------------------------
+struct TapSet {
+  const float* p[5];
+  float s[5];  // (float)Hin / (float)137, as resize_bilinear_launch computes it
+};
+
+__device__ __forceinline__ float4 tap_pixel(const float* __restrict__ tap, int hw, int ch, float s,
+                                            int oy, int ox, int cl) {
+  const float fy = (float)oy * s, fx = (float)ox * s;
+  const int ylo = (int)floorf(fy), xlo = (int)floorf(fx);
+  const int yhi = min(ylo + 1, hw - 1), xhi = min(xlo + 1, hw - 1);
+  const float yl = fy - (float)ylo, xl = fx - (float)xlo;
+  const float* base = tap + cl;
+  const float4 tl = *reinterpret_cast<const float4*>(base + ((size_t)ylo * hw + xlo) * ch);
+  const float4 tr = *reinterpret_cast<const float4*>(base + ((size_t)ylo * hw + xhi) * ch);
+  const float4 bl = *reinterpret_cast<const float4*>(base + ((size_t)yhi * hw + xlo) * ch);
+  const float4 br = *reinterpret_cast<const float4*>(base + ((size_t)yhi * hw + xhi) * ch);
+  float4 o;
+#define DISN_LERP(f)                             \
+  {                                              \
+    const float top = tl.f + (tr.f - tl.f) * xl; \
+    const float bot = bl.f + (br.f - bl.f) * xl; \
+    o.f = top + (bot - top) * yl;                \
+  }
+  DISN_LERP(x) DISN_LERP(y) DISN_LERP(z) DISN_LERP(w)
+#undef DISN_LERP
+  return o;
+}
+
+__global__ __launch_bounds__(256) void project_gather_taps_kernel(TapSet t,
+                                                                  const float* __restrict__ trans_mat_b,
+                                                                  const float* __restrict__ pts, int n,
+                                                                  float* __restrict__ feat) {
+  const size_t total = (size_t)n * DISN_FEAT4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pt = i / DISN_FEAT4;
+    const int c = (int)(i - pt * DISN_FEAT4) * 4;
+    float x, y;
+    project_point(trans_mat_b, pts[pt * 3], pts[pt * 3 + 1], pts[pt * 3 + 2], x, y);
+    const int k = c < 64 ? 0 : (c < 192 ? 1 : (c < 448 ? 2 : (c < 960 ? 3 : 4)));
+    const int hw = 224 >> k;
+    const int ch = k == 0 ? 64 : (k == 1 ? 128 : (k == 2 ? 256 : 512));
+    const int cl = c - (k == 0 ? 0 : (k == 1 ? 64 : (k == 2 ? 192 : (k == 3 ? 448 : 960))));
+    const float* tap = t.p[k];
+    const float s = t.s[k];
+    // the resampler of sample4, its four map reads replaced by tap_pixel
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool ok = x > -1.0f && y > -1.0f && x < (float)DISN_IMG && y < (float)DISN_IMG;
+    if (ok) {
+      const float fx = floorf(x), fy = floorf(y);
+      const float cx = fx + 1.0f, cy = fy + 1.0f;
+      const float dx = cx - x, dy = cy - y;
+      const int ifx = (int)fx, ify = (int)fy, icx = (int)cx, icy = (int)cy;
+      const float w_ff = dx * dy;
+      const float w_cc = (1.0f - dx) * (1.0f - dy);
+      const float w_fc = dx * (1.0f - dy);
+      const float w_cf = (1.0f - dx) * dy;
+      const bool xf = ifx >= 0 && ifx < DISN_IMG, xc = icx >= 0 && icx < DISN_IMG;
+      const bool yf = ify >= 0 && ify < DISN_IMG, yc = icy >= 0 && icy < DISN_IMG;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v_ff = (xf && yf) ? tap_pixel(tap, hw, ch, s, ify, ifx, cl) : z4;
+      const float4 v_cc = (xc && yc) ? tap_pixel(tap, hw, ch, s, icy, icx, cl) : z4;
+      const float4 v_fc = (xf && yc) ? tap_pixel(tap, hw, ch, s, icy, ifx, cl) : z4;
+      const float4 v_cf = (xc && yf) ? tap_pixel(tap, hw, ch, s, ify, icx, cl) : z4;
+#define DISN_ACC(f)          \
+  {                          \
+    float v = w_ff * v_ff.f; \
+    v = v + w_cc * v_cc.f;   \
+    v = v + w_fc * v_fc.f;   \
+    v = v + w_cf * v_cf.f;   \
+    o.f = v;                 \
+  }
+      DISN_ACC(x) DISN_ACC(y) DISN_ACC(z) DISN_ACC(w)
+#undef DISN_ACC
+    }
+    *reinterpret_cast<float4*>(feat + pt * DISN_FEAT + c) = o;
+  }
+}
+
+hipError_t project_gather_taps_launch(const float* const taps_b[5], const float* trans_mat_b,
+                                      const float* pts, int n, float* feat, hipStream_t st) {
+  TapSet t;
+  for (int k = 0; k < 5; ++k) {
+    t.p[k] = taps_b[k];
+    t.s[k] = (float)(224 >> k) / (float)DISN_IMG;
+  }
+  const size_t total = (size_t)n * DISN_FEAT4;
+  hipLaunchKernelGGL(project_gather_taps_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
+                     trans_mat_b, pts, n, feat);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // dense grid points: numpy.linspace in float64 (i*step + start, last = stop), cast float32
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void grid_points_kernel(GridSpec g, int64_t k0, int64_t k1,

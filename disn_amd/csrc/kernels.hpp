@@ -114,6 +114,9 @@ hipError_t gather_launch(const float* featmap, const float* xy, int B, int N, fl
 // project + gather for a chunk of ONE image (points are a slice of image b's points)
 hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_b, const float* pts,
                                  int n, float* feat, hipStream_t st);
+// same result without a feature map: up-samples the five taps of image b at the touched pixels
+hipError_t project_gather_taps_launch(const float* const taps_b[5], const float* trans_mat_b,
+                                      const float* pts, int n, float* feat, hipStream_t st);
 struct GridSpec {
   double start[3], step[3], stop[3];
   int res;  // R+1

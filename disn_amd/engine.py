@@ -96,7 +96,8 @@ class Encoded:
     resized: torch.Tensor          # [B,224,224,3]   'resized_ref_img'
     taps: List[torch.Tensor]       # conv1_2, conv2_2, conv3_3, conv4_3, conv5_3 (native resolution)
     embedding: torch.Tensor        # [B,1024]        'img_embedding'
-    featmap: torch.Tensor          # [B,137,137,1472] the five resized taps, channel-concatenated
+    featmap: Optional[torch.Tensor]  # [B,137,137,1472] the five resized taps, channel-concatenated;
+                                     # None until something needs it (SdfEngine.featmap_of builds it)
     pred: Optional[torch.Tensor] = None   # pred_sdf of the run that produced this state (encode_query)
 
 
@@ -143,16 +144,26 @@ class SdfEngine:
         return Encoded(resized, taps, emb, featmap)
 
     # rows A..H in one call: what ONE sess.run([pred_sdf]) of the reference executes
-    def encode_query(self, imgs, pts, trans_mat, pts_rot=None):
-        """-> (Encoded, pred_sdf [B,N]).  Nothing cached; B*N <= 65536.  The HBM-bound pieces
-        (feature-map write, fc weight stream) overlap the MFMA-bound ones on a second stream."""
+    def featmap_of(self, enc: Encoded) -> torch.Tensor:
+        """enc.featmap, built from the taps on first use (row E; encode_query does not write it)."""
+        if enc.featmap is None:
+            with torch.cuda.device(self.device):
+                enc.featmap = ops.build_featmap(enc.taps)
+        return enc.featmap
+
+    def encode_query(self, imgs, pts, trans_mat, pts_rot=None, keep_featmap: bool = False):
+        """-> (Encoded, pred_sdf [B,N]).  Nothing cached; B*N <= 65536.  The fc weight stream (HBM
+        bound) overlaps the gather + local MLP on a second stream.  Without ``keep_featmap`` the
+        110 MB/image feature map is not materialised: the gather up-samples the taps at the <= 4
+        pixels a point touches (bit-identical result); a later query()/query_grid() on the returned
+        state builds the map once from the taps."""
         imgs, pts, trans_mat = self._dev(imgs), self._dev(pts), self._dev(trans_mat)
         pts_rot = pts if pts_rot is None else self._dev(pts_rot)
         with torch.cuda.device(self.device):
             from ._lib import lib
             ws = self._workspace("encq", lib().disn_encode_query_workspace_bytes(pts.shape[0], pts.shape[1]))
             resized, taps, emb, featmap, sdf = ops.encode_query(self._ctx, self.weights.vgg, self.weights.mlp,
-                                                                imgs, trans_mat, pts, pts_rot, ws)
+                                                                imgs, trans_mat, pts, pts_rot, ws, keep_featmap)
         return Encoded(resized, taps, emb, featmap), sdf
 
     # rows D, F, G, H
@@ -164,7 +175,7 @@ class SdfEngine:
         with torch.cuda.device(self.device):
             from ._lib import lib
             ws = self._workspace("query", lib().disn_query_workspace_bytes(pts.shape[0], pts.shape[1]))
-            return ops.query(self.weights.mlp, enc.featmap, enc.embedding, trans_mat, pts, pts_rot, ws)
+            return ops.query(self.weights.mlp, self.featmap_of(enc), enc.embedding, trans_mat, pts, pts_rot, ws)
 
     def query_grid(self, enc: Encoded, image_index: int, trans_mat, sdf_params, res: int,
                    k0: int = 0, k1: Optional[int] = None, sdf_weight: float = 10.0,
@@ -183,5 +194,5 @@ class SdfEngine:
             need = (lib().disn_query_grid_ctx_workspace_bytes(k1 - k0) if ctx
                     else lib().disn_query_grid_workspace_bytes(k1 - k0))
             ws = self._workspace("grid", need)
-            return ops.query_grid(self.weights.mlp, enc.featmap[image_index], enc.embedding[image_index:image_index + 1],
+            return ops.query_grid(self.weights.mlp, self.featmap_of(enc)[image_index], enc.embedding[image_index:image_index + 1],
                                   tm.contiguous(), sdf_params, res, k0, k1, sdf_weight, ws, out, ctx)

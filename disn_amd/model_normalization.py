@@ -115,7 +115,7 @@ def get_model(ref_dict, num_point, is_training, bn=False, bn_decay=None, img_siz
 
     # row F (:172-190): point_img_feat [B,N,1,1472]
     def feat_fn(sess, e, xy):
-        return ops.gather(e.featmap, xy).reshape(xy.shape[0], xy.shape[1], 1, FEAT_DIM)
+        return ops.gather(sess.engine.featmap_of(e), xy).reshape(xy.shape[0], xy.shape[1], 1, FEAT_DIM)
 
     point_img_feat = SymTensor('point_img_feat', (B, N, 1, FEAT_DIM), feat_fn, (enc, sample_img_points))
 

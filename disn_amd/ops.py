@@ -164,12 +164,12 @@ def ctx_destroy(ctx: int) -> None:
         check("disn_ctx_destroy", lib().disn_ctx_destroy(ctx))
 
 
-def _alloc_encoder_outputs(B: int, num_classes: int, dev):
+def _alloc_encoder_outputs(B: int, num_classes: int, dev, featmap: bool = True):
     resized = torch.empty((B, 224, 224, 3), dtype=torch.float32, device=dev)
     taps = [torch.empty((B, hw, hw, ch), dtype=torch.float32, device=dev) for hw, ch in TAP_SHAPES]
     emb = torch.empty((B, num_classes), dtype=torch.float32, device=dev)
-    featmap = torch.empty((B, IMG, IMG, FEAT_DIM), dtype=torch.float32, device=dev)
-    return resized, taps, emb, featmap
+    fm = torch.empty((B, IMG, IMG, FEAT_DIM), dtype=torch.float32, device=dev) if featmap else None
+    return resized, taps, emb, fm
 
 
 def encode(ctx: Optional[int], w: VggWeights, img: torch.Tensor, ws: Optional[torch.Tensor] = None):
@@ -190,13 +190,16 @@ def encode(ctx: Optional[int], w: VggWeights, img: torch.Tensor, ws: Optional[to
 
 
 def encode_query(ctx: int, vw: VggWeights, mw: MlpWeights, img: torch.Tensor, trans_mat: torch.Tensor,
-                 pts: torch.Tensor, pts_rot: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
+                 pts: torch.Tensor, pts_rot: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+                 keep_featmap: bool = True):
     """One full evaluation of the graph for pred_sdf (what one sess.run executes), B*N <= 65536.
-    -> (resized224, taps, embedding, featmap, sdf [B,N])"""
+    -> (resized224, taps, embedding, featmap, sdf [B,N]).  keep_featmap=False: the [B,137,137,1472]
+    map is never written (featmap is None); the gather up-samples the taps at the pixels it touches,
+    with the same expression -- sdf is bit-identical."""
     img, pts, trans_mat = _chk(img, "img"), _chk(pts, "pts"), _chk(trans_mat, "trans_mat")
     pts_rot = pts if pts_rot is None else _chk(pts_rot, "pts_rot")
     B, N = pts.shape[0], pts.shape[1]
-    resized, taps, emb, featmap = _alloc_encoder_outputs(B, vw.num_classes, img.device)
+    resized, taps, emb, featmap = _alloc_encoder_outputs(B, vw.num_classes, img.device, keep_featmap)
     sdf = torch.empty((B, N), dtype=torch.float32, device=img.device)
     need = lib().disn_encode_query_workspace_bytes(B, N)
     if need == 0:
@@ -206,8 +209,8 @@ def encode_query(ctx: int, vw: VggWeights, mw: MlpWeights, img: torch.Tensor, tr
     tp = (C.c_void_p * 5)(*[t.data_ptr() for t in taps])
     check("disn_encode_query", lib().disn_encode_query(
         ctx, C.byref(vw), C.byref(mw), img.data_ptr(), trans_mat.data_ptr(), pts.data_ptr(), pts_rot.data_ptr(),
-        B, N, resized.data_ptr(), C.byref(tp), emb.data_ptr(), featmap.data_ptr(), sdf.data_ptr(),
-        ws.data_ptr(), ws.numel(), _stream()))
+        B, N, resized.data_ptr(), C.byref(tp), emb.data_ptr(), featmap.data_ptr() if keep_featmap else None,
+        sdf.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
     return resized, taps, emb, featmap, sdf
 
 

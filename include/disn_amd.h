@@ -207,7 +207,10 @@ int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, 
 
 /* One full evaluation of the reference graph for pred_sdf, i.e. what ONE
  * sess.run([pred_sdf]) executes (test/create_sdf.py:275): rows A..H, nothing cached.
- * B*N <= 65536.  Outputs as disn_encode plus sdf [B,N]. */
+ * B*N <= 65536.  Outputs as disn_encode plus sdf [B,N].  featmap may be NULL: the
+ * [B,137,137,1472] map is an intermediate of the graph, not something sess.run returns, and
+ * with NULL it is never materialised -- the gather bilinearly up-samples the taps on the fly
+ * (same expression, bit-identical sdf; the right trade for N up to ~10^4 per image). */
 size_t disn_encode_query_workspace_bytes(int B, int N);
 int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw,
                       const disn_mlp_weights_t* mw, const float* img, const float* trans_mat,

@@ -241,7 +241,11 @@ def test_encode_query_equals_encode_plus_query(B, N):
         sdf_b = eng.query(enc_b, pts, tms)
         torch.cuda.synchronize()
         assert torch.equal(enc_a.embedding, enc_b.embedding), "embedding differs (rep %d)" % rep
-        assert torch.equal(enc_a.featmap, enc_b.featmap), "featmap differs (rep %d)" % rep
+        assert enc_a.featmap is None          # the default never writes the 110 MB/image map ...
+        sdf_k = eng.encode_query(imgs, pts, tms, keep_featmap=True)
+        assert torch.equal(sdf_k[1], sdf_a), "gather from taps != gather from the map (rep %d)" % rep
+        assert torch.equal(sdf_k[0].featmap, enc_b.featmap), "featmap differs (rep %d)" % rep
+        assert torch.equal(eng.featmap_of(enc_a), enc_b.featmap)   # ... and builds it on demand
         for ta, tb in zip(enc_a.taps, enc_b.taps):
             assert torch.equal(ta, tb)
         if B == 1:   # same row count -> same stream-K plan -> same summation order
