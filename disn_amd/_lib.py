@@ -12,7 +12,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libdisn_amd.so")
+LIB_PATH = os.environ.get("DISN_AMD_LIB") or os.path.join(HERE, "csrc", "libdisn_amd.so")  # env: tools/ablate_x3.sh only
 ABI_VERSION = 2
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())

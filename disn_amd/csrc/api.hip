@@ -81,7 +81,9 @@ bool x3_enabled();
 
 int conv3x3_impl(const float* in, int B, int H, int W, int Cin, const float* w_packed,
                  const float* bias, int Cout, int relu, float* out, float* ws, size_t ws_bytes,
-                 hipStream_t st, const void* x3 = nullptr) {
+                 hipStream_t st, const void* x3 = nullptr, float* pool_out = nullptr,
+                 bool* pooled = nullptr) {
+  if (pooled) *pooled = false;
   if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
   if (!(Cin == 3 || Cin % 32 == 0) || Cout % 64 != 0 || H >= 32768 || W >= 32768)
     return DISN_E_SHAPE;
@@ -94,7 +96,7 @@ int conv3x3_impl(const float* in, int B, int H, int W, int Cin, const float* w_p
   // measured at B = 1 and B = 8 (tools/bf16_time.py, prepacked): the three-term kernel wins on every
   // layer with Cin >= 64
   if (x3 && Cin != 3 && x3_enabled()) {
-    DISN_TRY(gemm_bf16_launch(p, GEMM_CONV3, x3, ws, ws ? ws_bytes : 0, st, 3));
+    DISN_TRY(gemm_bf16_launch(p, GEMM_CONV3, x3, ws, ws ? ws_bytes : 0, st, 3, pool_out, pooled));
     return 0;
   }
   const GemmPlan pl = gemm_plan(p.M, p.N, p.K, ws ? ws_bytes : 0);
@@ -109,6 +111,9 @@ struct MlpWs {
   // local stream: e1l -> h256 -> h512a -> (with feat) h512b -> l5
   // global stream: e1g -> g256 -> g512 -> (with the folded bias) h512b -> g5
   float *e1g, *e1l, *h256, *h512a, *h512b, *g256, *g512, *g5, *l5, *gemm_ws;
+  // split global fold2/conv1 (disn_encode_query): g512 . W4_point before the embedding exists, the
+  // folded bias + ReLU once it does; the tail then runs beside phase 1, on its own GEMM scratch
+  float *g4pre, *zero512, *gemm_ws2;
   size_t gemm_ws_bytes, total;
 };
 
@@ -131,7 +136,7 @@ size_t mlp_gemm_ws(int n) {
   return m;
 }
 
-MlpWs mlp_layout(Bump& b, int n) {
+MlpWs mlp_layout(Bump& b, int n, bool split_g4 = false) {
   MlpWs w;
   const size_t f = sizeof(float);
   w.e1g = b.take((size_t)n * 64 * f);
@@ -145,6 +150,9 @@ MlpWs mlp_layout(Bump& b, int n) {
   w.l5 = b.take((size_t)n * 256 * f);
   w.gemm_ws_bytes = mlp_gemm_ws(n);
   w.gemm_ws = b.take(w.gemm_ws_bytes);
+  w.g4pre = split_g4 ? b.take((size_t)n * 512 * f) : nullptr;
+  w.zero512 = split_g4 ? b.take(512 * f) : nullptr;
+  w.gemm_ws2 = split_g4 ? b.take(w.gemm_ws_bytes) : nullptr;
   w.total = b.off;
   return w;
 }
@@ -166,12 +174,12 @@ bool x3_enabled() {
 
 int dense_layer(const float* a1, int lda1, int k1, const float* a2, int lda2, int K, int n,
                 const float* bp, const float* bias, int N, float* out, float* ws, size_t ws_bytes,
-                hipStream_t st, const void* x3 = nullptr) {
+                hipStream_t st, const void* x3 = nullptr, int relu = 1) {
   GemmParams p{};
   p.a1 = a1; p.lda1 = lda1; p.k1 = k1; p.a2 = a2; p.lda2 = lda2;
   p.M = n; p.N = N; p.K = K;
   p.bp = bp; p.bias = bias; p.rows_per_bias = 0;
-  p.out = out; p.ldc = N; p.relu = 1;
+  p.out = out; p.ldc = N; p.relu = relu;
   // measured in the step (profiles/r01k_infer_step_trace.txt): at a 2048-point batch the 64..512-deep
   // layers are launch-latency bound and the f32-input kernel's stream-K plan is faster (14.6 vs 23 us);
   // the three-term kernel wins from ~8k rows on, and on the 1984-deep layer always (42 vs 54 us)
@@ -226,6 +234,27 @@ int mlp_phase2(const disn_mlp_weights_t* w, int B, int N, const float* gbias, fl
   return 0;
 }
 
+// global fold2/conv1 in two halves.  g4_pre: the 512-deep product on the point features, no bias, no
+// ReLU -- needs only phase 0.  phase2_split: + the per-image folded bias, ReLU (the same fp32 add the
+// fused epilogue does), fold2/conv2 on s.gemm_ws2, then -- behind `joined` -- both conv5 and the sum.
+int mlp_g4_pre(const disn_mlp_weights_t* w, int n, const MlpWs& s, hipStream_t st) {
+  DISN_TRY(hipMemsetAsync(s.zero512, 0, 512 * sizeof(float), st));
+  return dense_layer(s.g512, 512, 512, nullptr, 0, 512, n, w->g_w4_point, s.zero512, 512, s.g4pre,
+                     s.gemm_ws, s.gemm_ws_bytes, st, w->g_x4_point, 0);
+}
+
+int mlp_phase2_split(const disn_mlp_weights_t* w, int B, int N, const float* gbias, float* sdf,
+                     const MlpWs& s, hipStream_t st, hipEvent_t joined) {
+  int rc;
+  const int n = B * N;
+  DISN_TRY(splitk_reduce_launch(s.g4pre, 1, n, 512, gbias, N, 1, s.g512, 512, st));
+  if ((rc = dense_layer(s.g512, 512, 512, nullptr, 0, 512, n, w->g_w5, w->g_b5, 256, s.g5, s.gemm_ws2, s.gemm_ws_bytes, st, w->g_x5))) return rc;
+  DISN_TRY(hipStreamWaitEvent(st, joined, 0));
+  DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, nullptr, nullptr,
+                            1.0f, st));
+  return 0;
+}
+
 // both MLP streams for n points of ONE image on one stream (gbias = that image's folded bias row)
 int mlp_chunk(const disn_mlp_weights_t* w, const float* pts_rot, int n, const float* gbias,
               const float* feat, float* sdf, float* sdf_g, float* sdf_l, float out_div,
@@ -242,14 +271,14 @@ struct QueryWs {
   size_t total;
 };
 
-QueryWs query_layout(void* ws, int B, int chunk, bool need_feat, bool need_pts) {
+QueryWs query_layout(void* ws, int B, int chunk, bool need_feat, bool need_pts, bool split_g4 = false) {
   Bump b(ws);
   QueryWs q;
   q.gbias = b.take((size_t)B * 512 * sizeof(float));
   q.gemv_ws = b.take(gemv_ws_bytes(B, DISN_EMBED_DIM, 512));
   q.feat = need_feat ? b.take((size_t)chunk * DISN_FEAT_DIM * sizeof(float)) : nullptr;
   q.pts = need_pts ? b.take((size_t)chunk * 3 * sizeof(float)) : nullptr;
-  q.mlp = mlp_layout(b, chunk);
+  q.mlp = mlp_layout(b, chunk, split_g4);
   q.total = (b.off + 255) & ~size_t(255);
   return q;
 }
@@ -365,7 +394,8 @@ size_t disn_vgg16_workspace_bytes(int B) {
 
 }  // extern "C"
 
-// struct disn_ctx (kernels.hpp) as used here -- ev 0: fork, 1..5: tap ready, 6: aux done, 7: spare
+// struct disn_ctx (kernels.hpp) as used here -- ev 0: fork, 1..5: tap ready, 6: aux done, 7: features
+// done, 8: g4_pre done
 
 namespace {
 
@@ -397,6 +427,13 @@ int prefetch_blocks() {
   static const int v = [] { const char* e = std::getenv("DISN_PREFETCH_BLOCKS"); return e ? std::atoi(e) : 256; }();
   return v;
 }
+// gather taps 0..3 on the aux stream under the conv5 layers (disn_encode_query without a map).
+// Off: measured 0.622 vs 0.625 ms -- the extra hipEventRecord on the convolution stream drains it
+// (a ~7 us bubble in the kernel trace), which eats what the earlier start buys.
+bool early_gather() {
+  const char* e = std::getenv("DISN_EARLY_GATHER");
+  return e ? std::atoi(e) != 0 : false;
+}
 int resize_bg_blocks() {
   const char* e = std::getenv("DISN_RESIZE_BG_BLOCKS");
   return e ? std::atoi(e) : 256;
@@ -416,7 +453,7 @@ bool vgg_weights_ok(const disn_vgg_weights_t* w) {
 // the MFMA-bound convolutions that follow on `st`.  Returns pool5 in *pool5.
 int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, int B, float* resized,
                  float* const taps[5], float* featmap, const VggWs& s, const float** pool5,
-                 hipStream_t st) {
+                 hipStream_t st, hipEvent_t tap3_ready = nullptr) {
   DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, resized, DISN_VGG_SIZE,
                                   DISN_VGG_SIZE, 3, 0, st));
   const float* x = resized;
@@ -436,10 +473,14 @@ int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, i
     }
     float* out = L.tap >= 0 ? taps[L.tap] : (L.hw >= 112 ? s.bufA : (toggle ? s.bufB : s.bufA));
     if (L.tap < 0 && L.hw < 112) toggle = !toggle;
+    // a layer the pool follows: when its split-K reduce runs anyway, that pass also emits the pool
+    bool pooled = false;
     const int rc = conv3x3_impl(x, B, L.hw, L.hw, L.cin, w->conv_w[i], w->conv_b[i], L.cout, 1,
-                                out, s.gemm_ws, gws_cap, st, w->conv_w_x3[i]);
+                                out, s.gemm_ws, gws_cap, st, w->conv_w_x3[i],
+                                kPoolAfter[i] ? s.bufP : nullptr, &pooled);
     if (rc) return rc;
     x = out;
+    if (L.tap == 3 && tap3_ready) DISN_TRY(hipEventRecord(tap3_ready, st));
     if (L.tap >= 0 && featmap) {
       hipStream_t rs = st;
       int cap = 0;
@@ -454,7 +495,7 @@ int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, i
                                       kTapOff[L.tap], rs, cap));
     }
     if (kPoolAfter[i]) {
-      DISN_TRY(maxpool2x2_launch(x, B, L.hw, L.hw, L.cout, s.bufP, st));
+      if (!pooled) DISN_TRY(maxpool2x2_launch(x, B, L.hw, L.hw, L.cout, s.bufP, st));
       x = s.bufP;
       toggle = false;
     }
@@ -484,7 +525,7 @@ EncQueryWs encq_layout(void* ws, int B, int N, int num_classes) {
   EncQueryWs e;
   e.vgg = vgg_layout(ws, B, num_classes);
   char* base = ws ? static_cast<char*>(ws) + e.vgg.total : nullptr;
-  e.q = query_layout(base, B, B * N, true, false);
+  e.q = query_layout(base, B, B * N, true, false, true);
   e.total = e.vgg.total + e.q.total;
   return e;
 }
@@ -498,7 +539,7 @@ int disn_ctx_create(disn_ctx_t** out) {
   disn_ctx* c = new (std::nothrow) disn_ctx();
   if (!c) return DISN_E_ARG;
   hipError_t e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
-  for (int i = 0; i < 8 && e == hipSuccess; ++i)
+  for (int i = 0; i < 10 && e == hipSuccess; ++i)
     e = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
   if (e != hipSuccess) {
     delete c;
@@ -511,7 +552,7 @@ int disn_ctx_create(disn_ctx_t** out) {
 int disn_ctx_destroy(disn_ctx_t* c) {
   if (!c) return DISN_E_ARG;
   (void)hipStreamSynchronize(c->aux);
-  for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 10; ++i) (void)hipEventDestroy(c->ev[i]);
   (void)hipStreamDestroy(c->aux);
   delete c;
   return 0;
@@ -589,19 +630,36 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   int rc;
   const bool mlp_aux0 = (overlap_mask() & 2) != 0;
   if (mlp_aux0 && (rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, ctx->aux))) return rc;
+  if (mlp_aux0 && (rc = mlp_g4_pre(mw, B * N, e.q.mlp, ctx->aux))) return rc;
+  if (mlp_aux0) DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
   // main: conv stack (+ tap up-samples, on aux only with overlap bit 0)
   const float* pool5 = nullptr;
+  const bool early = !featmap && early_gather();
   rc = vgg_features(ctx, vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap,
-                    e.vgg, &pool5, st);
+                    e.vgg, &pool5, st, early ? ctx->ev[4] : nullptr);
   if (rc) return rc;
   if (!mlp_aux0 && (rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, st))) return rc;
   // aux: behind the feature map (written on `st` when the up-samples are not on aux): gather +
   // local fold2 (MFMA bound), under the 495 MB fc6/fc7/fc8 weight stream (HBM bound) on `st`
   const bool mlp_aux = (overlap_mask() & 2) != 0;
   hipStream_t ms = mlp_aux ? ctx->aux : st;
+  // taps 0..3 (960 of the 1472 channels) are final after conv4_3: gather them on aux under the three
+  // conv5 layers, which leave most of the chip idle at small B
+  const bool early_done = early && mlp_aux;
+  if (early_done) {
+    DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[4], 0));
+    for (int b = 0; b < B; ++b) {
+      const float* tb[5];
+      for (int k = 0; k < 5; ++k) tb[k] = taps[k] + (size_t)b * kTapHw[k] * kTapHw[k] * kTapCh[k];
+      DISN_TRY(project_gather_taps_launch(tb, trans_mat + (size_t)b * 12, pts + (size_t)b * N * 3, N, 0, 4,
+                                          e.q.feat + (size_t)b * N * DISN_FEAT_DIM, ctx->aux));
+    }
+  }
   if (mlp_aux) {
     DISN_TRY(hipEventRecord(ctx->ev[7], st));
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
+    // g4_pre (aux, long done): its wait sits here, next to the record, where `st` drains anyway
+    if (mlp_aux0) DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));
   } else {  // single-stream order: join the aux work issued so far, then continue on `st`
     DISN_TRY(hipEventRecord(ctx->ev[7], ctx->aux));
     DISN_TRY(hipStreamWaitEvent(st, ctx->ev[7], 0));
@@ -617,7 +675,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
       const float* tb[5];
       for (int k = 0; k < 5; ++k) tb[k] = taps[k] + (size_t)b * kTapHw[k] * kTapHw[k] * kTapCh[k];
       DISN_TRY(project_gather_taps_launch(tb, trans_mat + (size_t)b * 12, pts + (size_t)b * N * 3, N,
-                                          feat_b, ms));
+                                          early_done ? 4 : 0, 5, feat_b, ms));
     }
   }
   if ((rc = mlp_phase1(mw, B * N, e.q.feat, e.q.mlp, ms))) return rc;
@@ -625,7 +683,10 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   if (mlp_aux && (rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, mw->g_w4_global, mw->g_b4, 512, 0, e.q.gbias,
                        e.q.gemv_ws, st));
-  // join, then the short tail behind the embedding
+  // the tail behind the embedding; with the split it joins aux only for the final sum
+  if (mlp_aux0 && mlp_aux) {
+    return mlp_phase2_split(mw, B, N, e.q.gbias, sdf, e.q.mlp, st, ctx->ev[6]);
+  }
   DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
   return mlp_phase2(mw, B, N, e.q.gbias, sdf, nullptr, nullptr, 1.0f, e.q.mlp, st);
 }

@@ -307,12 +307,13 @@ __device__ __forceinline__ float4 tap_pixel(const float* __restrict__ tap, int h
 __global__ __launch_bounds__(256) void project_gather_taps_kernel(TapSet t,
                                                                   const float* __restrict__ trans_mat_b,
                                                                   const float* __restrict__ pts, int n,
+                                                                  int c4_begin, int c4_count,
                                                                   float* __restrict__ feat) {
-  const size_t total = (size_t)n * DISN_FEAT4;
+  const size_t total = (size_t)n * c4_count;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
-    const size_t pt = i / DISN_FEAT4;
-    const int c = (int)(i - pt * DISN_FEAT4) * 4;
+    const size_t pt = i / c4_count;
+    const int c = (c4_begin + (int)(i - pt * c4_count)) * 4;
     float x, y;
     project_point(trans_mat_b, pts[pt * 3], pts[pt * 3 + 1], pts[pt * 3 + 2], x, y);
     const int k = c < 64 ? 0 : (c < 192 ? 1 : (c < 448 ? 2 : (c < 960 ? 3 : 4)));
@@ -356,15 +357,18 @@ __global__ __launch_bounds__(256) void project_gather_taps_kernel(TapSet t,
 }
 
 hipError_t project_gather_taps_launch(const float* const taps_b[5], const float* trans_mat_b,
-                                      const float* pts, int n, float* feat, hipStream_t st) {
+                                      const float* pts, int n, int tap_begin, int tap_end, float* feat,
+                                      hipStream_t st) {
+  static const int c4_off[6] = {0, 16, 48, 112, 240, DISN_FEAT4};
   TapSet t;
   for (int k = 0; k < 5; ++k) {
     t.p[k] = taps_b[k];
     t.s[k] = (float)(224 >> k) / (float)DISN_IMG;
   }
-  const size_t total = (size_t)n * DISN_FEAT4;
+  const int c4_begin = c4_off[tap_begin], c4_count = c4_off[tap_end] - c4_begin;
+  const size_t total = (size_t)n * c4_count;
   hipLaunchKernelGGL(project_gather_taps_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
-                     trans_mat_b, pts, n, feat);
+                     trans_mat_b, pts, n, c4_begin, c4_count, feat);
   return hipGetLastError();
 }
 

@@ -163,6 +163,13 @@ hipError_t pack_multi_launch(const PackJobs& jobs, hipStream_t st) {
   return hipGetLastError();
 }
 
+// Ablation switches for tools/ablate_x3.sh (WRONG results; never set in the product build):
+// 1: no residual chain in the A split, 2: B fragments loaded once, 4: A tile loaded once,
+// 8: one MFMA instead of six, 16: no LDS staging of A after the first tile
+#ifndef DISN_ABL
+#define DISN_ABL 0
+#endif
+
 // ---------------------------------------------------------------------------
 struct BfDev {
   GemmParams p;  // p.bp unused; p.K = padded reduction length (multiple of 32)
@@ -171,6 +178,7 @@ struct BfDev {
   int S;      // split-K factor = gridDim.y; S > 1: raw partials to ws [S][M][N], splitk_reduce finishes
   float* ws;
   int nsplit;  // 1: bf16 product; 3: fp32-accurate product from three bf16 terms per operand
+  float* pool_out;  // CONV3 with S > 1: the split-K reduce also writes the 2x2 max pool here
 };
 
 // NS = 1: plain bf16 multiply.  NS = 3: fp32-accurate product on the bf16 pipes ("3xBF16"): every
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = (__bf16)x[e];
-          x[e] -= (float)v[e];  // exact: the residual of a nearest-even bf16 rounding fits in fp32
+          if (!(DISN_ABL & 1)) x[e] -= (float)v[e];  // exact: the residual of a nearest-even bf16 rounding fits in fp32
         }
         *reinterpret_cast<bf16x4*>(&la[pl * PLANE + (arow + 32 * i) * LDA + c4]) = v;
       }
@@ -312,12 +320,12 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
   for (int s = s0; s < s1; ++s) {
     if constexpr (PF2) {
       const int sn = s + 2 < s1 ? s + 2 : s1 - 1;
-      load_a(sn, a2);
-      load_b(sn, b2);
+      if (!(DISN_ABL & 4)) load_a(sn, a2);
+      if (!(DISN_ABL & 2)) load_b(sn, b2);
     } else {
       const int sn = s + 1 < s1 ? s + 1 : s;
-      load_a(sn, a1);
-      load_b(sn, b1);
+      if (!(DISN_ABL & 4)) load_a(sn, a1);
+      if (!(DISN_ABL & 2)) load_b(sn, b1);
     }
     const __bf16* la = &lds[cur * NS * PLANE] + (wm * (BM / 2) + (lane & 31)) * LDA + 8 * (lane >> 5);
 #pragma unroll
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          if (NS == 3) {  // small terms first
+          if (NS == 3 && !(DISN_ABL & 8)) {  // small terms first
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], b0[1][kk][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], b0[2][kk][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], b0[0][kk][j], acc[i][j], 0, 0, 0);
@@ -342,12 +350,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], b0[0][kk][j], acc[i][j], 0, 0, 0);
         }
     }
-    store_a(cur ^ 1, a1);
+    if (!(DISN_ABL & 16)) store_a(cur ^ 1, a1);
     __syncthreads();
     cur ^= 1;
     if constexpr (PF2) {
 #pragma unroll
-      for (int i = 0; i < APASS; ++i) a1[i] = a2[i];
+      for (int i = 0; i < APASS; ++i)
+        if (!(DISN_ABL & 4)) a1[i] = a2[i];
     }
 #pragma unroll
     for (int pl = 0; pl < NS; ++pl)
@@ -355,6 +364,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+          if (DISN_ABL & 2) continue;
           b0[pl][kk][j] = b1[pl][kk][j];
           if constexpr (PF2) b1[pl][kk][j] = b2[pl][kk][j];
         }
@@ -444,6 +454,9 @@ static hipError_t bf_launch_mode(const BfDev& d, GemmMode mode, hipStream_t st) 
   else
     e = deep ? bf_launch_kernel<BM, BN, 1, 2>(d, mode, st) : bf_launch_kernel<BM, BN, 1, 1>(d, mode, st);
   if (e != hipSuccess || d.S == 1) return e;
+  if (d.pool_out)
+    return splitk_reduce_pool_launch(d.ws, d.S, d.p.M / (d.p.H * d.p.W), d.p.H, d.p.W, d.p.N, d.p.bias,
+                                     d.p.relu, d.p.out, d.pool_out, st);
   return splitk_reduce_launch(d.ws, d.S, d.p.M, d.p.N, d.p.bias, 0, d.p.relu, d.p.out, d.p.ldc, st);
 }
 
@@ -470,8 +483,10 @@ size_t gemm_bf16_ws_bytes(int M, int N, int K) {
 // p.bp is ignored; bpk = pack_bf16_launch output for the [p.K][p.N] operand; mode DENSE or CONV3;
 // ws: gemm_bf16_ws_bytes (less is allowed: fewer splits)
 hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk, float* ws,
-                            size_t ws_bytes, hipStream_t st, int nsplit) {
+                            size_t ws_bytes, hipStream_t st, int nsplit, float* pool_out, bool* pooled) {
   BfDev d;
+  d.pool_out = nullptr;
+  if (pooled) *pooled = false;
   d.p = p;
   d.nsplit = nsplit == 3 ? 3 : 1;
   d.bpk = reinterpret_cast<const __bf16*>(bpk);
@@ -487,6 +502,10 @@ hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk,
   }
   d.mtiles = (p.M + 63) / 64; d.ntiles = p.N / 64;
   d.S = ws ? bf_splits((long)d.mtiles * d.ntiles, p.K / 32, p.M, p.N, ws_bytes) : 1;
+  if (pool_out && pooled && d.S > 1 && mode == GEMM_CONV3 && p.ldc == p.N && !(p.H & 1) && !(p.W & 1)) {
+    d.pool_out = pool_out;
+    *pooled = true;
+  }
   return bf_launch_mode<64, 64>(d, mode, st);
 }
 

@@ -462,6 +462,79 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<float4*>(out + m * ldc + c) = v;
 }
 
+// splitk_reduce for a convolution that a 2x2 max pool follows (NHWC rows m = (b*H + y)*W + x): one
+// column group per 2x2 quad, the same s-lane partition and summation order per pixel as
+// splitk_reduce_kernel<SL> (bit-identical outputs), then the four finished pixels are stored (the
+// layer's own output, a tap) and their maximum goes to pool_out -- the pool costs no launch and
+// no re-read.
+template <int SL>
+__global__ __launch_bounds__(256) void splitk_reduce_pool_kernel(const float* __restrict__ ws, int S,
+                                                                 int B, int H, int W, int N,
+                                                                 const float* __restrict__ bias,
+                                                                 int relu, float* __restrict__ out,
+                                                                 float* __restrict__ pool_out) {
+  constexpr int CG = 256 / SL;
+  __shared__ float4 red[SL > 1 ? SL : 1][4][CG];
+  const int sl = threadIdx.x / CG, cg = threadIdx.x - sl * CG;
+  const int Ho = H >> 1, Wo = W >> 1;
+  const size_t n4 = (size_t)N >> 2;
+  const size_t total = (size_t)B * Ho * Wo * n4;
+  const size_t i = (size_t)blockIdx.x * CG + cg;
+  const bool live = i < total;
+  size_t q = live ? i / n4 : 0;
+  const int c = live ? (int)(i - q * n4) * 4 : 0;
+  const int ox = (int)(q % Wo);
+  q /= Wo;
+  const int oy = (int)(q % Ho);
+  const int b = (int)(q / Ho);
+  const size_t m00 = ((size_t)b * H + 2 * oy) * W + 2 * ox;
+  const size_t moff[4] = {0, 1, (size_t)W, (size_t)W + 1};
+  float4 v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const size_t slab = (size_t)B * H * W * N;
+#pragma unroll 6
+    for (int s = sl; s < S; s += SL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 u = *reinterpret_cast<const float4*>(ws + (size_t)s * slab + (m00 + moff[j]) * N + c);
+        v[j].x += u.x; v[j].y += u.y; v[j].z += u.z; v[j].w += u.w;
+      }
+    }
+  }
+  if (SL > 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[sl][j][cg] = v[j];
+    __syncthreads();
+    if (sl != 0) return;
+#pragma unroll
+    for (int k = 1; k < SL; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 u = red[k][j][cg];
+        v[j].x += u.x; v[j].y += u.y; v[j].z += u.z; v[j].w += u.w;
+      }
+  }
+  if (!live) return;
+  const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j].x += bv.x; v[j].y += bv.y; v[j].z += bv.z; v[j].w += bv.w;
+    if (relu) {
+      v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f);
+      v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
+    }
+    *reinterpret_cast<float4*>(out + (m00 + moff[j]) * N + c) = v[j];
+  }
+  float4 o;
+  o.x = fmaxf(fmaxf(v[0].x, v[1].x), fmaxf(v[2].x, v[3].x));
+  o.y = fmaxf(fmaxf(v[0].y, v[1].y), fmaxf(v[2].y, v[3].y));
+  o.z = fmaxf(fmaxf(v[0].z, v[1].z), fmaxf(v[2].z, v[3].z));
+  o.w = fmaxf(fmaxf(v[0].w, v[1].w), fmaxf(v[2].w, v[3].w));
+  *reinterpret_cast<float4*>(pool_out + (((size_t)b * Ho + oy) * Wo + ox) * N + c) = o;
+}
+
 // packed[((k/8)*(N/32) + n/32)*256 + lane*4 + t] = W[8*(k/8) + 4*(lane>>5) + t][32*(n/32)+(lane&31)]
 __global__ __launch_bounds__(256) void pack_kn_kernel(const float* __restrict__ w, int K, int N,
                                                       int Kpad, float* __restrict__ packed) {
@@ -616,6 +689,32 @@ hipError_t splitk_reduce_launch(const float* ws, int S, int M, int N, const floa
     default:
       hipLaunchKernelGGL((splitk_reduce_kernel<16>), dim3(blocks), dim3(256), 0, st, ws, S, M, N,
                          bias, rows_per_bias, relu, out, ldc);
+      break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t splitk_reduce_pool_launch(const float* ws, int S, int B, int H, int W, int N,
+                                     const float* bias, int relu, float* out, float* pool_out,
+                                     hipStream_t st) {
+  // the s-lane count splitk_reduce_launch would use for this layer: same summation order
+  const size_t total = (size_t)B * H * W * (N / 4);
+  const int sl = (total >= 131072 || S < 4) ? 1 : ((total >= 16384 || S < 16) ? 4 : 16);
+  const int cg = 256 / sl;
+  const size_t quads = total / 4;
+  const unsigned blocks = (unsigned)((quads + cg - 1) / cg);
+  switch (sl) {
+    case 1:
+      hipLaunchKernelGGL((splitk_reduce_pool_kernel<1>), dim3(blocks), dim3(256), 0, st, ws, S, B, H, W, N,
+                         bias, relu, out, pool_out);
+      break;
+    case 4:
+      hipLaunchKernelGGL((splitk_reduce_pool_kernel<4>), dim3(blocks), dim3(256), 0, st, ws, S, B, H, W, N,
+                         bias, relu, out, pool_out);
+      break;
+    default:
+      hipLaunchKernelGGL((splitk_reduce_pool_kernel<16>), dim3(blocks), dim3(256), 0, st, ws, S, B, H, W,
+                         N, bias, relu, out, pool_out);
       break;
   }
   return hipGetLastError();

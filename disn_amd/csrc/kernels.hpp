@@ -8,7 +8,7 @@
 // disn_ctx_t of include/disn_amd.h: the auxiliary stream and the fork/join events of one caller stream
 struct disn_ctx {
   hipStream_t aux;
-  hipEvent_t ev[8];
+  hipEvent_t ev[10];
 };
 
 namespace disn {
@@ -61,6 +61,10 @@ hipError_t pack_kn_launch(const float* w, int K, int N, int Kpad, float* packed,
 // out[m][n] = act(sum_s ws[s][m][n] + bias[row(m)][n])
 hipError_t splitk_reduce_launch(const float* ws, int S, int M, int N, const float* bias,
                                 int rows_per_bias, int relu, float* out, int ldc, hipStream_t st);
+// the same for an NHWC conv output [B,H,W,N] (H, W even, ldc = N) + its 2x2 max pool -> pool_out
+hipError_t splitk_reduce_pool_launch(const float* ws, int S, int B, int H, int W, int N,
+                                     const float* bias, int relu, float* out, float* pool_out,
+                                     hipStream_t st);
 
 // ---- gemm_bf16_mfma.hip: bf16-compute variant for the mixed-precision training step ---------
 // view 0: W [K][N]; 1: W^T (reduction N, columns K); 2: flipped 3x3 kernel for conv backward-data
@@ -87,7 +91,8 @@ hipError_t pack_multi_launch(const PackJobs& jobs, hipStream_t st);
 // as gemm_launch (DENSE or CONV3, fp32 in / fp32 out, bias + optional ReLU), multiply in bf16
 size_t gemm_bf16_ws_bytes(int M, int N, int K);  // split-K partials for layers with few tiles
 hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk, float* ws,
-                            size_t ws_bytes, hipStream_t st, int nsplit = 1);
+                            size_t ws_bytes, hipStream_t st, int nsplit = 1, float* pool_out = nullptr,
+                            bool* pooled = nullptr);
 
 // ---- gemv.hip ------------------------------------------------------------
 int gemv_splits(int K, int N);
@@ -114,9 +119,11 @@ hipError_t gather_launch(const float* featmap, const float* xy, int B, int N, fl
 // project + gather for a chunk of ONE image (points are a slice of image b's points)
 hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_b, const float* pts,
                                  int n, float* feat, hipStream_t st);
-// same result without a feature map: up-samples the five taps of image b at the touched pixels
+// same result without a feature map: up-samples taps [tap_begin, tap_end) of image b at the touched
+// pixels and writes their channels of the [n,1472] rows
 hipError_t project_gather_taps_launch(const float* const taps_b[5], const float* trans_mat_b,
-                                      const float* pts, int n, float* feat, hipStream_t st);
+                                      const float* pts, int n, int tap_begin, int tap_end, float* feat,
+                                      hipStream_t st);
 struct GridSpec {
   double start[3], step[3], stop[3];
   int res;  // R+1
