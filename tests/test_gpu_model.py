@@ -257,6 +257,38 @@ def test_encode_query_equals_encode_plus_query(B, N):
     report_close("encode_query vs oracle", sdf_a.cpu().numpy(), ref["pred_sdf"][..., 0], ATOL, RTOL)
 
 
+def test_vgg_stack_equals_standalone_layer_chain():
+    """The conv stack inside disn_encode (split-K reduce that also emits the 2x2 max pool for conv2_2,
+    conv3_3, conv4_3, conv5_3; a separate pool after conv1_2) == the same layers one by one through
+    disn_conv3x3_x3 + disn_maxpool2x2, bit for bit at every tap."""
+    from disn_amd import ops
+    from disn_amd.engine import SdfEngine
+    from disn_amd.weights import WeightStore, VGG_CONV_NAMES
+    store = WeightStore.random_init(3, mode="he")
+    eng = SdfEngine(store)
+    rng = np.random.default_rng(5)
+    for B in (1, 2):
+        imgs = rng.random((B, 137, 137, 3), dtype=np.float32)
+        enc = eng.encode(imgs)
+        x = enc.resized
+        tap = 0
+        pool_after = {1, 3, 6, 9, 12}
+        for i, nm in enumerate(VGG_CONV_NAMES):
+            w = store[nm + "/weights"]
+            kh, kw, ci, co = w.shape
+            wd = torch.from_numpy(np.ascontiguousarray(w.reshape(kh * kw * ci, co))).cuda()
+            bias = torch.from_numpy(store[nm + "/biases"]).cuda()
+            if ci == 3:
+                x = ops.conv3x3(x, ops.pack_kn(wd), bias, co, True)
+            else:
+                x = ops.conv3x3_x3(x, ops.pack_kn_x3(wd), bias, co, True)
+            if i in pool_after:
+                assert torch.equal(x, enc.taps[tap]), "tap %d (%s) differs, B=%d" % (tap, nm, B)
+                tap += 1
+                x = ops.maxpool2x2(x)
+        assert tap == 5
+
+
 def test_pipelined_grid_equals_sequential():
     """disn_query_grid_ctx (gather of chunk i+1 on the aux stream under the MLP of chunk i, double
     buffer + events) == disn_query_grid, bit for bit, on a range with several chunks and a ragged
