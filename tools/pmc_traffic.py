@@ -47,6 +47,7 @@ gathers = [i for i in ids if "gather_kernel" in fetch[i]["name"] and "project" n
 g_small = [i for i in gathers if int(fetch[i]["grid"]) < 1_000_000][-1]
 g_big = [i for i in gathers if int(fetch[i]["grid"]) >= 1_000_000][-1]
 cal = 262144 * 5888 / 1024.0 / write[g_big]["v"]
+g_taps = [i for i in ids if "project_gather_taps_kernel" in fetch[i]["name"]]
 
 
 def hbm(idl):
@@ -64,5 +65,9 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tool
                                     "through L2/MALL (hits there are counted by FETCH_SIZE)"),
        "gather_n2048": dict(hbm([g_small]), algorithmic_bytes=2048 * 29440),
        "gather_n262144": dict(hbm([g_big]), algorithmic_bytes=262144 * 29440),
+       "gather_from_taps_n2048": (dict(hbm(g_taps[-1:]), algorithmic_bytes=2048 * (16 * 5888 + 5888),
+                                       note="disn_encode_query: 16 tap reads + 1 write per output float4; the taps "
+                                            "(24.5 MB) are L2 / MALL resident, so the memory-side bytes are far "
+                                            "below the algorithmic reads") if g_taps else None),
        "write_calibration": {"factor": cal, "basis": "gather_kernel at N=262144 writes exactly 262144*5888 B"}}
 print(json.dumps(out, indent=1))

@@ -1,6 +1,6 @@
 """Small, bounded workload for rocprofv3 passes (kernel trace or one PMC counter at a time):
-2 full steps (encode + 2048-point query), one standalone gather at 2048 and 262144 points,
-one 65536-point query."""
+PROF_STEPS x (encode + 2048-point query), one standalone gather at 2048 and 262144 points,
+one 65536-point query, one single-call step (disn_encode_query: no feature map, gather from the taps)."""
 import os, sys
 import numpy as np
 import torch
@@ -27,5 +27,6 @@ for n in (2048, 262144):
 p = torch.rand((1, 65536, 3), device="cuda") * 2 - 1
 for _ in range(2):
     eng.query(enc, p, tm)
+eng.encode_query(img, pts, tm)
 torch.cuda.synchronize()
 print("done")
