@@ -13,7 +13,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DISN_AMD_LIB") or os.path.join(HERE, "csrc", "libdisn_amd.so")  # env: tools/ablate_x3.sh only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -42,10 +42,11 @@ MLP_FIELDS = ("g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3", "g_w4_point", "g_w
 
 
 MLP_X3_FIELDS = ("g_x2", "g_x3", "g_x4_point", "g_x5", "l_x2", "l_x3", "l_x4", "l_x5")   # optional
+MLP_FOLD_FIELDS = ("l_w4_point", "l_w4_feat", "l_x4_point", "l_x4_feat")   # optional: *_folded entry points
 
 
 class MlpWeights(C.Structure):  # disn_mlp_weights_t
-    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS + MLP_X3_FIELDS]
+    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS + MLP_X3_FIELDS + MLP_FOLD_FIELDS]
 
 
 CAM_FIELDS = tuple("%s_%s%d" % (t, k, i) for t in "srt" for i in (1, 2, 3) for k in "wb")
@@ -124,6 +125,11 @@ SIGNATURES = {
     "disn_query_grid_workspace_bytes": (Z, [L]),
     "disn_query_grid": (I, [C.POINTER(MlpWeights), P, P, P, C.POINTER(C.c_double * 6), I, L, L, F, P,
                             P, Z, P]),
+    "disn_fold_local_workspace_bytes": (Z, []),
+    "disn_fold_local": (I, [C.POINTER(MlpWeights), P, P, P, Z, P]),
+    "disn_query_folded": (I, [C.POINTER(MlpWeights), P, P, P, P, P, I, I, P, P, Z, P]),
+    "disn_query_grid_folded": (I, [C.POINTER(MlpWeights), P, P, P, C.POINTER(C.c_double * 6), I, L, L, F, P,
+                                   P, Z, P]),
 }
 
 _LIB: Optional[C.CDLL] = None

@@ -151,7 +151,7 @@ MlpWs mlp_layout(Bump& b, int n, bool split_g4 = false) {
   w.gemm_ws_bytes = mlp_gemm_ws(n);
   w.gemm_ws = b.take(w.gemm_ws_bytes);
   w.g4pre = split_g4 ? b.take((size_t)n * 512 * f) : nullptr;
-  w.zero512 = split_g4 ? b.take(512 * f) : nullptr;
+  w.zero512 = b.take(512 * f);
   w.gemm_ws2 = split_g4 ? b.take(w.gemm_ws_bytes) : nullptr;
   w.total = b.off;
   return w;
@@ -238,7 +238,7 @@ int mlp_phase2(const disn_mlp_weights_t* w, int B, int N, const float* gbias, fl
 // ReLU -- needs only phase 0.  phase2_split: + the per-image folded bias, ReLU (the same fp32 add the
 // fused epilogue does), fold2/conv2 on s.gemm_ws2, then -- behind `joined` -- both conv5 and the sum.
 int mlp_g4_pre(const disn_mlp_weights_t* w, int n, const MlpWs& s, hipStream_t st) {
-  DISN_TRY(hipMemsetAsync(s.zero512, 0, 512 * sizeof(float), st));
+  DISN_TRY(hipMemsetAsync(s.zero512, 0, 512 * sizeof(float), st));  // on this stream: no cross-stream order
   return dense_layer(s.g512, 512, 512, nullptr, 0, 512, n, w->g_w4_point, s.zero512, 512, s.g4pre,
                      s.gemm_ws, s.gemm_ws_bytes, st, w->g_x4_point, 0);
 }
@@ -253,6 +253,28 @@ int mlp_phase2_split(const disn_mlp_weights_t* w, int B, int N, const float* gbi
   DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, nullptr, nullptr,
                             1.0f, st));
   return 0;
+}
+
+// phase 1 with the folded local fold2/conv1 (disn_fold_local): 512-deep product on the point
+// features, then + resampled pmap rows + bias, ReLU in one gather pass; no [n,1472] feature rows
+int mlp_phase1_folded(const disn_mlp_weights_t* w, int n, const float* pmap_b, const float* trans_mat_b,
+                      const float* pts, const MlpWs& s, hipStream_t st) {
+  int rc;
+  if ((rc = dense_layer(s.h512a, 512, 512, nullptr, 0, 512, n, w->l_w4_point, s.zero512, 512, s.h512b,
+                        s.gemm_ws, s.gemm_ws_bytes, st, w->l_x4_point, 0)))
+    return rc;
+  DISN_TRY(gather_fold_launch(pmap_b, trans_mat_b, pts, n, s.h512b, w->l_b4, s.h512b, st));
+  return dense_layer(s.h512b, 512, 512, nullptr, 0, 512, n, w->l_w5, w->l_b5, 256, s.l5, s.gemm_ws,
+                     s.gemm_ws_bytes, st, w->l_x5);
+}
+
+int mlp_chunk_folded(const disn_mlp_weights_t* w, const float* pts, const float* pts_rot, int n,
+                     const float* gbias, const float* pmap_b, const float* trans_mat_b, float* sdf,
+                     float out_div, const MlpWs& s, hipStream_t st) {
+  int rc;
+  if ((rc = mlp_phase0(w, pts_rot, n, s, st))) return rc;
+  if ((rc = mlp_phase1_folded(w, n, pmap_b, trans_mat_b, pts, s, st))) return rc;
+  return mlp_phase2(w, 1, n, gbias, sdf, nullptr, nullptr, out_div, s, st);
 }
 
 // both MLP streams for n points of ONE image on one stream (gbias = that image's folded bias row)
@@ -772,6 +794,82 @@ int disn_query(const disn_mlp_weights_t* w, const float* featmap, const float* e
                                nullptr, nullptr, 1.0f, q.mlp, st);
       if (rc) return rc;
     }
+  return 0;
+}
+
+// ---- folded local stream (include/disn_amd.h) -------------------------------------------------
+static const int kMapPixels = DISN_IMG_H * DISN_IMG_W;
+
+static size_t fold_gemm_ws() {
+  const size_t a = gemm_plan(kMapPixels, 512, DISN_FEAT_DIM).ws_bytes;
+  const size_t b = gemm_bf16_ws_bytes(kMapPixels, 512, DISN_FEAT_DIM);
+  return ((a > b ? a : b) + 255) & ~size_t(255);
+}
+
+size_t disn_fold_local_workspace_bytes(void) { return 2048 + fold_gemm_ws(); }
+
+int disn_fold_local(const disn_mlp_weights_t* w, const float* featmap_b, float* pmap, void* ws,
+                    size_t ws_bytes, void* stream) {
+  if (!mlp_weights_ok(w) || !w->l_w4_point || !w->l_w4_feat || !featmap_b || !pmap || !ws)
+    return DISN_E_ARG;
+  if (ws_bytes < disn_fold_local_workspace_bytes()) return DISN_E_WS;
+  hipStream_t st = (hipStream_t)stream;
+  float* zero = static_cast<float*>(ws);
+  DISN_TRY(hipMemsetAsync(zero, 0, 512 * sizeof(float), st));
+  return dense_layer(featmap_b, DISN_FEAT_DIM, DISN_FEAT_DIM, nullptr, 0, DISN_FEAT_DIM, kMapPixels,
+                     w->l_w4_feat, zero, 512, pmap, reinterpret_cast<float*>(static_cast<char*>(ws) + 2048),
+                     ws_bytes - 2048, st, w->l_x4_feat, 0);
+}
+
+int disn_query_folded(const disn_mlp_weights_t* w, const float* pmap, const float* embedding,
+                      const float* trans_mat, const float* pts, const float* pts_rot, int B, int N,
+                      float* sdf, void* ws, size_t ws_bytes, void* stream) {
+  if (!mlp_weights_ok(w) || !w->l_w4_point || !pmap || !embedding || !trans_mat || !pts || !pts_rot ||
+      !sdf || !ws || B <= 0 || N <= 0)
+    return DISN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunk = chunk_for(N);
+  const QueryWs q = query_layout(ws, B, chunk, true, false);
+  if (q.total > ws_bytes) return DISN_E_WS;
+  DISN_TRY(hipMemsetAsync(q.mlp.zero512, 0, 512 * sizeof(float), st));
+  DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
+                       q.gemv_ws, st));
+  for (int b = 0; b < B; ++b)
+    for (int n0 = 0; n0 < N; n0 += chunk) {
+      const int n = (N - n0) < chunk ? (N - n0) : chunk;
+      const size_t o = (size_t)b * N + n0;
+      const int rc = mlp_chunk_folded(w, pts + o * 3, pts_rot + o * 3, n, q.gbias + (size_t)b * 512,
+                                      pmap + (size_t)b * kMapPixels * 512, trans_mat + (size_t)b * 12,
+                                      sdf + o, 1.0f, q.mlp, st);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+int disn_query_grid_folded(const disn_mlp_weights_t* w, const float* pmap, const float* embedding,
+                           const float* trans_mat, const double* sdf_params_host, int R,
+                           int64_t k0, int64_t k1, float sdf_weight, float* out, void* ws,
+                           size_t ws_bytes, void* stream) {
+  GridSpec g;
+  if (!mlp_weights_ok(w) || !w->l_w4_point || !pmap || !embedding || !trans_mat || !out || !ws ||
+      !grid_spec(sdf_params_host, R, &g))
+    return DISN_E_ARG;
+  const int64_t total = (int64_t)g.res * g.res * g.res;
+  if (k0 < 0 || k1 > total || k0 >= k1 || sdf_weight == 0.0f) return DISN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunk = chunk_for(k1 - k0);
+  const QueryWs q = query_layout(ws, 1, chunk, true, true);
+  if (q.total > ws_bytes) return DISN_E_WS;
+  DISN_TRY(hipMemsetAsync(q.mlp.zero512, 0, 512 * sizeof(float), st));
+  DISN_TRY(gemv_launch(embedding, 1, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
+                       q.gemv_ws, st));
+  for (int64_t k = k0; k < k1; k += chunk) {
+    const int n = (int)((k1 - k) < chunk ? (k1 - k) : chunk);
+    DISN_TRY(grid_points_launch(g, k, k + n, q.pts, st));
+    const int rc = mlp_chunk_folded(w, q.pts, q.pts, n, q.gbias, pmap, trans_mat, out + (k - k0),
+                                    sdf_weight, q.mlp, st);
+    if (rc) return rc;
+  }
   return 0;
 }
 

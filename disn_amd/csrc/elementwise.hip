@@ -373,6 +373,73 @@ hipError_t project_gather_taps_launch(const float* const taps_b[5], const float*
 }
 
 // ---------------------------------------------------------------------------
+// folded local fold2/conv1: h[pt][:] = relu(pre[pt][:] + sum_c w_c * pmap[pixel_c][:] + bias), where
+// pmap = featmap . W_feat ([137*137][512], disn_fold_local) and pre = point512 . W_point.  The
+// resampler weights / validity are sample4's; one thread per (point, float4 of the 512 outputs), so a
+// point's four 2-KiB pmap rows are read by 128 consecutive lanes.  In place (h may be pre).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_fold_kernel(const float* __restrict__ pmap_b,
+                                                          const float* __restrict__ trans_mat_b,
+                                                          const float* __restrict__ pts, int n,
+                                                          const float* pre,
+                                                          const float* __restrict__ bias, float* h) {
+  const size_t total = (size_t)n * 128;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pt = i >> 7;
+    const int c = (int)(i & 127) * 4;
+    float x, y;
+    project_point(trans_mat_b, pts[pt * 3], pts[pt * 3 + 1], pts[pt * 3 + 2], x, y);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool ok = x > -1.0f && y > -1.0f && x < (float)DISN_IMG && y < (float)DISN_IMG;
+    if (ok) {
+      const float fx = floorf(x), fy = floorf(y);
+      const float cx = fx + 1.0f, cy = fy + 1.0f;
+      const float dx = cx - x, dy = cy - y;
+      const int ifx = (int)fx, ify = (int)fy, icx = (int)cx, icy = (int)cy;
+      const float w_ff = dx * dy;
+      const float w_cc = (1.0f - dx) * (1.0f - dy);
+      const float w_fc = dx * (1.0f - dy);
+      const float w_cf = (1.0f - dx) * dy;
+      const bool xf = ifx >= 0 && ifx < DISN_IMG, xc = icx >= 0 && icx < DISN_IMG;
+      const bool yf = ify >= 0 && ify < DISN_IMG, yc = icy >= 0 && icy < DISN_IMG;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* m = pmap_b + c;
+      const float4 v_ff = (xf && yf) ? *reinterpret_cast<const float4*>(m + ((size_t)ify * DISN_IMG + ifx) * 512) : z4;
+      const float4 v_cc = (xc && yc) ? *reinterpret_cast<const float4*>(m + ((size_t)icy * DISN_IMG + icx) * 512) : z4;
+      const float4 v_fc = (xf && yc) ? *reinterpret_cast<const float4*>(m + ((size_t)icy * DISN_IMG + ifx) * 512) : z4;
+      const float4 v_cf = (xc && yf) ? *reinterpret_cast<const float4*>(m + ((size_t)ify * DISN_IMG + icx) * 512) : z4;
+#define DISN_ACC(f)           \
+  {                           \
+    float t = w_ff * v_ff.f;  \
+    t = t + w_cc * v_cc.f;    \
+    t = t + w_fc * v_fc.f;    \
+    t = t + w_cf * v_cf.f;    \
+    v.f = t;                  \
+  }
+      DISN_ACC(x) DISN_ACC(y) DISN_ACC(z) DISN_ACC(w)
+#undef DISN_ACC
+    }
+    const float4 p4 = *reinterpret_cast<const float4*>(pre + pt * 512 + c);
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + c);
+    float4 o;
+    o.x = fmaxf((p4.x + v.x) + b4.x, 0.f);
+    o.y = fmaxf((p4.y + v.y) + b4.y, 0.f);
+    o.z = fmaxf((p4.z + v.z) + b4.z, 0.f);
+    o.w = fmaxf((p4.w + v.w) + b4.w, 0.f);
+    *reinterpret_cast<float4*>(h + pt * 512 + c) = o;
+  }
+}
+
+hipError_t gather_fold_launch(const float* pmap_b, const float* trans_mat_b, const float* pts, int n,
+                              const float* pre, const float* bias, float* h, hipStream_t st) {
+  const size_t total = (size_t)n * 128;
+  hipLaunchKernelGGL(gather_fold_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, pmap_b,
+                     trans_mat_b, pts, n, pre, bias, h);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // dense grid points: numpy.linspace in float64 (i*step + start, last = stop), cast float32
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void grid_points_kernel(GridSpec g, int64_t k0, int64_t k1,

@@ -124,6 +124,9 @@ hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_
 hipError_t project_gather_taps_launch(const float* const taps_b[5], const float* trans_mat_b,
                                       const float* pts, int n, int tap_begin, int tap_end, float* feat,
                                       hipStream_t st);
+// folded local fold2/conv1 (disn_fold_local): h = relu(pre + resample(pmap_b)(pts) + bias), [n,512]
+hipError_t gather_fold_launch(const float* pmap_b, const float* trans_mat_b, const float* pts, int n,
+                              const float* pre, const float* bias, float* h, hipStream_t st);
 struct GridSpec {
   double start[3], step[3], stop[3];
   int res;  // R+1

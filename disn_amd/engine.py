@@ -79,7 +79,10 @@ class DeviceWeights:
         w4g = W(g, "fold2/conv1")                          # [512+1024, 512]: rows 0-511 point, rest global
         m.g_w4_point = pk(w4g[:512], "g_x4_point")
         m.g_w4_global = dev(w4g[512:]).data_ptr()          # folded into a per-image bias by the library
-        m.l_w4 = pk(W(l, "fold2/conv1"), "l_x4")           # [512+1472, 512]
+        w4l = W(l, "fold2/conv1")                          # [512+1472, 512]
+        m.l_w4 = pk(w4l, "l_x4")
+        m.l_w4_point = pk(w4l[:512], "l_x4_point")         # the two halves on their own: the folded
+        m.l_w4_feat = pk(w4l[512:], "l_x4_feat")           # local stream (disn_fold_local)
         for f in MLP_FIELDS:
             assert getattr(m, f), f
         self.mlp = m
@@ -88,6 +91,11 @@ class DeviceWeights:
     def _hold(self, t: torch.Tensor) -> torch.Tensor:
         self._keep.append(t)
         return t
+
+
+# Points per image from which folding the local fold2/conv1 into the feature map pays: the fold is a
+# 28 GFLOP GEMM (~0.25 ms), it saves 1.5 MFLOP and 15 KB of gather traffic per point (~12 ns).
+FOLD_MIN_POINTS = 32768
 
 
 @dataclass
@@ -99,6 +107,7 @@ class Encoded:
     featmap: Optional[torch.Tensor]  # [B,137,137,1472] the five resized taps, channel-concatenated;
                                      # None until something needs it (SdfEngine.featmap_of builds it)
     pred: Optional[torch.Tensor] = None   # pred_sdf of the run that produced this state (encode_query)
+    pmap: Optional[dict] = None           # image index -> [137*137,512] folded feature map (SdfEngine.pmap_of)
 
 
 class SdfEngine:
@@ -151,6 +160,17 @@ class SdfEngine:
                 enc.featmap = ops.build_featmap(enc.taps)
         return enc.featmap
 
+    def pmap_of(self, enc: Encoded, image_index: int) -> torch.Tensor:
+        """Feature map of one image times the feature rows of the local fold2/conv1 (disn_fold_local),
+        built on first use: what the folded queries gather from (4 x 512 instead of 4 x 1472 floats per
+        point, and a 512- instead of a 1984-deep layer)."""
+        if enc.pmap is None:
+            enc.pmap = {}
+        if image_index not in enc.pmap:
+            with torch.cuda.device(self.device):
+                enc.pmap[image_index] = ops.fold_local(self.weights.mlp, self.featmap_of(enc)[image_index])
+        return enc.pmap[image_index]
+
     def encode_query(self, imgs, pts, trans_mat, pts_rot=None, keep_featmap: bool = False):
         """-> (Encoded, pred_sdf [B,N]).  Nothing cached; B*N <= 65536.  The fc weight stream (HBM
         bound) overlaps the gather + local MLP on a second stream.  Without ``keep_featmap`` the
@@ -167,20 +187,31 @@ class SdfEngine:
         return Encoded(resized, taps, emb, featmap), sdf
 
     # rows D, F, G, H
-    def query(self, enc: Encoded, pts, trans_mat, pts_rot=None) -> torch.Tensor:
-        """pts [B,N,3] -> pred_sdf [B,N] (un-divided, as models/model_normalization.py:204)."""
+    def query(self, enc: Encoded, pts, trans_mat, pts_rot=None, fold: Optional[bool] = None) -> torch.Tensor:
+        """pts [B,N,3] -> pred_sdf [B,N] (un-divided, as models/model_normalization.py:204).
+        ``fold``: use the folded local stream (pmap_of; same math re-associated, fp32-rounding-level
+        difference); default: from FOLD_MIN_POINTS points per image on."""
         pts = self._dev(pts)
         pts_rot = pts if pts_rot is None else self._dev(pts_rot)
         trans_mat = self._dev(trans_mat)
         with torch.cuda.device(self.device):
             from ._lib import lib
             ws = self._workspace("query", lib().disn_query_workspace_bytes(pts.shape[0], pts.shape[1]))
+            if fold is None:
+                fold = pts.shape[1] >= FOLD_MIN_POINTS
+            if fold:
+                B = pts.shape[0]
+                pm = self.pmap_of(enc, 0) if B == 1 else torch.stack([self.pmap_of(enc, b) for b in range(B)])
+                return ops.query_folded(self.weights.mlp, pm, enc.embedding, trans_mat, pts, pts_rot, ws)
             return ops.query(self.weights.mlp, self.featmap_of(enc), enc.embedding, trans_mat, pts, pts_rot, ws)
 
     def query_grid(self, enc: Encoded, image_index: int, trans_mat, sdf_params, res: int,
                    k0: int = 0, k1: Optional[int] = None, sdf_weight: float = 10.0,
-                   out: Optional[torch.Tensor] = None, pipelined: bool = False) -> torch.Tensor:
-        """rows J + D..H + '/SDF_WEIGHT' for grid points k0..k1-1 of one image.  ``pipelined``:
+                   out: Optional[torch.Tensor] = None, pipelined: bool = False,
+                   fold: Optional[bool] = None) -> torch.Tensor:
+        """rows J + D..H + '/SDF_WEIGHT' for grid points k0..k1-1 of one image.  ``fold``: folded local
+        stream (see query(); the default unless ``pipelined`` -- for every range size, so that any slice of
+        a grid equals the same slice of the whole grid up to the GEMM plan).  ``pipelined``:
         chunk i+1's gather on the auxiliary stream under chunk i's MLP (same result; measured
         0.564 s vs 0.561 s sequential for 257^3 -- the gather's traffic slows the GEMMs as much as
         it hides, so it is off by default)."""
@@ -191,6 +222,13 @@ class SdfEngine:
         with torch.cuda.device(self.device):
             from ._lib import lib
             ctx = self._ctx if pipelined else None
+            if fold is None:
+                fold = not pipelined
+            if fold:
+                ws = self._workspace("grid", lib().disn_query_grid_workspace_bytes(k1 - k0))
+                return ops.query_grid(self.weights.mlp, None, enc.embedding[image_index:image_index + 1],
+                                      tm.contiguous(), sdf_params, res, k0, k1, sdf_weight, ws, out, None,
+                                      self.pmap_of(enc, image_index))
             need = (lib().disn_query_grid_ctx_workspace_bytes(k1 - k0) if ctx
                     else lib().disn_query_grid_workspace_bytes(k1 - k0))
             ws = self._workspace("grid", need)

@@ -276,6 +276,44 @@ def query(w: MlpWeights, featmap: torch.Tensor, embedding: torch.Tensor, trans_m
     return out
 
 
+MAP_PIXELS = IMG * IMG
+
+
+def fold_local(w: MlpWeights, featmap_b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pmap [137*137, 512] = featmap of ONE image [137,137,1472] times the 1472 feature rows of the local
+    fold2/conv1 (disn_fold_local): what the *_folded queries gather from instead of the feature map."""
+    featmap_b = _chk(featmap_b, "featmap")
+    if featmap_b.numel() != MAP_PIXELS * FEAT_DIM:
+        raise ValueError("fold_local takes the feature map of one image")
+    if out is None:
+        out = torch.empty((MAP_PIXELS, 512), dtype=torch.float32, device=featmap_b.device)
+    ws = _ws(lib().disn_fold_local_workspace_bytes(), featmap_b.device)
+    check("disn_fold_local", lib().disn_fold_local(C.byref(w), featmap_b.data_ptr(), out.data_ptr(),
+                                                   ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def query_folded(w: MlpWeights, pmap: torch.Tensor, embedding: torch.Tensor, trans_mat: torch.Tensor,
+                 pts: torch.Tensor, pts_rot: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """query() with pmap [B,137*137,512] (fold_local per image) in place of the feature map"""
+    pts = _chk(pts, "pts")
+    pts_rot = pts if pts_rot is None else _chk(pts_rot, "pts_rot")
+    B, N, _ = pts.shape
+    if pmap.numel() != B * MAP_PIXELS * 512:
+        raise ValueError("pmap must be [B,137*137,512]")
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=pts.device)
+    need = lib().disn_query_workspace_bytes(B, N)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, pts.device)
+    check("disn_query_folded", lib().disn_query_folded(
+        C.byref(w), _chk(pmap, "pmap").data_ptr(), _chk(embedding, "embedding").data_ptr(),
+        _chk(trans_mat, "trans_mat").data_ptr(), pts.data_ptr(), pts_rot.data_ptr(), B, N,
+        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
 def _params6(sdf_params) -> C.Array:
     vals = [float(v) for v in sdf_params]
     if len(vals) != 6:
@@ -294,13 +332,23 @@ def grid_points(sdf_params, res: int, k0: int, k1: int, device) -> torch.Tensor:
 def query_grid(w: MlpWeights, featmap: torch.Tensor, embedding: torch.Tensor, trans_mat: torch.Tensor,
                sdf_params, res: int, k0: int, k1: int, sdf_weight: float = 10.0,
                ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-               ctx: Optional[int] = None) -> torch.Tensor:
+               ctx: Optional[int] = None, pmap: Optional[torch.Tensor] = None) -> torch.Tensor:
     """SDF of grid points k0..k1-1 of ONE image (featmap [137,137,1472] or [1,...]).  With a
-    context the chunks are pipelined over two streams (gather of chunk i+1 under the MLP of chunk i)."""
-    dev = featmap.device
+    context the chunks are pipelined over two streams (gather of chunk i+1 under the MLP of chunk i).
+    With ``pmap`` (fold_local of that image) the folded local stream runs and featmap is not read."""
+    dev = pmap.device if pmap is not None else featmap.device
     if out is None:
         out = torch.empty((k1 - k0,), dtype=torch.float32, device=dev)
     p6 = _params6(sdf_params)
+    if pmap is not None:
+        need = lib().disn_query_grid_workspace_bytes(k1 - k0)
+        if ws is None or ws.numel() < need:
+            ws = _ws(need, dev)
+        check("disn_query_grid_folded", lib().disn_query_grid_folded(
+            C.byref(w), _chk(pmap, "pmap").data_ptr(), _chk(embedding, "embedding").data_ptr(),
+            _chk(trans_mat, "trans_mat").data_ptr(), C.byref(p6), res, k0, k1, float(sdf_weight),
+            out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return out
     if ctx:
         need = lib().disn_query_grid_ctx_workspace_bytes(k1 - k0)
         if ws is None or ws.numel() < need:

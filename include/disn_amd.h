@@ -38,7 +38,7 @@ extern "C" {
 #define DISN_E_WS (-3)    /* workspace too small */
 
 /* ABI version of this header; disn_abi_version() returns the library's. */
-#define DISN_ABI_VERSION 2
+#define DISN_ABI_VERSION 3
 int disn_abi_version(void);
 
 /* ---------------------------------------------------------------------- *
@@ -163,6 +163,11 @@ typedef struct disn_mlp_weights {
   /* optional (NULL = not used): disn_pack_kn_x3 images of g_w2, g_w3, g_w4_point, g_w5, l_w2, l_w3,
    * l_w4, l_w5 (same matrices as the fp32 packs); see disn_vgg_weights_t.conv_w_x3 */
   const void *g_x2, *g_x3, *g_x4_point, *g_x5, *l_x2, *l_x3, *l_x4, *l_x5;
+  /* optional, for the *_folded entry points: the local fold2/conv1 matrix [1984][512] as two
+   * disn_pack_kn images -- rows 0..511 (point features) and rows 512..1983 (the 1472 gathered
+   * channels) -- and their disn_pack_kn_x3 images (optional again) */
+  const float *l_w4_point, *l_w4_feat;
+  const void *l_x4_point, *l_x4_feat;
 } disn_mlp_weights_t;
 
 /* scratch for one launch over B images x N points (N per image) */
@@ -183,6 +188,25 @@ int disn_query(const disn_mlp_weights_t* w, const float* featmap, const float* e
                const float* trans_mat, const float* pts, const float* pts_rot, int B, int N,
                float* sdf, void* ws, size_t ws_bytes, void* stream);
 
+/* Folded local stream.  sdfprediction_imgfeat/fold2/conv1 (models/sdfnet.py:180-182) is linear in
+ * the gathered feature, and the gather (models/model_normalization.py:172-190) is a 4-tap weighted
+ * sum of feature-map pixels, so
+ *     feat(p) . W_feat = sum_c w_c(p) * (featmap[pixel_c(p)] . W_feat).
+ * disn_fold_local multiplies ONE image's feature map with the 1472 feature rows of that layer once,
+ * pmap [137*137][512] (28 GFLOP, 38 MB); the *_folded queries then gather 4 x 512 floats per point
+ * from pmap instead of 4 x 1472 from featmap and run a 512-deep instead of a 1984-deep layer:
+ * 1.5 MFLOP and 15 KB of traffic less per point (pays from ~2e4 points per image; the dense grid
+ * has 1.7e7).  Same math re-associated: results differ from disn_query / disn_query_grid by fp32
+ * rounding only (measured <= 2e-6 of the output scale; tests/test_gpu_fold.py).
+ * w->l_w4_point and w->l_w4_feat must be set. */
+size_t disn_fold_local_workspace_bytes(void);
+int disn_fold_local(const disn_mlp_weights_t* w, const float* featmap_b, float* pmap, void* ws,
+                    size_t ws_bytes, void* stream);
+/* disn_query with pmap [B][137*137][512] in place of featmap; workspace as disn_query */
+int disn_query_folded(const disn_mlp_weights_t* w, const float* pmap, const float* embedding,
+                      const float* trans_mat, const float* pts, const float* pts_rot, int B, int N,
+                      float* sdf, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------- *
  * Concurrency context.  The path mixes MFMA-bound launches (convolutions,  *
  * MLP GEMMs) with HBM-bound ones (the 110 MB feature-map write, the 495 MB *
@@ -190,7 +214,7 @@ int disn_query(const disn_mlp_weights_t* w, const float* featmap, const float* e
  * disn_encode_query run the latter on the context's auxiliary HIP stream,  *
  * forked from and joined back into the caller's `stream` with events, so   *
  * the caller still sees ONE asynchronous operation on `stream`.            *
- * A context owns one non-blocking stream and eight events; use one context *
+ * A context owns one non-blocking stream and ten events; use one context *
  * per caller stream (not thread-safe).  ctx may be NULL for disn_encode    *
  * (everything then runs on `stream`).                                      *
  * ---------------------------------------------------------------------- */
@@ -235,6 +259,13 @@ int disn_query_grid(const disn_mlp_weights_t* w, const float* featmap, const flo
                     const float* trans_mat, const double* sdf_params_host, int R, int64_t k0,
                     int64_t k1, float sdf_weight, float* out, void* ws, size_t ws_bytes,
                     void* stream);
+
+/* disn_query_grid with pmap [137*137][512] (disn_fold_local) in place of featmap; workspace as
+ * disn_query_grid */
+int disn_query_grid_folded(const disn_mlp_weights_t* w, const float* pmap, const float* embedding,
+                           const float* trans_mat, const double* sdf_params_host, int R,
+                           int64_t k0, int64_t k1, float sdf_weight, float* out, void* ws,
+                           size_t ws_bytes, void* stream);
 
 /* disn_query_grid, chunk-pipelined over the context's two streams: the HBM-bound front of chunk
  * i+1 (grid points, projection, gather) runs under the MFMA-bound MLP of chunk i.  Same result. */

@@ -299,7 +299,7 @@ def test_pipelined_grid_equals_sequential():
     enc = eng.encode(O.synth_inputs(1, 1, 8)["imgs"])
     R, sp = 128, [-1, -0.9, -0.8, 1, 0.9, 0.8]
     k0, k1 = 1000, 1000 + 5 * 65536 + 4321
-    ref = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, k0, k1, pipelined=False).clone()
+    ref = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, k0, k1, pipelined=False, fold=False).clone()
     for rep in range(4):
         got = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, k0, k1, pipelined=True)
         torch.cuda.synchronize()

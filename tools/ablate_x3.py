@@ -61,4 +61,21 @@ else:
             f()
         e.record(); e.synchronize()
         out.append("%5.1f" % (s.elapsed_time(e) / 20 * 1e3))
+    # the point MLP at 65536 rows (all dense layers on the three-term kernel, 128x128 tiles): whole query
+    from disn_amd.engine import SdfEngine
+    from disn_amd.weights import WeightStore
+    import numpy as np
+    eng = SdfEngine(WeightStore.random_init(0, mode="he"))
+    img = torch.rand((1, 137, 137, 3), device=dev)
+    tm = torch.tensor(np.array([[[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], [68, 68, 2.0]]], dtype=np.float32), device=dev)
+    enc = eng.encode(img)
+    p = torch.rand((1, 65536, 3), device=dev) * 2 - 1
+    f = lambda: eng.query(enc, p, tm)
+    f(); f(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10):
+        f()
+    e.record(); e.synchronize()
+    out.append("| query65536 %6.1f us" % (s.elapsed_time(e) / 10 * 1e3))
     print(" ".join(out))
