@@ -30,7 +30,6 @@ SOURCES = {
     "train.hip": [],
     "cam_head.hip": [],
     "mlp_small.hip": [],
-    "mlp_fused.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],
     "marching_cubes.hip": ["-ffp-contract=off"],
     "api.hip": [],
