@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256) void gather_fold_kernel(const float* __restric
 hipError_t gather_fold_launch(const float* pmap_b, const float* trans_mat_b, const float* pts, int n,
                               const float* pre, const float* bias, float* h, hipStream_t st) {
   const size_t total = (size_t)n * 128;
+  // (block count 1024 .. 65536: no effect on the chunk time, tools/fold_time.py)
   hipLaunchKernelGGL(gather_fold_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, pmap_b,
                      trans_mat_b, pts, n, pre, bias, h);
   return hipGetLastError();
