@@ -670,12 +670,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   const bool early_done = early && mlp_aux;
   if (early_done) {
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[4], 0));
-    for (int b = 0; b < B; ++b) {
-      const float* tb[5];
-      for (int k = 0; k < 5; ++k) tb[k] = taps[k] + (size_t)b * kTapHw[k] * kTapHw[k] * kTapCh[k];
-      DISN_TRY(project_gather_taps_launch(tb, trans_mat + (size_t)b * 12, pts + (size_t)b * N * 3, N, 0, 4,
-                                          e.q.feat + (size_t)b * N * DISN_FEAT_DIM, ctx->aux));
-    }
+    DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 4, e.q.feat, ctx->aux));
   }
   if (mlp_aux) {
     DISN_TRY(hipEventRecord(ctx->ev[7], st));
@@ -688,17 +683,13 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
   const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
-  for (int b = 0; b < B; ++b) {
-    float* feat_b = e.q.feat + (size_t)b * N * DISN_FEAT_DIM;
-    if (featmap) {
+  if (featmap) {
+    for (int b = 0; b < B; ++b)
       DISN_TRY(project_gather_launch(featmap + b * map_stride, trans_mat + (size_t)b * 12,
-                                     pts + (size_t)b * N * 3, N, feat_b, ms));
-    } else {  // no map: up-sample the taps at the touched pixels (bit-identical)
-      const float* tb[5];
-      for (int k = 0; k < 5; ++k) tb[k] = taps[k] + (size_t)b * kTapHw[k] * kTapHw[k] * kTapCh[k];
-      DISN_TRY(project_gather_taps_launch(tb, trans_mat + (size_t)b * 12, pts + (size_t)b * N * 3, N,
-                                          early_done ? 4 : 0, 5, feat_b, ms));
-    }
+                                     pts + (size_t)b * N * 3, N,
+                                     e.q.feat + (size_t)b * N * DISN_FEAT_DIM, ms));
+  } else {  // no map: up-sample the taps at the touched pixels (bit-identical), all images in one launch
+    DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, early_done ? 4 : 0, 5, e.q.feat, ms));
   }
   if ((rc = mlp_phase1(mw, B * N, e.q.feat, e.q.mlp, ms))) return rc;
   DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));

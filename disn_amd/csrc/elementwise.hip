@@ -278,7 +278,8 @@ hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_
 // ---------------------------------------------------------------------------
 struct TapSet {
   const float* p[5];
-  float s[5];  // (float)Hin / (float)137, as resize_bilinear_launch computes it
+  float s[5];      // (float)Hin / (float)137, as resize_bilinear_launch computes it
+  size_t stride[5];  // floats per image of each tap
 };
 
 __device__ __forceinline__ float4 tap_pixel(const float* __restrict__ tap, int hw, int ch, float s,
@@ -305,22 +306,24 @@ __device__ __forceinline__ float4 tap_pixel(const float* __restrict__ tap, int h
 }
 
 __global__ __launch_bounds__(256) void project_gather_taps_kernel(TapSet t,
-                                                                  const float* __restrict__ trans_mat_b,
-                                                                  const float* __restrict__ pts, int n,
-                                                                  int c4_begin, int c4_count,
+                                                                  const float* __restrict__ trans_mat,
+                                                                  const float* __restrict__ pts, int B,
+                                                                  int n, int c4_begin, int c4_count,
                                                                   float* __restrict__ feat) {
-  const size_t total = (size_t)n * c4_count;
+  // B images x n points each (rows image-major); tap k of image b at t.p[k] + b * t.stride[k]
+  const size_t total = (size_t)B * n * c4_count;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
     const size_t pt = i / c4_count;
     const int c = (c4_begin + (int)(i - pt * c4_count)) * 4;
+    const int b = (int)(pt / n);
     float x, y;
-    project_point(trans_mat_b, pts[pt * 3], pts[pt * 3 + 1], pts[pt * 3 + 2], x, y);
+    project_point(trans_mat + (size_t)b * 12, pts[pt * 3], pts[pt * 3 + 1], pts[pt * 3 + 2], x, y);
     const int k = c < 64 ? 0 : (c < 192 ? 1 : (c < 448 ? 2 : (c < 960 ? 3 : 4)));
     const int hw = 224 >> k;
     const int ch = k == 0 ? 64 : (k == 1 ? 128 : (k == 2 ? 256 : 512));
     const int cl = c - (k == 0 ? 0 : (k == 1 ? 64 : (k == 2 ? 192 : (k == 3 ? 448 : 960))));
-    const float* tap = t.p[k];
+    const float* tap = t.p[k] + (size_t)b * t.stride[k];
     const float s = t.s[k];
     // the resampler of sample4, its four map reads replaced by tap_pixel
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -356,19 +359,21 @@ __global__ __launch_bounds__(256) void project_gather_taps_kernel(TapSet t,
   }
 }
 
-hipError_t project_gather_taps_launch(const float* const taps_b[5], const float* trans_mat_b,
-                                      const float* pts, int n, int tap_begin, int tap_end, float* feat,
-                                      hipStream_t st) {
+hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
+                                      const float* pts, int B, int n, int tap_begin, int tap_end,
+                                      float* feat, hipStream_t st) {
   static const int c4_off[6] = {0, 16, 48, 112, 240, DISN_FEAT4};
+  static const int ch[5] = {64, 128, 256, 512, 512};
   TapSet t;
   for (int k = 0; k < 5; ++k) {
-    t.p[k] = taps_b[k];
+    t.p[k] = taps[k];
     t.s[k] = (float)(224 >> k) / (float)DISN_IMG;
+    t.stride[k] = (size_t)(224 >> k) * (224 >> k) * ch[k];
   }
   const int c4_begin = c4_off[tap_begin], c4_count = c4_off[tap_end] - c4_begin;
-  const size_t total = (size_t)n * c4_count;
+  const size_t total = (size_t)B * n * c4_count;
   hipLaunchKernelGGL(project_gather_taps_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
-                     trans_mat_b, pts, n, c4_begin, c4_count, feat);
+                     trans_mat, pts, B, n, c4_begin, c4_count, feat);
   return hipGetLastError();
 }
 

@@ -119,11 +119,11 @@ hipError_t gather_launch(const float* featmap, const float* xy, int B, int N, fl
 // project + gather for a chunk of ONE image (points are a slice of image b's points)
 hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_b, const float* pts,
                                  int n, float* feat, hipStream_t st);
-// same result without a feature map: up-samples taps [tap_begin, tap_end) of image b at the touched
-// pixels and writes their channels of the [n,1472] rows
-hipError_t project_gather_taps_launch(const float* const taps_b[5], const float* trans_mat_b,
-                                      const float* pts, int n, int tap_begin, int tap_end, float* feat,
-                                      hipStream_t st);
+// same result without a feature map, for B images x n points each: up-samples taps [tap_begin,
+// tap_end) (taps[k] = [B,hw,hw,ch] NHWC) at the touched pixels, writes their channels of [B*n,1472]
+hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
+                                      const float* pts, int B, int n, int tap_begin, int tap_end,
+                                      float* feat, hipStream_t st);
 // folded local fold2/conv1 (disn_fold_local): h = relu(pre + resample(pmap_b)(pts) + bias), [n,512]
 hipError_t gather_fold_launch(const float* pmap_b, const float* trans_mat_b, const float* pts, int n,
                               const float* pre, const float* bias, float* h, hipStream_t st);

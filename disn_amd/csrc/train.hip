@@ -208,7 +208,7 @@ struct TrainWs {
   float* conv_bT[13];
   float *g_t2, *g_t3, *g_t4, *g_t5, *l_t2, *l_t3, *l_t4, *l_t4f, *l_t5;
   // activations
-  float *resized, *act[13], *pooled[13], *h6, *h7, *emb, *gbias, *featmap, *xy, *feat;
+  float *resized, *act[13], *pooled[13], *h6, *h7, *emb, *gbias, *xy, *feat;
   float *g1, *l1, *g2, *l2, *g3, *l3, *g4, *l4, *g5, *l5;
   // gradients
   float *dpred, *d5, *d4, *d3, *d2, *d1, *dfeat, *dmap, *dgbias, *demb, *dz7, *dz6, *dpool5, *gA, *gB;
@@ -264,7 +264,6 @@ TrainWs train_layout(void* ws, int B, int N) {
   }
   t.h6 = b.take((size_t)B * 4096); t.h7 = b.take((size_t)B * 4096);
   t.emb = b.take((size_t)B * DISN_EMBED_DIM); t.gbias = b.take((size_t)B * 512);
-  t.featmap = b.take((size_t)B * 137 * 137 * DISN_FEAT_DIM);
   t.xy = b.take((size_t)M * 2); t.feat = b.take((size_t)M * DISN_FEAT_DIM);
   t.g1 = b.take((size_t)M * 64); t.l1 = b.take((size_t)M * 64);
   t.g2 = b.take((size_t)M * 256); t.l2 = b.take((size_t)M * 256);
@@ -494,9 +493,6 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
     const ConvL& c = kConv[i];
     DISN_RC(conv_fwd(x, B, c.hw, c.hw, c.cin, t.conv_p[i], P(2 * i + 1), c.cout, 1, t.act[i], gws, gwb, st, bf));
     x = t.act[i];
-    if (c.tap >= 0)
-      DISN_TRY(resize_bilinear_launch(t.act[i], B, c.hw, c.hw, c.cout, t.featmap, DISN_IMG_H,
-                                      DISN_IMG_W, DISN_FEAT_DIM, kTapOff[c.tap], st));
     if (c.pool) {
       DISN_TRY(maxpool2x2_launch(x, B, c.hw, c.hw, c.cout, t.pooled[i], st));
       x = t.pooled[i];
@@ -515,7 +511,14 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
                        t.gbias, t.fc_ws, as));
   if (ctx) DISN_TRY(hipEventRecord(ctx->ev[2], as));
   DISN_TRY(project_launch(pts, trans_mat, B, N, t.xy, st));
-  DISN_TRY(gather_launch(t.featmap, t.xy, B, N, t.feat, st));
+  // rows E + F without the [B,137,137,1472] map (880 MB at B = 8): the five taps are up-sampled at the
+  // pixels each point touches, bit-identical to resize -> gather; the backward needs xy and dfeat only
+  {
+    const float* tb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 13; ++i)
+      if (kConv[i].tap >= 0) tb[kConv[i].tap] = t.act[i];
+    DISN_TRY(project_gather_taps_launch(tb, trans_mat, pts, B, N, 0, 5, t.feat, st));
+  }
   DISN_TRY(pt_embed_launch(pts_rot, M, P(V_G), P(V_G + 1), P(V_L), P(V_L + 1), t.g1, t.l1, st));
   DISN_RC(dense_fwd(t.l1, 64, 64, nullptr, 0, 64, (int)M, t.l_p2, P(V_L + 3), 256, 1, t.l2, gws, gwb, st, bf));
   DISN_RC(dense_fwd(t.l2, 256, 256, nullptr, 0, 256, (int)M, t.l_p3, P(V_L + 5), 512, 1, t.l3, gws, gwb, st, bf));
