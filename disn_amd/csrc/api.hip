@@ -449,13 +449,6 @@ int prefetch_blocks() {
   static const int v = [] { const char* e = std::getenv("DISN_PREFETCH_BLOCKS"); return e ? std::atoi(e) : 256; }();
   return v;
 }
-// gather taps 0..3 on the aux stream under the conv5 layers (disn_encode_query without a map).
-// Off: measured 0.622 vs 0.625 ms -- the extra hipEventRecord on the convolution stream drains it
-// (a ~7 us bubble in the kernel trace), which eats what the earlier start buys.
-bool early_gather() {
-  const char* e = std::getenv("DISN_EARLY_GATHER");
-  return e ? std::atoi(e) != 0 : false;
-}
 int resize_bg_blocks() {
   const char* e = std::getenv("DISN_RESIZE_BG_BLOCKS");
   return e ? std::atoi(e) : 256;
@@ -475,7 +468,7 @@ bool vgg_weights_ok(const disn_vgg_weights_t* w) {
 // the MFMA-bound convolutions that follow on `st`.  Returns pool5 in *pool5.
 int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, int B, float* resized,
                  float* const taps[5], float* featmap, const VggWs& s, const float** pool5,
-                 hipStream_t st, hipEvent_t tap3_ready = nullptr) {
+                 hipStream_t st) {
   DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, resized, DISN_VGG_SIZE,
                                   DISN_VGG_SIZE, 3, 0, st));
   const float* x = resized;
@@ -502,7 +495,6 @@ int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, i
                                 kPoolAfter[i] ? s.bufP : nullptr, &pooled);
     if (rc) return rc;
     x = out;
-    if (L.tap == 3 && tap3_ready) DISN_TRY(hipEventRecord(tap3_ready, st));
     if (L.tap >= 0 && featmap) {
       hipStream_t rs = st;
       int cap = 0;
@@ -644,63 +636,54 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   hipStream_t st = (hipStream_t)stream;
   const EncQueryWs e = encq_layout(ws, B, N, vw->num_classes);
   if (e.total > ws_bytes) return DISN_E_WS;
-  // fork
-  DISN_TRY(hipEventRecord(ctx->ev[0], st));
-  DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
-  // aux, from the fork on: the point-only MLP layers (phase 0) -- small GEMMs that fill the
-  // quantisation holes of the convolutions running on `st`
+  // Two streams.  `st` (the caller's): resize, conv stack, fc6..fc8, the folded global bias, then the
+  // short tail of the global MLP stream.  ctx->aux: everything of the MLPs that does not need the
+  // embedding -- from the fork on the point-only layers of both streams and the point half of the
+  // global fold2/conv1 (small GEMMs in the quantisation holes of the convolutions); behind conv5_3 the
+  // gather and the local fold2 layers (MFMA bound), under the 495 MB fc weight stream (HBM bound).
+  // Every event record / wait on `st` drains it (~6 us in the kernel trace): there are three.
+  // DISN_OVERLAP=0 (debugging) runs the same launches on `st` alone.
+  const bool two = (overlap_mask() & 2) != 0;
+  hipStream_t ms = two ? ctx->aux : st;
   int rc;
-  const bool mlp_aux0 = (overlap_mask() & 2) != 0;
-  if (mlp_aux0 && (rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, ctx->aux))) return rc;
-  if (mlp_aux0 && (rc = mlp_g4_pre(mw, B * N, e.q.mlp, ctx->aux))) return rc;
-  if (mlp_aux0) DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
-  // main: conv stack (+ tap up-samples, on aux only with overlap bit 0)
-  const float* pool5 = nullptr;
-  const bool early = !featmap && early_gather();
-  rc = vgg_features(ctx, vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap,
-                    e.vgg, &pool5, st, early ? ctx->ev[4] : nullptr);
-  if (rc) return rc;
-  if (!mlp_aux0 && (rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, st))) return rc;
-  // aux: behind the feature map (written on `st` when the up-samples are not on aux): gather +
-  // local fold2 (MFMA bound), under the 495 MB fc6/fc7/fc8 weight stream (HBM bound) on `st`
-  const bool mlp_aux = (overlap_mask() & 2) != 0;
-  hipStream_t ms = mlp_aux ? ctx->aux : st;
-  // taps 0..3 (960 of the 1472 channels) are final after conv4_3: gather them on aux under the three
-  // conv5 layers, which leave most of the chip idle at small B
-  const bool early_done = early && mlp_aux;
-  if (early_done) {
-    DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[4], 0));
-    DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 4, e.q.feat, ctx->aux));
+  DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (also orders aux behind the caller's inputs)
+  DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
+  if (two) {
+    if ((rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, ctx->aux))) return rc;
+    if ((rc = mlp_g4_pre(mw, B * N, e.q.mlp, ctx->aux))) return rc;
+    DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
   }
-  if (mlp_aux) {
+  const float* pool5 = nullptr;
+  rc = vgg_features(ctx, vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg,
+                    &pool5, st);
+  if (rc) return rc;
+  if (two) {
     DISN_TRY(hipEventRecord(ctx->ev[7], st));
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
-    // g4_pre (aux, long done): its wait sits here, next to the record, where `st` drains anyway
-    if (mlp_aux0) DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));
-  } else {  // single-stream order: join the aux work issued so far, then continue on `st`
-    DISN_TRY(hipEventRecord(ctx->ev[7], ctx->aux));
-    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[7], 0));
+    // g4_pre finished long ago: its wait sits next to the record, where `st` drains anyway
+    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));
+  } else {
+    if ((rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, st))) return rc;
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
-  const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
   if (featmap) {
+    const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
     for (int b = 0; b < B; ++b)
       DISN_TRY(project_gather_launch(featmap + b * map_stride, trans_mat + (size_t)b * 12,
                                      pts + (size_t)b * N * 3, N,
                                      e.q.feat + (size_t)b * N * DISN_FEAT_DIM, ms));
   } else {  // no map: up-sample the taps at the touched pixels (bit-identical), all images in one launch
-    DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, early_done ? 4 : 0, 5, e.q.feat, ms));
+    DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, ms));
   }
   if ((rc = mlp_phase1(mw, B * N, e.q.feat, e.q.mlp, ms))) return rc;
-  DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
-  if (mlp_aux && (rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
+  if (two) {
+    DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
+    if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
+  }
   DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, mw->g_w4_global, mw->g_b4, 512, 0, e.q.gbias,
                        e.q.gemv_ws, st));
-  // the tail behind the embedding; with the split it joins aux only for the final sum
-  if (mlp_aux0 && mlp_aux) {
+  if (two)  // bias + ReLU of the split layer, fold2/conv2, then -- behind ev[6] -- the final sum
     return mlp_phase2_split(mw, B, N, e.q.gbias, sdf, e.q.mlp, st, ctx->ev[6]);
-  }
-  DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
   return mlp_phase2(mw, B, N, e.q.gbias, sdf, nullptr, nullptr, 1.0f, e.q.mlp, st);
 }
 
