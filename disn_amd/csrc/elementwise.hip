@@ -389,7 +389,15 @@ __global__ __launch_bounds__(256) void gather_fold_kernel(const float* __restric
                                                           const float* pre,
                                                           const float* __restrict__ bias, float* h) {
   const size_t total = (size_t)n * 128;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+  // XCD-aware order: hardware workgroup w runs on XCD w % 8; give each XCD a CONTIGUOUS eighth of the
+  // blocks, so the pmap rows its points touch (neighbouring points project to neighbouring pixels)
+  // fit its 4 MB L2 instead of all eight L2s streaming the whole footprint from the Infinity Cache
+  unsigned lb = blockIdx.x;
+  {
+    const unsigned W = gridDim.x, q = W >> 3, r = W & 7, xcd = lb & 7, idx = lb >> 3;
+    lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  for (size_t i = (size_t)lb * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
     const size_t pt = i >> 7;
     const int c = (int)(i & 127) * 4;
