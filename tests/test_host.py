@@ -62,6 +62,23 @@ def test_argument_validation_without_gpu():
     assert h.disn_vgg16_workspace_bytes(8) > h.disn_vgg16_workspace_bytes(1)
     assert h.disn_query_workspace_bytes(1, 2048) > 2048 * 1472 * 4
     assert h.disn_query_workspace_bytes(0, 5) == 0
+    # folded local stream: NULL weights / maps, and weights without the split fold2/conv1 halves
+    assert h.disn_fold_local_workspace_bytes() > 2048
+    assert h.disn_fold_local(None, 1, 1, 1, 1 << 30, None) == -1
+    w = _lib.MlpWeights()
+    for f in _lib.MLP_FIELDS:
+        setattr(w, f, 1)
+    assert h.disn_fold_local(ctypes.byref(w), 1, 1, 1, 1 << 30, None) == -1        # l_w4_point / l_w4_feat unset
+    assert h.disn_query_folded(ctypes.byref(w), 1, 1, 1, 1, 1, 1, 8, 1, 1, 1 << 30, None) == -1
+    assert h.disn_query_grid_folded(ctypes.byref(w), 1, 1, 1, ctypes.byref(p6), 4, 0, 10, 10.0, 1, 1, 1 << 30,
+                                    None) == -1
+    w.l_w4_point = 1
+    w.l_w4_feat = 1
+    assert h.disn_fold_local(ctypes.byref(w), 1, 1, 1, 16, None) == -3              # workspace too small
+    assert h.disn_query_grid_folded(ctypes.byref(w), 1, 1, 1, ctypes.byref(p6), 4, 0, 126, 10.0, 1, 1, 1 << 30,
+                                    None) == -1                                     # k1 > 5^3
+    # disn_encode_query takes featmap = NULL (map not materialised) but still validates the rest
+    assert h.disn_encode_query(None, None, None, 1, 1, 1, 1, 1, 8, None, None, 1, None, 1, 1, 0, None) == -1
     with pytest.raises(_lib.DisnError):
         _lib.check("x", -3)
 
