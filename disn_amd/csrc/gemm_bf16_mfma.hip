@@ -189,10 +189,18 @@ struct BfDev {
 template <int BM, int BN, int MODE, int NS, int PF>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16_mfma(const BfDev d) {
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int LDA = 40;  // bf16 per staged row
+  // A planes in LDS: rows of 32 bf16 padded to 40 (80 B).  ds_read_b128 (MI355X_MICROARCH.md, LDS: four
+  // non-contiguous 16-lane groups, bank = (a/4) mod 64): the 16 rows of a group land on 16 different
+  // 16-byte slots ((5 row + c) mod 16) -> conflict-free.  ds_write_b64 (contiguous 16-lane groups, bank =
+  // (a/4) mod 32): the two rows a group writes must be 4 apart (80 dwords = 16 mod 32), not adjacent
+  // (20 dwords: four banks shared, every write 2 cycles, SQ_LDS_BANK_CONFLICT 33 % of the LDS cycles) --
+  // hence the row order of the A loader below.
+  constexpr int LDA = 40;
   constexpr int APASS = BM / 32;
   constexpr int PLANE = BM * LDA;
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NS * PLANE];
+  // (the 128-row plain-bf16 variant keeps enough LDS for the staged epilogue: 4 waves x 32x36 floats)
+  constexpr int LDS_ELEMS = (BM >= 128 && 2 * NS * PLANE < 4 * 32 * 36 * 2) ? 4 * 32 * 36 * 2 : 2 * NS * PLANE;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_ELEMS];
   const GemmParams& p = d.p;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,8 +215,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
   const int KS_all = p.K >> 5;
   const int s0 = (int)(((long)KS_all * blockIdx.y) / d.S), s1 = (int)(((long)KS_all * (blockIdx.y + 1)) / d.S);
 
-  // ---- A loader: rows (tid>>3) + 32*pass, float4 column (tid&7) ----------------------------------
-  const int arow = tid >> 3, c4 = (tid & 7) * 4;
+  // ---- A loader: one row per 8-lane octet (+ 32 rows per pass), float4 column (tid&7) -------------
+  // each 8-lane octet takes one row; the octets of a wave take rows 0,4,1,5,2,6,3,7 of its 8-row band, so
+  // that the two rows of a 16-lane ds_write_b64 group are 4 apart (see LDA above)
+  const int oct = (tid >> 3) & 7;
+  const int arow = (tid >> 6) * 8 + (oct >> 1) + 4 * (oct & 1), c4 = (tid & 7) * 4;
   const float* pa1[APASS];
   const float* pa2[APASS];
   unsigned vmask[APASS];
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
   // lanes per 128-byte row (4 store instructions per tile instead of 16; DS operations of one wave
   // execute in order, so the exchange needs no barrier).  NS = 1 with the 64-row tile has too little
   // LDS for that and stores element-wise.
-  constexpr bool STAGE = (size_t)2 * NS * PLANE * sizeof(__bf16) >= (size_t)4 * 32 * 36 * sizeof(float);
+  constexpr bool STAGE = (size_t)LDS_ELEMS * sizeof(__bf16) >= (size_t)4 * 32 * 36 * sizeof(float);
   if (STAGE) {
     float* stg = reinterpret_cast<float*>(lds) + wave * 32 * 36;
     const int srow = lane >> 3, scol = (lane & 7) * 4;
