@@ -416,42 +416,23 @@ size_t disn_vgg16_workspace_bytes(int B) {
 
 }  // extern "C"
 
-// struct disn_ctx (kernels.hpp) as used here -- ev 0: fork, 1..5: tap ready, 6: aux done, 7: features
-// done, 8: g4_pre done
+// struct disn_ctx (kernels.hpp) as used here -- ev 0: fork, 1..4: grid pipeline buffers, 6: aux done,
+// 7: features done, 8: g4_pre done
 
 namespace {
 
 const int kTapHw[5] = {224, 112, 56, 28, 14}, kTapCh[5] = {64, 128, 256, 512, 512};
 const int kTapOff[5] = {0, 64, 192, 448, 960};
 
-// Which overlaps disn_encode / disn_encode_query use: bit 0 = tap up-samples on the aux stream
-// under the convolutions, bit 1 = MLP phase 1 on the aux stream under the fc head.
-// DISN_OVERLAP / DISN_RESIZE_BG_BLOCKS override the defaults (tuning / debugging only).
-int overlap_mask() {
-  // Measured on MI355X (tools/overlap_sweep.py, cfg2 step): none 0.886 ms; bit 1 only 0.797 ms;
-  // bit 0 only 0.892-0.979 ms at every throttle; both 0.863 ms.  The streamed 110 MB of
-  // up-sample writes disturb the latency-sensitive convolution loads more than they hide, so
-  // the default keeps them on the caller's stream and overlaps only the fc head.
+// disn_encode_query runs on two streams unless DISN_OVERLAP=0 (debugging: same launches, one stream).
+// Measured on MI355X (tools/overlap_sweep.py, cfg2 step of build r01c): single stream 0.886 ms, MLP
+// under the fc head 0.797 ms.  Two other overlaps were tried and removed: the 110 MB tap up-samples
+// on the auxiliary stream under the convolutions (0.86-0.98 ms at every throttle: their streamed
+// writes disturb the latency-sensitive convolution loads) and a trickle read of the fc6 weights
+// into the memory-side cache under conv4/conv5 (no gain up to 200 MB, slower beyond).
+bool two_streams() {
   const char* e = std::getenv("DISN_OVERLAP");
-  return e ? std::atoi(e) : 2;
-}
-// fc6 weight prefetch (tools/overlap_sweep.py): MB to read ahead, the conv layer before which the
-// read starts, and its grid size (small: it must trickle under the convolutions)
-int prefetch_mb() {
-  static const int v = [] { const char* e = std::getenv("DISN_PREFETCH_MB"); return e ? std::atoi(e) : 0; }();
-  return v;
-}
-int prefetch_layer() {
-  static const int v = [] { const char* e = std::getenv("DISN_PREFETCH_LAYER"); return e ? std::atoi(e) : 10; }();
-  return v;
-}
-int prefetch_blocks() {
-  static const int v = [] { const char* e = std::getenv("DISN_PREFETCH_BLOCKS"); return e ? std::atoi(e) : 256; }();
-  return v;
-}
-int resize_bg_blocks() {
-  const char* e = std::getenv("DISN_RESIZE_BG_BLOCKS");
-  return e ? std::atoi(e) : 256;
+  return !e || std::atoi(e) != 0;
 }
 
 bool vgg_weights_ok(const disn_vgg_weights_t* w) {
@@ -463,10 +444,8 @@ bool vgg_weights_ok(const disn_vgg_weights_t* w) {
   return true;
 }
 
-// rows A, B (+E when featmap != nullptr): resize, conv stack, pools.  With a context the five
-// tap up-samples (HBM-write bound, 110 MB) run on ctx->aux as soon as their tap is final, under
-// the MFMA-bound convolutions that follow on `st`.  Returns pool5 in *pool5.
-int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, int B, float* resized,
+// rows A, B (+E when featmap != nullptr): resize, conv stack, pools, all on `st`.  Returns pool5.
+int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* resized,
                  float* const taps[5], float* featmap, const VggWs& s, const float** pool5,
                  hipStream_t st) {
   DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, resized, DISN_VGG_SIZE,
@@ -476,16 +455,6 @@ int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, i
   const size_t gws_cap = (size_t)((char*)s.fc_ws - (char*)s.gemm_ws);
   for (int i = 0; i < 13; ++i) {
     const VggLayer& L = kVgg[i];
-    if (ctx && i == prefetch_layer() && prefetch_mb() > 0) {
-      // warm the memory-side cache with the head of the fc6 weights while the (MFMA-bound) last
-      // convolutions run: fc6 is the HBM-bound 411 MB stream that follows them on the critical path
-      size_t bytes = (size_t)prefetch_mb() << 20;
-      const size_t all = (size_t)25088 * 4096 * sizeof(float);
-      if (bytes > all) bytes = all;
-      DISN_TRY(hipEventRecord(ctx->ev[5], st));
-      DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[5], 0));
-      DISN_TRY(prefetch_launch(w->fc_w[0], bytes, s.fc6, prefetch_blocks(), ctx->aux));
-    }
     float* out = L.tap >= 0 ? taps[L.tap] : (L.hw >= 112 ? s.bufA : (toggle ? s.bufB : s.bufA));
     if (L.tap < 0 && L.hw < 112) toggle = !toggle;
     // a layer the pool follows: when its split-K reduce runs anyway, that pass also emits the pool
@@ -495,19 +464,10 @@ int vgg_features(disn_ctx* ctx, const disn_vgg_weights_t* w, const float* img, i
                                 kPoolAfter[i] ? s.bufP : nullptr, &pooled);
     if (rc) return rc;
     x = out;
-    if (L.tap >= 0 && featmap) {
-      hipStream_t rs = st;
-      int cap = 0;
-      if (ctx && (overlap_mask() & 1)) {
-        DISN_TRY(hipEventRecord(ctx->ev[1 + L.tap], st));
-        DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[1 + L.tap], 0));
-        rs = ctx->aux;
-        cap = resize_bg_blocks();  // background launch: trickle under the convolutions
-      }
+    if (L.tap >= 0 && featmap)
       DISN_TRY(resize_bilinear_launch(taps[L.tap], B, kTapHw[L.tap], kTapHw[L.tap], kTapCh[L.tap],
                                       featmap, DISN_IMG_H, DISN_IMG_W, DISN_FEAT_DIM,
-                                      kTapOff[L.tap], rs, cap));
-    }
+                                      kTapOff[L.tap], st, 0));
     if (kPoolAfter[i]) {
       if (!pooled) DISN_TRY(maxpool2x2_launch(x, B, L.hw, L.hw, L.cout, s.bufP, st));
       x = s.bufP;
@@ -583,7 +543,7 @@ int disn_vgg16_forward(const disn_vgg_weights_t* w, const float* img, int B, flo
   const VggWs s = vgg_layout(ws, B, w->num_classes);
   if (s.total > ws_bytes) return DISN_E_WS;
   const float* pool5 = nullptr;
-  int rc = vgg_features(nullptr, w, img, B, resized224 ? resized224 : s.resized, taps, nullptr, s,
+  int rc = vgg_features(w, img, B, resized224 ? resized224 : s.resized, taps, nullptr, s,
                         &pool5, st);
   if (rc) return rc;
   return vgg_head(w, pool5, B, embedding, s, st);
@@ -602,19 +562,11 @@ int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, 
   hipStream_t st = (hipStream_t)stream;
   const VggWs s = vgg_layout(ws, B, w->num_classes);
   if (s.total > ws_bytes) return DISN_E_WS;
-  if (ctx) {  // fork: the aux stream starts behind everything already queued on `st`
-    DISN_TRY(hipEventRecord(ctx->ev[0], st));
-    DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
-  }
+  (void)ctx;  // everything runs on `st`: nothing in the encoder alone is worth a second stream
   const float* pool5 = nullptr;
-  int rc = vgg_features(ctx, w, img, B, resized224 ? resized224 : s.resized, taps, featmap, s, &pool5, st);
+  int rc = vgg_features(w, img, B, resized224 ? resized224 : s.resized, taps, featmap, s, &pool5, st);
   if (rc) return rc;
-  if ((rc = vgg_head(w, pool5, B, embedding, s, st))) return rc;
-  if (ctx) {  // join
-    DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
-    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
-  }
-  return 0;
+  return vgg_head(w, pool5, B, embedding, s, st);
 }
 
 size_t disn_encode_query_workspace_bytes(int B, int N) {
@@ -643,7 +595,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   // gather and the local fold2 layers (MFMA bound), under the 495 MB fc weight stream (HBM bound).
   // Every event record / wait on `st` drains it (~6 us in the kernel trace): there are three.
   // DISN_OVERLAP=0 (debugging) runs the same launches on `st` alone.
-  const bool two = (overlap_mask() & 2) != 0;
+  const bool two = two_streams();
   hipStream_t ms = two ? ctx->aux : st;
   int rc;
   DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (also orders aux behind the caller's inputs)
@@ -654,8 +606,8 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
   }
   const float* pool5 = nullptr;
-  rc = vgg_features(ctx, vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg,
-                    &pool5, st);
+  rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5,
+                    st);
   if (rc) return rc;
   if (two) {
     DISN_TRY(hipEventRecord(ctx->ev[7], st));

@@ -52,27 +52,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
   }
 }
 
-// Pull a weight range through the memory-side cache ahead of its HBM-bound consumer (fc6 streams
-// 411 MB right after the MFMA-bound convolutions, whose HBM traffic is small): a grid-stride read of
-// `n16` 16-byte words whose values are folded into a never-true store so it is not optimised away.
-__global__ __launch_bounds__(256) void prefetch_kernel(const float4* __restrict__ p, size_t n16,
-                                                       float* __restrict__ sink) {
-  float acc = 0.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const float4 v = p[i];
-    acc += v.x + v.y + v.z + v.w;
-  }
-  if (acc == 1.2345678e38f) *sink = acc;
-}
-
-hipError_t prefetch_launch(const float* p, size_t bytes, float* sink, int blocks, hipStream_t st) {
-  if (bytes < 16 || blocks < 1) return hipSuccess;
-  hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(p),
-                     bytes / 16, sink);
-  return hipGetLastError();
-}
-
 int gemv_splits(int K, int N) {
   const int colblocks = N / 256;
   int s = (2048 + colblocks - 1) / colblocks;

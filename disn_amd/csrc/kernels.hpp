@@ -101,8 +101,6 @@ size_t gemv_ws_bytes(int B, int K, int N);
 hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const float* bias, int N,
                        int relu, float* out, float* ws, hipStream_t st);
 
-// read `bytes` of p with `blocks` workgroups (warms the memory-side cache); sink: any device float
-hipError_t prefetch_launch(const float* p, size_t bytes, float* sink, int blocks, hipStream_t st);
 
 // ---- elementwise.hip (compiled with -ffp-contract=off) --------------------
 // max_blocks > 0 caps the grid (grid-stride): a background launch that should trickle under

@@ -209,14 +209,16 @@ int disn_query_folded(const disn_mlp_weights_t* w, const float* pmap, const floa
 
 /* ---------------------------------------------------------------------- *
  * Concurrency context.  The path mixes MFMA-bound launches (convolutions,  *
- * MLP GEMMs) with HBM-bound ones (the 110 MB feature-map write, the 495 MB *
- * fc6-fc8 weight stream) that do not depend on each other; disn_encode /   *
- * disn_encode_query run the latter on the context's auxiliary HIP stream,  *
+ * MLP GEMMs) with an HBM-bound one (the 495 MB fc6-fc8 weight stream) that *
+ * do not depend on each other; disn_encode_query runs the point MLPs'      *
+ * embedding-independent layers on the context's auxiliary HIP stream,      *
  * forked from and joined back into the caller's `stream` with events, so   *
- * the caller still sees ONE asynchronous operation on `stream`.            *
- * A context owns one non-blocking stream and ten events; use one context *
- * per caller stream (not thread-safe).  ctx may be NULL for disn_encode    *
- * (everything then runs on `stream`).                                      *
+ * the caller still sees ONE asynchronous operation on `stream`;            *
+ * disn_query_grid_ctx pipelines chunks over the two streams.               *
+ * A context owns one non-blocking stream and ten events; use one context   *
+ * per caller stream (not thread-safe).  disn_encode accepts a context for  *
+ * symmetry and ignores it (may be NULL): the encoder alone runs on         *
+ * `stream`.                                                                *
  * ---------------------------------------------------------------------- */
 typedef struct disn_ctx disn_ctx_t;
 int disn_ctx_create(disn_ctx_t** out);
