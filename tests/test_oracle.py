@@ -161,3 +161,24 @@ def test_loss_formula():
     # |10*gt - pred| * mask, mask = 4 where gt <= 0.01
     expect = np.mean([abs(2.0 - 1.0) * 1, abs(-1.0 + 2.0) * 4, abs(0.05 - 0.5) * 4]) * 1000
     assert abs(L["sdf_loss"] - expect) < 1e-3
+
+
+def test_fold_identities_behind_the_folded_local_stream():
+    """The two linear-algebra facts disn_fold_local / project_gather_taps rest on, in oracle terms:
+    (1) resampling commutes with a right-multiplication of the map: resampler(map) @ W == resampler(map @ W)
+        (models/model_normalization.py:172-190 gather, models/sdfnet.py:180-182 first local fold2 layer);
+    (2) resampling the legacy-resized tap == resampling a map that holds the resized tap only at the touched
+        pixels (trivially), and the legacy resize is itself linear in the tap: resize(tap @ W) == resize(tap) @ W."""
+    rng = np.random.default_rng(11)
+    fm = rng.standard_normal((1, 137, 137, 24)).astype(np.float32)
+    W = rng.standard_normal((24, 7)).astype(np.float32)
+    xy = np.concatenate([rng.uniform(-2, 139, (1, 300, 2)),
+                         np.array([[[0, 0], [136, 136], [136.0, 0.5], [-0.5, 10], [12.25, 136.9]]])], 1).astype(np.float32)
+    a = O.resampler(fm, xy).astype(np.float64) @ W.astype(np.float64)
+    pm = (fm.astype(np.float64) @ W.astype(np.float64)).astype(np.float32)
+    b = O.resampler(pm, xy).astype(np.float64)
+    assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max())
+    tap = rng.standard_normal((1, 14, 14, 24)).astype(np.float32)
+    r1 = O.resize_bilinear_legacy(tap, 137, 137).astype(np.float64) @ W.astype(np.float64)
+    r2 = O.resize_bilinear_legacy((tap.astype(np.float64) @ W.astype(np.float64)).astype(np.float32), 137, 137).astype(np.float64)
+    assert np.abs(r1 - r2).max() <= 2e-5 * max(1.0, np.abs(r1).max())
