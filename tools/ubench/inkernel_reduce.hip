@@ -14,6 +14,8 @@
 //                    point), s_waitcnt vmcnt(0), agent-scope counter; the last arriver reads with
 //                    workgroup-scope (sc0) atomic loads so that its own L1 cannot serve a line of the
 //                    previous launch
+//   3  as 2, with the last arriver reading four slabs per iteration into independent registers (the
+//      r01p measurement showed variant 2's slab-after-slab loop costing ~1.5 us per split)
 // Every launch uses new data (seed), the output is compared on the host after every R launches, and the
 // reported time is per launch (HIP events, back-to-back launches on one stream).
 // Build: hipcc --offload-arch=gfx950 -O3 -o inkernel_reduce inkernel_reduce.hip ; run: ./inkernel_reduce
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void produce_reduce(float* ws, float* __restri
   }
   __syncthreads();
   if (!last_flag) return;
-  if (VARIANT == 2 && threadIdx.x == 0) {
+  if (VARIANT >= 2 && threadIdx.x == 0) {
     const unsigned me = xcc_id();
     for (int t = 0; t < S; ++t)
       if (__hip_atomic_load(xcc_seen + (size_t)tile * S + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != me)
@@ -123,14 +125,35 @@ __global__ __launch_bounds__(256) void produce_reduce(float* ws, float* __restri
   float acc[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-  for (int t = 0; t < S; ++t) {
+  int t0 = 0;
+  if (VARIANT == 3) {
+    // four slabs in flight: 32 independent 8-byte loads per thread, then added in slab order
+    for (; t0 + 4 <= S; t0 += 4) {
+      unsigned long long b[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned long long* q =
+            reinterpret_cast<const unsigned long long*>(ws + ((size_t)(t0 + u) * T + tile) * TILE) + threadIdx.x * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b[u][k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          acc[2 * k] += __uint_as_float((unsigned)b[u][k]);
+          acc[2 * k + 1] += __uint_as_float((unsigned)(b[u][k] >> 32));
+        }
+    }
+  }
+  for (int t = t0; t < S; ++t) {
     const float* src = ws + ((size_t)t * T + tile) * TILE;
     const unsigned long long* q = reinterpret_cast<const unsigned long long*>(src) + threadIdx.x * 8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const unsigned long long bits =
           VARIANT == 1 ? __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                       : __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                       : __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // variants 2, 3
       acc[2 * k] += __uint_as_float((unsigned)bits);
       acc[2 * k + 1] += __uint_as_float((unsigned)(bits >> 32));
     }
@@ -168,8 +191,8 @@ int main() {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int work : {0, 20000}) {
-      for (int variant = 0; variant < 3; ++variant) {
+    for (int work : {0, 1500}) {  // 1500 spin iterations ~ a 20-30 us producer
+      for (int variant = 0; variant < 4; ++variant) {
         long bad = 0;
         int seed = 1;
         auto launch = [&](int sd) {
@@ -180,8 +203,10 @@ int main() {
             const int G = 8 * ((T + 7) / 8) * S;
             if (variant == 1)
               hipLaunchKernelGGL((produce_reduce<1>), dim3(G), dim3(256), 0, 0, ws, out, ctr, seen, mism, T, S, sd, work);
-            else
+            else if (variant == 2)
               hipLaunchKernelGGL((produce_reduce<2>), dim3(G), dim3(256), 0, 0, ws, out, ctr, seen, mism, T, S, sd, work);
+            else
+              hipLaunchKernelGGL((produce_reduce<3>), dim3(G), dim3(256), 0, 0, ws, out, ctr, seen, mism, T, S, sd, work);
           }
         };
         // correctness: 50 launches with fresh data, each checked
@@ -201,7 +226,7 @@ int main() {
         unsigned mm = 0;
         CHECK(hipMemcpy(&mm, mism, 4, hipMemcpyDeviceToHost));
         printf("T %3d S %2d work %5d  variant %d : %7.2f us per launch, %ld wrong values in 50 checked launches%s\n", T, S,
-               work, variant, ms * 1e3 / 200, bad, variant == 2 ? (mm ? "  [XCC_ID mismatch seen!]" : "  [same XCC_ID per tile]") : "");
+               work, variant, ms * 1e3 / 200, bad, variant >= 2 ? (mm ? "  [XCC_ID mismatch seen!]" : "  [same XCC_ID per tile]") : "");
       }
     }
     CHECK(hipFree(ws)); CHECK(hipFree(out)); CHECK(hipFree(ctr)); CHECK(hipFree(seen)); CHECK(hipFree(mism));
