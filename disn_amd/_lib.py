@@ -12,8 +12,9 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DISN_AMD_LIB") or os.path.join(HERE, "csrc", "libdisn_amd.so")  # env: tools/ablate_x3.sh only
-ABI_VERSION = 3
+# DISN_AMD_LIB: tools/ only -- points the binding at a tuning build (csrc/build.py --tuning), never set by the product
+LIB_PATH = os.environ.get("DISN_AMD_LIB") or os.path.join(HERE, "csrc", "libdisn_amd.so")
+ABI_VERSION = 4
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -43,10 +44,11 @@ MLP_FIELDS = ("g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3", "g_w4_point", "g_w
 
 MLP_X3_FIELDS = ("g_x2", "g_x3", "g_x4_point", "g_x5", "l_x2", "l_x3", "l_x4", "l_x5")   # optional
 MLP_FOLD_FIELDS = ("l_w4_point", "l_w4_feat", "l_x4_point", "l_x4_feat")   # optional: *_folded entry points
+MLP_FUSED_FIELDS = ("g_fused", "l_fused")   # optional: *_fused entry points (disn_mlp_fused_pack images)
 
 
 class MlpWeights(C.Structure):  # disn_mlp_weights_t
-    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS + MLP_X3_FIELDS + MLP_FOLD_FIELDS]
+    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS + MLP_X3_FIELDS + MLP_FOLD_FIELDS + MLP_FUSED_FIELDS]
 
 
 CAM_FIELDS = tuple("%s_%s%d" % (t, k, i) for t in "srt" for i in (1, 2, 3) for k in "wb")
@@ -77,6 +79,8 @@ SIGNATURES = {
     "disn_vgg16_forward": (I, [C.POINTER(VggWeights), P, I, P, C.POINTER(C.c_void_p * 5), P, P, Z, P]),
     "disn_conv3x3_workspace_bytes": (Z, [I, I, I, I, I]),
     "disn_conv3x3": (I, [P, I, I, I, I, P, P, I, I, P, P, Z, P]),
+    "disn_conv3x3_planned_workspace_bytes": (Z, [I, I, I, I, I, I, I, I]),
+    "disn_conv3x3_planned": (I, [P, I, I, I, I, P, P, I, I, P, P, Z, I, I, I, P]),
     "disn_maxpool2x2": (I, [P, I, I, I, I, P, P]),
     "disn_fc_workspace_bytes": (Z, [I, I, I]),
     "disn_fc": (I, [P, I, I, P, P, I, I, P, P, Z, P]),
@@ -85,6 +89,16 @@ SIGNATURES = {
     "disn_build_featmap": (I, [C.POINTER(C.c_void_p * 5), I, P, P]),
     "disn_project": (I, [P, P, I, I, P, P]),
     "disn_gather": (I, [P, P, I, I, P, P]),
+    "disn_gather_taps": (I, [C.POINTER(C.c_void_p * 5), P, P, I, I, P, P]),
+    "disn_gather_fold": (I, [P, P, P, I, P, P, P, P]),
+    "disn_mlp_fused_image_bytes": (Z, []),
+    "disn_mlp_fused_pack": (I, [P, P, P, P, P, P]),
+    "disn_amax": (I, [P, L, P, P]),
+    "disn_query_fused_workspace_bytes": (Z, [I, L]),
+    "disn_query_fused": (I, [C.POINTER(MlpWeights), P, P, P, P, P, P, I, L, P, P, Z, P]),
+    "disn_query_grid_fused_workspace_bytes": (Z, [L]),
+    "disn_query_grid_fused": (I, [C.POINTER(MlpWeights), P, P, P, P, C.POINTER(C.c_double * 6), I, L, L, F, P,
+                                  P, Z, P]),
     "disn_sdf_mlp_workspace_bytes": (Z, [I, I]),
     "disn_sdf_mlp": (I, [C.POINTER(MlpWeights), P, P, P, I, I, P, P, P, P, Z, P]),
     "disn_query_workspace_bytes": (Z, [I, I]),

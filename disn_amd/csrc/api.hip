@@ -3,8 +3,8 @@
 #include "../../include/disn_amd.h"
 
 #include "kernels.hpp"
+#include "tuning.hpp"
 
-#include <cstdlib>
 #include <new>
 
 using namespace disn;
@@ -166,11 +166,8 @@ bool mlp_weights_ok(const disn_mlp_weights_t* w) {
 }
 
 // fp32-accurate products on the bf16 MFMA pipes (three bf16 terms per operand, gemm_bf16_mfma.hip)
-// wherever the caller supplied the 3-plane weight image; DISN_X3=0 forces the f32-input MFMA
-bool x3_enabled() {
-  static const bool v = [] { const char* e = std::getenv("DISN_X3"); return !e || std::atoi(e) != 0; }();
-  return v;
-}
+// wherever the caller supplied the 3-plane weight image
+bool x3_enabled() { return tune::x3 != 0; }
 
 int dense_layer(const float* a1, int lda1, int k1, const float* a2, int lda2, int K, int n,
                 const float* bp, const float* bias, int N, float* out, float* ws, size_t ws_bytes,
@@ -287,6 +284,8 @@ int mlp_chunk(const disn_mlp_weights_t* w, const float* pts_rot, int n, const fl
   return mlp_phase2(w, 1, n, gbias, sdf, sdf_g, sdf_l, out_div, s, st);
 }
 
+const int kMapPixels = DISN_IMG_H * DISN_IMG_W;
+
 struct QueryWs {
   float *gbias, *gemv_ws, *feat, *pts;
   MlpWs mlp;
@@ -365,6 +364,32 @@ int disn_conv3x3(const float* in, int B, int H, int W, int Cin, const float* w_p
                       (hipStream_t)stream);
 }
 
+size_t disn_conv3x3_planned_workspace_bytes(int B, int H, int W, int Cin, int Cout, int bm, int bn, int wgs) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  const int force[3] = {bm, bn, wgs};
+  return gemm_plan(B * H * W, Cout, conv_k(Cin), ~size_t(0), force).ws_bytes;
+}
+
+int disn_conv3x3_planned(const float* in, int B, int H, int W, int Cin, const float* w_packed,
+                         const float* bias, int Cout, int relu, float* out, void* ws, size_t ws_bytes,
+                         int bm, int bn, int wgs, void* stream) {
+  if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
+  if (!(Cin == 3 || Cin % 32 == 0) || Cout % 64 != 0 || H >= 32768 || W >= 32768) return DISN_E_SHAPE;
+  if (!((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && Cout % bn == 0 && (wgs >= 1 || wgs == -1)))
+    return DISN_E_SHAPE;
+  GemmParams p{};
+  p.a1 = in;
+  p.H = H; p.W = W; p.Cin = Cin;
+  p.M = B * H * W; p.N = Cout; p.K = conv_k(Cin);
+  p.bp = w_packed; p.bias = bias; p.rows_per_bias = 0;
+  p.out = out; p.ldc = Cout; p.relu = relu;
+  const int force[3] = {bm, bn, wgs};
+  const GemmPlan pl = gemm_plan(p.M, p.N, p.K, ~size_t(0), force);
+  if (pl.ws_bytes > (ws ? ws_bytes : 0)) return DISN_E_WS;
+  DISN_TRY(gemm_launch(p, Cin == 3 ? GEMM_CONV3_C3 : GEMM_CONV3, pl, (float*)ws, (hipStream_t)stream));
+  return 0;
+}
+
 int disn_maxpool2x2(const float* in, int B, int H, int W, int C, float* out, void* stream) {
   if (!in || !out || B <= 0 || H < 2 || W < 2) return DISN_E_ARG;
   if (C % 4) return DISN_E_SHAPE;
@@ -424,16 +449,13 @@ namespace {
 const int kTapHw[5] = {224, 112, 56, 28, 14}, kTapCh[5] = {64, 128, 256, 512, 512};
 const int kTapOff[5] = {0, 64, 192, 448, 960};
 
-// disn_encode_query runs on two streams unless DISN_OVERLAP=0 (debugging: same launches, one stream).
+// disn_encode_query runs on two streams (a tuning build can run the same launches on one).
 // Measured on MI355X (tools/overlap_sweep.py, cfg2 step of build r01c): single stream 0.886 ms, MLP
 // under the fc head 0.797 ms.  Two other overlaps were tried and removed: the 110 MB tap up-samples
 // on the auxiliary stream under the convolutions (0.86-0.98 ms at every throttle: their streamed
 // writes disturb the latency-sensitive convolution loads) and a trickle read of the fc6 weights
 // into the memory-side cache under conv4/conv5 (no gain up to 200 MB, slower beyond).
-bool two_streams() {
-  const char* e = std::getenv("DISN_OVERLAP");
-  return !e || std::atoi(e) != 0;
-}
+bool two_streams() { return tune::overlap != 0; }
 
 bool vgg_weights_ok(const disn_vgg_weights_t* w) {
   if (!w) return false;
@@ -594,7 +616,6 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   // global fold2/conv1 (small GEMMs in the quantisation holes of the convolutions); behind conv5_3 the
   // gather and the local fold2 layers (MFMA bound), under the 495 MB fc weight stream (HBM bound).
   // Every event record / wait on `st` drains it (~6 us in the kernel trace): there are three.
-  // DISN_OVERLAP=0 (debugging) runs the same launches on `st` alone.
   const bool two = two_streams();
   hipStream_t ms = two ? ctx->aux : st;
   int rc;
@@ -664,6 +685,22 @@ int disn_gather(const float* featmap, const float* xy, int B, int N, float* feat
   return 0;
 }
 
+int disn_gather_taps(const float* const taps[5], const float* trans_mat, const float* pts, int B, int N,
+                     float* feat, void* stream) {
+  if (!taps || !trans_mat || !pts || !feat || B <= 0 || N <= 0) return DISN_E_ARG;
+  for (int i = 0; i < 5; ++i)
+    if (!taps[i]) return DISN_E_ARG;
+  DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, feat, (hipStream_t)stream));
+  return 0;
+}
+
+int disn_gather_fold(const float* pmap_b, const float* trans_mat_b, const float* pts, int N, const float* pre,
+                     const float* bias, float* h, void* stream) {
+  if (!pmap_b || !trans_mat_b || !pts || !pre || !bias || !h || N <= 0) return DISN_E_ARG;
+  DISN_TRY(gather_fold_launch(pmap_b, trans_mat_b, pts, N, pre, bias, h, (hipStream_t)stream));
+  return 0;
+}
+
 size_t disn_sdf_mlp_workspace_bytes(int B, int N) {
   if (B <= 0 || N <= 0) return 0;
   return query_layout(nullptr, B, chunk_for(N), false, false).total;
@@ -724,7 +761,6 @@ int disn_query(const disn_mlp_weights_t* w, const float* featmap, const float* e
 }
 
 // ---- folded local stream (include/disn_amd.h) -------------------------------------------------
-static const int kMapPixels = DISN_IMG_H * DISN_IMG_W;
 
 static size_t fold_gemm_ws() {
   const size_t a = gemm_plan(kMapPixels, 512, DISN_FEAT_DIM).ws_bytes;
@@ -797,6 +833,103 @@ int disn_query_grid_folded(const disn_mlp_weights_t* w, const float* pmap, const
     if (rc) return rc;
   }
   return 0;
+}
+
+// ---- fused point MLP (mlp_fused.hip) -----------------------------------------------------------------
+size_t disn_mlp_fused_image_bytes(void) { return mlp_fused_image_bytes(); }
+
+int disn_mlp_fused_pack(const float* w2, const float* w3, const float* w4_point, const float* w5, void* image,
+                        void* stream) {
+  if (!w2 || !w3 || !w4_point || !w5 || !image) return DISN_E_ARG;
+  DISN_TRY(mlp_fused_pack_launch(w2, w3, w4_point, w5, image, (hipStream_t)stream));
+  return 0;
+}
+
+int disn_amax(const float* x, int64_t n, float* out, void* stream) {
+  if (!x || !out || n <= 0) return DISN_E_ARG;
+  if (n % 4) return DISN_E_SHAPE;
+  DISN_TRY(amax_launch(x, (size_t)n, out, (hipStream_t)stream));
+  return 0;
+}
+
+namespace {
+struct FusedWs {
+  float *gbias, *gemv_ws, *gsum;
+  size_t total;
+};
+FusedWs fused_layout(void* ws, int B, int64_t n_max) {
+  Bump b(ws);
+  FusedWs f;
+  f.gbias = b.take((size_t)B * 512 * sizeof(float));
+  f.gemv_ws = b.take(gemv_ws_bytes(B, DISN_EMBED_DIM, 512));
+  f.gsum = b.take((size_t)n_max * sizeof(float));
+  f.total = (b.off + 255) & ~size_t(255);
+  return f;
+}
+bool fused_ok(const disn_mlp_weights_t* w) { return mlp_weights_ok(w) && w->g_fused && w->l_fused; }
+
+// both streams for n points of one image: the global stream's sums go through ws, the local kernel adds them
+int fused_streams(const disn_mlp_weights_t* w, const float* gbias_b, const float* pmap_b,
+                  const float* pmap_amax_b, const float* trans_mat_b, const float* pts, const float* pts_rot,
+                  const GridSpec* grid, long long k0, long long n, float* gsum, float* out, float out_div,
+                  hipStream_t st) {
+  DISN_TRY(mlp_fused_launch(false, w->g_fused, w->g_w1, w->g_b1, w->g_b2, w->g_b3, gbias_b, w->g_b5, w->g_w6,
+                            w->g_b6, nullptr, pts_rot, grid, k0, n, nullptr, nullptr, nullptr, nullptr, gsum,
+                            1.0f, st));
+  DISN_TRY(mlp_fused_launch(true, w->l_fused, w->l_w1, w->l_b1, w->l_b2, w->l_b3, w->l_b4, w->l_b5, w->l_w6,
+                            w->l_b6, pts, pts_rot, grid, k0, n, trans_mat_b, pmap_b, pmap_amax_b, gsum, out,
+                            out_div, st));
+  return 0;
+}
+}  // namespace
+
+size_t disn_query_fused_workspace_bytes(int B, int64_t N) {
+  if (B <= 0 || N <= 0) return 0;
+  return fused_layout(nullptr, B, N).total;
+}
+
+int disn_query_fused(const disn_mlp_weights_t* w, const float* pmap, const float* pmap_amax,
+                     const float* embedding, const float* trans_mat, const float* pts, const float* pts_rot,
+                     int B, int64_t N, float* sdf, void* ws, size_t ws_bytes, void* stream) {
+  if (!fused_ok(w) || !pmap || !pmap_amax || !embedding || !trans_mat || !pts || !pts_rot || !sdf || !ws ||
+      B <= 0 || N <= 0)
+    return DISN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const FusedWs f = fused_layout(ws, B, N);
+  if (f.total > ws_bytes) return DISN_E_WS;
+  DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, f.gbias, f.gemv_ws, st));
+  for (int b = 0; b < B; ++b) {
+    const size_t o = (size_t)b * N;
+    const int rc = fused_streams(w, f.gbias + (size_t)b * 512, pmap + (size_t)b * kMapPixels * 512, pmap_amax + b,
+                                 trans_mat + (size_t)b * 12, pts + o * 3, pts_rot + o * 3, nullptr, 0, N, f.gsum,
+                                 sdf + o, 1.0f, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+size_t disn_query_grid_fused_workspace_bytes(int64_t max_points) {
+  if (max_points <= 0) return 0;
+  return fused_layout(nullptr, 1, max_points).total;
+}
+
+int disn_query_grid_fused(const disn_mlp_weights_t* w, const float* pmap, const float* pmap_amax,
+                          const float* embedding, const float* trans_mat, const double* sdf_params_host, int R,
+                          int64_t k0, int64_t k1, float sdf_weight, float* out, void* ws, size_t ws_bytes,
+                          void* stream) {
+  GridSpec g;
+  if (!fused_ok(w) || !pmap || !pmap_amax || !embedding || !trans_mat || !out || !ws ||
+      !grid_spec(sdf_params_host, R, &g))
+    return DISN_E_ARG;
+  const int64_t total = (int64_t)g.res * g.res * g.res;
+  if (k0 < 0 || k1 > total || k0 >= k1 || sdf_weight == 0.0f) return DISN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const FusedWs f = fused_layout(ws, 1, k1 - k0);
+  if (f.total > ws_bytes) return DISN_E_WS;
+  DISN_TRY(gemv_launch(embedding, 1, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, f.gbias, f.gemv_ws, st));
+  // one launch per stream over the whole range: no chunking, no per-point workspace but the global sums
+  return fused_streams(w, f.gbias, pmap, pmap_amax, trans_mat, nullptr, nullptr, &g, k0, k1 - k0, f.gsum, out,
+                       sdf_weight, st);
 }
 
 int disn_grid_points(const double* sdf_params_host, int R, int64_t k0, int64_t k1, float* pts,
@@ -913,3 +1046,21 @@ int disn_mc_emit(const float* sdf, const double* sdf_params_host, int R, float i
 }
 
 }  // extern "C"
+
+#ifdef DISN_TUNING
+namespace disn {
+namespace tune {
+int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0;
+int gemm_force[3] = {0, 0, 0};
+}
+}  // namespace disn
+// tuning builds only (build.py --tuning -> libdisn_amd_tuning.so): 0 x3, 1 overlap, 2 bf_splits, 3 skip_pack,
+// 4 fused_safe
+extern "C" int disn_tuning_set(int key, int value) {
+  int* k[5] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
+               &disn::tune::fused_safe};
+  if (key < 0 || key > 4) return DISN_E_ARG;
+  *k[key] = value;
+  return 0;
+}
+#endif

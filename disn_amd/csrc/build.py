@@ -1,6 +1,6 @@
 """Build libdisn_amd.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python -m disn_amd.csrc.build [--force] [--verbose]
+    python -m disn_amd.csrc.build [--force] [--verbose] [--tuning]
 
 The library is built IN-TREE (disn_amd/csrc/libdisn_amd.so) so that it travels to the GPU
 box with the repo snapshot.  elementwise.hip is compiled with -ffp-contract=off (bit-exact
@@ -17,6 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libdisn_amd.so")
+LIB_TUNING = os.path.join(HERE, "libdisn_amd_tuning.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -30,13 +31,14 @@ SOURCES = {
     "train.hip": [],
     "cam_head.hip": [],
     "mlp_small.hip": [],
+    "mlp_fused.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],
     "marching_cubes.hip": ["-ffp-contract=off"],
     "api.hip": [],
     "host_util.cpp": ["-msse4.2"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-HEADERS = ["kernels.hpp", "mc_tables.h", os.path.join(ROOT, "include", "disn_amd.h")]
+HEADERS = ["kernels.hpp", "tuning.hpp", "mc_tables.h", os.path.join(ROOT, "include", "disn_amd.h")]
 
 
 def _digest(paths, extra=""):
@@ -47,8 +49,12 @@ def _digest(paths, extra=""):
     return h.hexdigest()[:16]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    srcs = {s: f for s, f in SOURCES.items() if os.path.exists(os.path.join(HERE, s))}
+def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+    """tuning=True: the same sources with -DDISN_TUNING (run-time knobs + disn_tuning_set, csrc/tuning.hpp)
+    as libdisn_amd_tuning.so -- for tools/ only; the product library has no knobs."""
+    lib = LIB_TUNING if tuning else LIB
+    extra = ["-DDISN_TUNING"] if tuning else []
+    srcs = {s: f + extra for s, f in SOURCES.items() if os.path.exists(os.path.join(HERE, s))}
     hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
     objs, jobs = [], []
     for src, flags in srcs.items():
@@ -74,11 +80,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(compile_one, jobs))
-    stamp = os.path.join(HERE, "build", "link.stamp")
+    stamp = os.path.join(HERE, "build", "link_tuning.stamp" if tuning else "link.stamp")
     want = _digest(objs) if all(os.path.exists(o) for o in objs) else ""
     have = open(stamp).read().strip() if os.path.exists(stamp) else ""
-    if force or jobs or not os.path.exists(LIB) or want != have:
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if force or jobs or not os.path.exists(lib) or want != have:
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -86,8 +92,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
         with open(stamp, "w") as f:
             f.write(want)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv,
+                tuning="--tuning" in sys.argv))

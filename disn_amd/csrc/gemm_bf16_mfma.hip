@@ -1,9 +1,11 @@
-// bf16-MFMA GEMM for the mixed-precision TRAINING step (BASELINE config 5 names bf16; the
-// inference path stays on the exact fp32 MFMA: its parity bar is 1e-5).  Same two shapes as
-// gemm_mfma.hip -- the 3x3 SAME convolution as an implicit GEMM over NHWC input and the point-MLP
-// 1x1 convolutions -- with fp32 activations in HBM, fp32 accumulation and fp32 output: only the
-// multiply runs in bf16 (operands rounded to nearest-even when they are staged), i.e. "bf16 compute,
-// fp32 master" with nothing else of the step changed.
+// GEMM on the bf16 matrix pipes, two uses (template parameter NS):
+//   NS = 3  the INFERENCE path's fp32-accurate kernel: every fp32 operand is split into three bf16 terms
+//           and the product is accumulated from the six largest cross terms (see below) -- 12 of the 13
+//           VGG convolutions (models/CNN/vgg.py:187-196) and the deep / large-batch point-MLP layers;
+//   NS = 1  plain bf16 multiply for the mixed-precision TRAINING step (BASELINE config 5 names bf16):
+//           operands rounded to nearest-even when they are staged, "bf16 compute, fp32 master".
+// Same two shapes as gemm_mfma.hip -- the 3x3 SAME convolution as an implicit GEMM over NHWC input and
+// the point-MLP 1x1 convolutions -- with fp32 activations in HBM, fp32 accumulation and fp32 output.
 //
 //   v_mfma_f32_32x32x16_bf16: 16x the rate of the f32-input MFMA (2.5 PFLOP/s dense peak); per lane
 //   8 consecutive k of one row (A) / one column (B): A-fragment lane (i = l&31, g = l>>5) holds
@@ -18,8 +20,7 @@
 // batch every layer has >= 200 tiles and the kernel is L2-bandwidth bound, not MFMA bound:
 // 128x128x32 moves 32 KB per 256 MFMA cycles).
 #include "kernels.hpp"
-
-#include <cstdlib>
+#include "tuning.hpp"
 
 namespace disn {
 
@@ -163,10 +164,11 @@ hipError_t pack_multi_launch(const PackJobs& jobs, hipStream_t st) {
   return hipGetLastError();
 }
 
-// Ablation switches for tools/ablate_x3.sh (WRONG results; never set in the product build):
+// Ablation mask of tools/ablate_x3.py (WRONG results, timing only; honoured by tuning builds alone):
 // 1: no residual chain in the A split, 2: B fragments loaded once, 4: A tile loaded once,
 // 8: one MFMA instead of six, 16: no LDS staging of A after the first tile
-#ifndef DISN_ABL
+#if !defined(DISN_TUNING) || !defined(DISN_ABL)
+#undef DISN_ABL
 #define DISN_ABL 0
 #endif
 
@@ -474,11 +476,11 @@ static hipError_t bf_launch_mode(const BfDev& d, GemmMode mode, hipStream_t st) 
 // split-K factor for a layer with few 64x64 tiles (the 14x14 / 28x28 convolutions, small point
 // sets): enough workgroups for ~3 per CU, at least 4 k-steps each, partials within ws_bytes
 static int bf_splits(long tiles, int ksteps, int M, int N, size_t ws_bytes) {
-  static const int forced = [] { const char* e = std::getenv("DISN_BF_SPLITS"); return e ? std::atoi(e) : 0; }();
+  const int forced = tune::bf_splits;  // 0 in the product build
   if (tiles >= 512 && !forced) return 1;
-  // measured per layer at B = 1 (DISN_BF_SPLITS sweep): ~1200 workgroups in flight and at least
+  // measured per layer at B = 1 (split-factor sweep of a tuning build): ~1200 workgroups in flight and at least
   // 12 k-steps per workgroup (a shorter loop does not amortise its prologue and the reduce pass)
-  int s = forced ? forced : (int)((1176 + tiles / 2) / tiles);  // DISN_BF_SPLITS: tuning only
+  int s = forced ? forced : (int)((1176 + tiles / 2) / tiles);
   if (s < 1) s = 1;
   if (s > 16) s = 16;
   const int min_steps = forced ? 1 : 12;
@@ -588,9 +590,7 @@ int disn_conv3x3_bf16(const float* in, int B, int H, int W, int Cin, const float
   if (Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return DISN_E_SHAPE;
   if (ws_bytes < disn_conv3x3_bf16_workspace_bytes(B, H, W, Cin, Cout)) return DISN_E_WS;
   hipStream_t st = (hipStream_t)stream;
-  // DISN_BF16_SKIP_PACK (timing only): reuse the packed image a previous call left in ws
-  static const bool skip_pack = std::getenv("DISN_BF16_SKIP_PACK") != nullptr;
-  hipError_t e = skip_pack ? hipSuccess : disn::pack_bf16_launch(w_hwio, 0, 9 * Cin, Cout, ws, st, nsplit);
+  hipError_t e = disn::tune::skip_pack ? hipSuccess : disn::pack_bf16_launch(w_hwio, 0, 9 * Cin, Cout, ws, st, nsplit);
   if (e != hipSuccess) return (int)e;
   disn::GemmParams p{};
   p.a1 = in; p.H = H; p.W = W; p.Cin = Cin;

@@ -20,8 +20,8 @@
 // k-permutation: MFMA k-index h of step t inside an 8-k block is k = 4h + t on
 // both operands, so one float4 per operand feeds four MFMAs.
 #include "kernels.hpp"
+#include "tuning.hpp"
 
-#include <cstdlib>
 
 namespace disn {
 
@@ -554,12 +554,6 @@ __global__ __launch_bounds__(256) void pack_kn_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static bool parse_force(int* bm, int* bn, int* w) {
-  const char* e = std::getenv("DISN_GEMM_FORCE");  // "BM,BN,W" -- tuning/debug only
-  if (!e) return false;
-  return std::sscanf(e, "%d,%d,%d", bm, bn, w) == 3;
-}
-
 static size_t slab_bytes(int bm, int bn, int W) { return (size_t)2 * W * bm * bn * sizeof(float); }
 
 static bool needs_fixup(long tiles, int ksteps, int W) {
@@ -567,7 +561,7 @@ static bool needs_fixup(long tiles, int ksteps, int W) {
   return !(U % W == 0 && (U / W) % ksteps == 0);
 }
 
-GemmPlan gemm_plan(int M, int N, int K, size_t max_ws) {
+GemmPlan gemm_plan(int M, int N, int K, size_t max_ws, const int* force) {
   const int ksteps = K / 32;
   const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
   double best = 1e300;
@@ -614,9 +608,11 @@ GemmPlan gemm_plan(int M, int N, int K, size_t max_ws) {
       }
     }
   }
-  int fbm, fbn, fw;
-  if (parse_force(&fbm, &fbn, &fw) && (fbm == 64 || fbm == 128) && (fbn == 64 || fbn == 128) &&
-      N % fbn == 0 && (fw >= 1 || fw == -1)) {  // W = -1: one workgroup per tile
+  // an explicit plan (disn_conv3x3_planned: the plan-invariance test surface): {BM, BN, workgroups}
+  if (!force && tune::gemm_force[0]) force = tune::gemm_force;  // tuning builds only
+  int fbm = force ? force[0] : 0, fbn = force ? force[1] : 0, fw = force ? force[2] : 0;
+  if (force && (fbm == 64 || fbm == 128) && (fbn == 64 || fbn == 128) && N % fbn == 0 &&
+      (fw >= 1 || fw == -1)) {  // W = -1: one workgroup per tile
     const long tiles = (long)((M + fbm - 1) / fbm) * (N / fbn);
     if (fw == -1) fw = (int)tiles;
     if (fw > tiles * ksteps) fw = (int)(tiles * ksteps);

@@ -53,8 +53,9 @@ struct GemmPlan {
   size_t ws_bytes;  // stream-K partial slabs (0 when every workgroup owns whole tiles)
 };
 
-// max_ws bounds the stream-K partial slabs the plan may use (the plan is a pure speed choice)
-GemmPlan gemm_plan(int M, int N, int K, size_t max_ws = ~size_t(0));
+// max_ws bounds the stream-K partial slabs the plan may use (the plan is a pure speed choice);
+// force = {BM, BN, workgroups} replaces the cost model's choice when it is a valid plan
+GemmPlan gemm_plan(int M, int N, int K, size_t max_ws = ~size_t(0), const int* force = nullptr);
 hipError_t gemm_launch(const GemmParams& p, GemmMode mode, const GemmPlan& plan, float* ws,
                        hipStream_t st);
 hipError_t pack_kn_launch(const float* w, int K, int N, int Kpad, float* packed, hipStream_t st);
@@ -223,6 +224,21 @@ hipError_t mc_count_launch(const float* vol, int R, float iso, unsigned long lon
                            hipStream_t st);
 hipError_t mc_emit_launch(const float* vol, const GridSpec& g, float iso, float* verts, int* faces,
                           void* ws, hipStream_t st);
+
+// ---- mlp_fused.hip: both point MLPs as one persistent kernel per stream, activations in registers ----
+size_t mlp_fused_image_bytes();
+// w2 [64][256], w3 [256][512], w4_point [512][512] (the point rows of fold2/conv1), w5 [512][256]: TF [K][N]
+hipError_t mlp_fused_pack_launch(const float* w2, const float* w3, const float* w4_point, const float* w5,
+                                 void* image, hipStream_t st);
+hipError_t amax_launch(const float* x, size_t n, float* out, hipStream_t st);  // n % 4 == 0
+// one stream for n points of one image; pts_rot == nullptr: points k0.. of `grid`.  local: gather from
+// pmap + 'sdfprediction_imgfeat', out = (add_in + sum) / out_div; global: 'sdfprediction' with b4 = the
+// folded per-image bias row, out = sum
+hipError_t mlp_fused_launch(bool local, const void* image, const float* w1, const float* b1, const float* b2,
+                            const float* b3, const float* b4, const float* b5, const float* w6, const float* b6,
+                            const float* pts, const float* pts_rot, const GridSpec* grid, long long k0,
+                            long long n, const float* trans_mat_b, const float* pmap, const float* pmap_amax,
+                            const float* add_in, float* out, float out_div, hipStream_t st);
 
 // ---- mlp_small.hip ---------------------------------------------------------
 // relu(p . W1 + b1) for both streams: pts [M][3] -> out_g [M][64], out_l [M][64]

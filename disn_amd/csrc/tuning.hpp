@@ -1,0 +1,21 @@
+// Tuning / ablation knobs.  The product library (disn_amd/csrc/build.py, default) has NONE: every knob
+// is a compile-time constant here and no environment variable is read anywhere.  `build.py --tuning`
+// compiles the same sources with -DDISN_TUNING into libdisn_amd_tuning.so, where the knobs are
+// run-time integers behind the extra export disn_tuning_set(); only tools/ load that library.
+#pragma once
+
+namespace disn {
+namespace tune {
+#ifdef DISN_TUNING
+extern int x3;          // 0: f32-input MFMA everywhere (no three-term bf16 kernels)
+extern int overlap;     // 0: disn_encode_query on the caller's stream only
+extern int bf_splits;   // > 0: force this split-K factor in the three-term kernels
+extern int skip_pack;   // 1: disn_conv3x3_bf16 reuses the packed image of the previous call (timing only)
+extern int fused_safe;  // 1: fused point MLP waits for ALL LDS-DMA at every sync (debugging)
+extern int gemm_force[3];  // {BM, BN, workgroups}: plan of the f32-input GEMM when BM != 0 (tools/sweep_gemm.py)
+#else
+constexpr int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0;
+constexpr int gemm_force[3] = {0, 0, 0};
+#endif
+}  // namespace tune
+}  // namespace disn

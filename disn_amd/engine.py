@@ -83,6 +83,11 @@ class DeviceWeights:
         m.l_w4 = pk(w4l, "l_x4")
         m.l_w4_point = pk(w4l[:512], "l_x4_point")         # the two halves on their own: the folded
         m.l_w4_feat = pk(w4l[512:], "l_x4_feat")           # local stream (disn_fold_local)
+        # fused point-MLP kernels (mlp_fused.hip): one weight image per stream from the raw TF matrices
+        for pre, scope, w4 in (("g", g, w4g), ("l", l, w4l)):
+            img = ops.mlp_fused_pack(dev(W(scope, "fold1/conv2")), dev(W(scope, "fold1/conv3")), dev(w4[:512]),
+                                     dev(W(scope, "fold2/conv2")))
+            setattr(m, pre + "_fused", self._hold(img).data_ptr())
         for f in MLP_FIELDS:
             assert getattr(m, f), f
         self.mlp = m
@@ -108,15 +113,21 @@ class Encoded:
                                      # None until something needs it (SdfEngine.featmap_of builds it)
     pred: Optional[torch.Tensor] = None   # pred_sdf of the run that produced this state (encode_query)
     pmap: Optional[dict] = None           # image index -> [137*137,512] folded feature map (SdfEngine.pmap_of)
+    pmap_amax: Optional[dict] = None      # image index -> max |pmap| (1-element tensor; the fused kernels' bound)
 
 
 class SdfEngine:
-    def __init__(self, store: WeightStore, device: Optional[torch.device] = None):
+    """``fused``: run the folded queries (large point sets, the dense grid) through the fused point-MLP
+    kernels (mlp_fused.hip: activations in registers, fp32-accurate two-term fp16 products) instead of the
+    layer-by-layer GEMM chain (three-term bf16 products); same math, fp32-rounding-level difference."""
+
+    def __init__(self, store: WeightStore, device: Optional[torch.device] = None, fused: bool = True):
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         if not torch.cuda.is_available():
             raise RuntimeError("disn_amd needs a HIP device: the product path has no CPU fallback")
         self.device = torch.device(device)
+        self.fused = bool(fused)
         with torch.cuda.device(self.device):
             self.weights = DeviceWeights(store, self.device)
             self._ctx = ops.ctx_create()      # aux HIP stream + events for the overlapped encoder
@@ -171,6 +182,16 @@ class SdfEngine:
                 enc.pmap[image_index] = ops.fold_local(self.weights.mlp, self.featmap_of(enc)[image_index])
         return enc.pmap[image_index]
 
+    def pmap_amax_of(self, enc: Encoded, image_index: int) -> torch.Tensor:
+        """max |pmap| of one image (1-element device tensor): bounds the additive term of fold2/conv1 when the
+        fused kernels pick the activation scale of that layer"""
+        if enc.pmap_amax is None:
+            enc.pmap_amax = {}
+        if image_index not in enc.pmap_amax:
+            with torch.cuda.device(self.device):
+                enc.pmap_amax[image_index] = ops.amax(self.pmap_of(enc, image_index))
+        return enc.pmap_amax[image_index]
+
     def encode_query(self, imgs, pts, trans_mat, pts_rot=None, keep_featmap: bool = False):
         """-> (Encoded, pred_sdf [B,N]).  Nothing cached; B*N <= 65536.  The fc weight stream (HBM
         bound) overlaps the gather + local MLP on a second stream.  Without ``keep_featmap`` the
@@ -187,10 +208,12 @@ class SdfEngine:
         return Encoded(resized, taps, emb, featmap), sdf
 
     # rows D, F, G, H
-    def query(self, enc: Encoded, pts, trans_mat, pts_rot=None, fold: Optional[bool] = None) -> torch.Tensor:
+    def query(self, enc: Encoded, pts, trans_mat, pts_rot=None, fold: Optional[bool] = None,
+              fused: Optional[bool] = None) -> torch.Tensor:
         """pts [B,N,3] -> pred_sdf [B,N] (un-divided, as models/model_normalization.py:204).
         ``fold``: use the folded local stream (pmap_of; same math re-associated, fp32-rounding-level
-        difference); default: from FOLD_MIN_POINTS points per image on."""
+        difference); default: from FOLD_MIN_POINTS points per image on.  ``fused``: run the folded form
+        through the fused kernels (default: the engine's setting)."""
         pts = self._dev(pts)
         pts_rot = pts if pts_rot is None else self._dev(pts_rot)
         trans_mat = self._dev(trans_mat)
@@ -202,13 +225,17 @@ class SdfEngine:
             if fold:
                 B = pts.shape[0]
                 pm = self.pmap_of(enc, 0) if B == 1 else torch.stack([self.pmap_of(enc, b) for b in range(B)])
+                if self.fused if fused is None else fused:
+                    am = torch.cat([self.pmap_amax_of(enc, b) for b in range(B)])
+                    wsf = self._workspace("fused", lib().disn_query_fused_workspace_bytes(B, pts.shape[1]))
+                    return ops.query_fused(self.weights.mlp, pm, am, enc.embedding, trans_mat, pts, pts_rot, wsf)
                 return ops.query_folded(self.weights.mlp, pm, enc.embedding, trans_mat, pts, pts_rot, ws)
             return ops.query(self.weights.mlp, self.featmap_of(enc), enc.embedding, trans_mat, pts, pts_rot, ws)
 
     def query_grid(self, enc: Encoded, image_index: int, trans_mat, sdf_params, res: int,
                    k0: int = 0, k1: Optional[int] = None, sdf_weight: float = 10.0,
                    out: Optional[torch.Tensor] = None, pipelined: bool = False,
-                   fold: Optional[bool] = None) -> torch.Tensor:
+                   fold: Optional[bool] = None, fused: Optional[bool] = None) -> torch.Tensor:
         """rows J + D..H + '/SDF_WEIGHT' for grid points k0..k1-1 of one image.  ``fold``: folded local
         stream (see query(); the default unless ``pipelined`` -- for every range size, so that any slice of
         a grid equals the same slice of the whole grid up to the GEMM plan).  ``pipelined``:
@@ -224,6 +251,13 @@ class SdfEngine:
             ctx = self._ctx if pipelined else None
             if fold is None:
                 fold = not pipelined
+            if fold and (self.fused if fused is None else fused):
+                # one launch per MLP stream over the whole range (no chunks, no per-point activations in HBM)
+                ws = self._workspace("fused", lib().disn_query_grid_fused_workspace_bytes(k1 - k0))
+                return ops.query_grid_fused(self.weights.mlp, self.pmap_of(enc, image_index),
+                                            self.pmap_amax_of(enc, image_index),
+                                            enc.embedding[image_index:image_index + 1], tm.contiguous(), sdf_params,
+                                            res, k0, k1, sdf_weight, ws, out)
             if fold:
                 ws = self._workspace("grid", lib().disn_query_grid_workspace_bytes(k1 - k0))
                 return ops.query_grid(self.weights.mlp, None, enc.embedding[image_index:image_index + 1],

@@ -66,11 +66,19 @@ def resize_bilinear(x: torch.Tensor, out_h: int, out_w: int, out: Optional[torch
     return out
 
 
-def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool = True
-            ) -> torch.Tensor:
+def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool = True,
+            plan: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+    """plan = (BM, BN, workgroups): run under an explicit GEMM plan (disn_conv3x3_planned)"""
     x = _chk(x, "x")
     B, H, W, Cin = x.shape
     out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    if plan is not None:
+        bm, bn, wgs = plan
+        ws = _ws(lib().disn_conv3x3_planned_workspace_bytes(B, H, W, Cin, cout, bm, bn, wgs), x.device)
+        check("disn_conv3x3_planned", lib().disn_conv3x3_planned(
+            x.data_ptr(), B, H, W, Cin, w_packed.data_ptr(), bias.data_ptr(), cout, int(relu), out.data_ptr(),
+            ws.data_ptr(), ws.numel(), bm, bn, wgs, _stream()))
+        return out
     nb = lib().disn_conv3x3_workspace_bytes(B, H, W, Cin, cout)
     ws = _ws(nb, x.device)
     check("disn_conv3x3", lib().disn_conv3x3(x.data_ptr(), B, H, W, Cin, w_packed.data_ptr(),
@@ -239,6 +247,93 @@ def gather(featmap: torch.Tensor, xy: torch.Tensor, out: Optional[torch.Tensor] 
         out = torch.empty((B, N, FEAT_DIM), dtype=torch.float32, device=xy.device)
     check("disn_gather", lib().disn_gather(featmap.data_ptr(), xy.data_ptr(), B, N, out.data_ptr(),
                                            _stream()))
+    return out
+
+
+def gather_taps(taps: Sequence[torch.Tensor], trans_mat: torch.Tensor, pts: torch.Tensor,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """rows D + E + F without the feature map (disn_gather_taps): taps x pts [B,N,3] -> feat [B,N,1472]"""
+    pts = _chk(pts, "pts")
+    B, N, _ = pts.shape
+    if out is None:
+        out = torch.empty((B, N, FEAT_DIM), dtype=torch.float32, device=pts.device)
+    arr = (C.c_void_p * 5)(*[_chk(t, "tap").data_ptr() for t in taps])
+    check("disn_gather_taps", lib().disn_gather_taps(C.byref(arr), _chk(trans_mat, "trans_mat").data_ptr(),
+                                                     pts.data_ptr(), B, N, out.data_ptr(), _stream()))
+    return out
+
+
+def gather_fold(pmap_b: torch.Tensor, trans_mat_b: torch.Tensor, pts: torch.Tensor, pre: torch.Tensor,
+                bias: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """relu(pre + resample(pmap_b)(project(pts)) + bias) for N points of one image (disn_gather_fold)"""
+    pts, pre = _chk(pts, "pts"), _chk(pre, "pre")
+    N = pts.shape[0]
+    if out is None:
+        out = torch.empty((N, 512), dtype=torch.float32, device=pts.device)
+    check("disn_gather_fold", lib().disn_gather_fold(_chk(pmap_b, "pmap").data_ptr(),
+                                                     _chk(trans_mat_b, "trans_mat").data_ptr(), pts.data_ptr(), N,
+                                                     pre.data_ptr(), _chk(bias, "bias").data_ptr(),
+                                                     out.data_ptr(), _stream()))
+    return out
+
+
+def mlp_fused_pack(w2: torch.Tensor, w3: torch.Tensor, w4_point: torch.Tensor, w5: torch.Tensor) -> torch.Tensor:
+    """fused-kernel weight image of one MLP stream (disn_mlp_fused_pack) from its four MFMA-shaped layers,
+    TF [K][N]: fold1/conv2 [64,256], fold1/conv3 [256,512], fold2/conv1 point rows [512,512], fold2/conv2 [512,256]"""
+    ws = [_chk(t, "w") for t in (w2, w3, w4_point, w5)]
+    for t, shp in zip(ws, ((64, 256), (256, 512), (512, 512), (512, 256))):
+        if tuple(t.shape) != shp:
+            raise ValueError("mlp_fused_pack: expected %s, got %s" % (shp, tuple(t.shape)))
+    out = torch.empty(lib().disn_mlp_fused_image_bytes(), dtype=torch.uint8, device=ws[0].device)
+    check("disn_mlp_fused_pack", lib().disn_mlp_fused_pack(ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(),
+                                                           ws[3].data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
+def amax(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """max |x| as a 1-element device tensor (disn_amax); x.numel() % 4 == 0"""
+    x = _chk(x, "x")
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check("disn_amax", lib().disn_amax(x.data_ptr(), x.numel(), out.data_ptr(), _stream()))
+    return out
+
+
+def query_fused(w: MlpWeights, pmap: torch.Tensor, pmap_amax: torch.Tensor, embedding: torch.Tensor,
+                trans_mat: torch.Tensor, pts: torch.Tensor, pts_rot: Optional[torch.Tensor] = None,
+                ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """query_folded() through the fused point-MLP kernels; pmap [B,137*137,512], pmap_amax [B]"""
+    pts = _chk(pts, "pts")
+    pts_rot = pts if pts_rot is None else _chk(pts_rot, "pts_rot")
+    B, N, _ = pts.shape
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=pts.device)
+    need = lib().disn_query_fused_workspace_bytes(B, N)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, pts.device)
+    check("disn_query_fused", lib().disn_query_fused(
+        C.byref(w), _chk(pmap, "pmap").data_ptr(), _chk(pmap_amax, "pmap_amax").data_ptr(),
+        _chk(embedding, "embedding").data_ptr(), _chk(trans_mat, "trans_mat").data_ptr(), pts.data_ptr(),
+        pts_rot.data_ptr(), B, N, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def query_grid_fused(w: MlpWeights, pmap: torch.Tensor, pmap_amax: torch.Tensor, embedding: torch.Tensor,
+                     trans_mat: torch.Tensor, sdf_params, res: int, k0: int, k1: int, sdf_weight: float = 10.0,
+                     ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """disn_query_grid_fused: grid points k0..k1-1 of one image through the fused kernels, one launch per stream"""
+    dev = embedding.device
+    n = k1 - k0
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+    need = lib().disn_query_grid_fused_workspace_bytes(n)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, dev)
+    p6 = _params6(sdf_params)
+    check("disn_query_grid_fused", lib().disn_query_grid_fused(
+        C.byref(w), _chk(pmap, "pmap").data_ptr(), _chk(pmap_amax, "pmap_amax").data_ptr(),
+        _chk(embedding, "embedding").data_ptr(), _chk(trans_mat, "trans_mat").data_ptr(), C.byref(p6), res,
+        k0, k1, float(sdf_weight), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
     return out
 
 

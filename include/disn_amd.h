@@ -38,7 +38,7 @@ extern "C" {
 #define DISN_E_WS (-3)    /* workspace too small */
 
 /* ABI version of this header; disn_abi_version() returns the library's. */
-#define DISN_ABI_VERSION 3
+#define DISN_ABI_VERSION 4
 int disn_abi_version(void);
 
 /* ---------------------------------------------------------------------- *
@@ -110,6 +110,13 @@ size_t disn_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int disn_conv3x3(const float* in, int B, int H, int W, int Cin, const float* w_packed,
                  const float* bias, int Cout, int relu, float* out, void* ws, size_t ws_bytes,
                  void* stream);
+/* disn_conv3x3 under an EXPLICIT GEMM plan -- tile bm x bn in {64,128}^2 and `wgs` stream-K workgroups
+ * (-1: one per tile) -- instead of the cost model's choice.  The plan is a pure speed knob: every valid
+ * plan gives the same layer (tests/test_gpu_kernels.py::test_conv3x3_every_tile_config_and_splitk). */
+size_t disn_conv3x3_planned_workspace_bytes(int B, int H, int W, int Cin, int Cout, int bm, int bn, int wgs);
+int disn_conv3x3_planned(const float* in, int B, int H, int W, int Cin, const float* w_packed,
+                         const float* bias, int Cout, int relu, float* out, void* ws, size_t ws_bytes,
+                         int bm, int bn, int wgs, void* stream);
 int disn_maxpool2x2(const float* in, int B, int H, int W, int C, float* out, void* stream);
 /* out[b][n] = act(sum_k x[b][k] W[k][n] + bias[n]); ws >= disn_fc_workspace_bytes */
 size_t disn_fc_workspace_bytes(int B, int K, int N);
@@ -143,6 +150,17 @@ int disn_project(const float* pts, const float* trans_mat, int B, int N, float* 
  * xy [B,N,2] -> feat [B,N,1472] ('point_img_feat').  Bit-exact with the oracle. */
 int disn_gather(const float* featmap, const float* xy, int B, int N, float* feat, void* stream);
 
+/* Rows D + E + F without the feature map (what disn_encode_query runs with featmap == NULL): project
+ * pts [B,N,3] with trans_mat [B,4,3], up-sample the five taps (models/model_normalization.py:171-183) at
+ * the <= 4 pixels each point touches and resample (:172-190) -> feat [B,N,1472].  Bit-identical to
+ * disn_build_featmap + disn_project + disn_gather. */
+int disn_gather_taps(const float* const taps[5], const float* trans_mat, const float* pts, int B, int N,
+                     float* feat, void* stream);
+/* The gather of the folded local stream (see disn_fold_local): for N points of ONE image
+ * h[n][:] = relu(pre[n][:] + resample(pmap_b)(project(pts[n])) + bias), all [N,512]; h may alias pre. */
+int disn_gather_fold(const float* pmap_b, const float* trans_mat_b, const float* pts, int N, const float* pre,
+                     const float* bias, float* h, void* stream);
+
 /* ---------------------------------------------------------------------- *
  * Rows G + H: the two point MLPs and their sum --                          *
  * models/sdfnet.py:69-92 (scope 'sdfprediction'), :171-190 (scope          *
@@ -168,6 +186,8 @@ typedef struct disn_mlp_weights {
    * channels) -- and their disn_pack_kn_x3 images (optional again) */
   const float *l_w4_point, *l_w4_feat;
   const void *l_x4_point, *l_x4_feat;
+  /* optional, for the *_fused entry points: disn_mlp_fused_pack images of the two streams */
+  const void *g_fused, *l_fused;
 } disn_mlp_weights_t;
 
 /* scratch for one launch over B images x N points (N per image) */
@@ -268,6 +288,39 @@ int disn_query_grid_folded(const disn_mlp_weights_t* w, const float* pmap, const
                            const float* trans_mat, const double* sdf_params_host, int R,
                            int64_t k0, int64_t k1, float sdf_weight, float* out, void* ws,
                            size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------- *
+ * Fused point MLP (mlp_fused.hip): rows D, F (folded), G, H of one stream  *
+ * in ONE persistent kernel -- models/sdfnet.py:71-88 ('sdfprediction') and *
+ * :173-186 ('sdfprediction_imgfeat'), sum models/model_normalization.py:204*
+ * -- with every activation in registers; only the weights move (L2 -> LDS  *
+ * ring -> MFMA).  fp32-accurate products from a two-term fp16 split of     *
+ * every operand (x = h + l, 23 significant bits; power-of-two scales per   *
+ * layer for the weights and per point for the activations), fp32           *
+ * accumulation.  disn_mlp_fused_pack builds one stream's weight image from *
+ * its four MFMA-shaped layers in TF [K][N] layout: fold1/conv2 [64][256],  *
+ * fold1/conv3 [256][512], the 512 point rows of fold2/conv1 [512][512],    *
+ * fold2/conv2 [512][256]; set w->g_fused / w->l_fused.  The local stream   *
+ * gathers from pmap (disn_fold_local) and needs max|pmap| of each image    *
+ * (disn_amax) for its activation-scale bound.                              *
+ * ---------------------------------------------------------------------- */
+size_t disn_mlp_fused_image_bytes(void);
+int disn_mlp_fused_pack(const float* w2, const float* w3, const float* w4_point, const float* w5, void* image,
+                        void* stream);
+/* *out = max |x[i]|, n a multiple of 4 */
+int disn_amax(const float* x, int64_t n, float* out, void* stream);
+/* disn_query_folded / disn_query_grid_folded through the fused kernels (two launches per image: global
+ * stream, then local stream + sum + '/ sdf_weight').  pmap [B][137*137][512], pmap_amax [B].  Same math as
+ * the *_folded entry points; differs from them by fp32 rounding (tests/test_gpu_fused.py). */
+size_t disn_query_fused_workspace_bytes(int B, int64_t N);
+int disn_query_fused(const disn_mlp_weights_t* w, const float* pmap, const float* pmap_amax,
+                     const float* embedding, const float* trans_mat, const float* pts, const float* pts_rot,
+                     int B, int64_t N, float* sdf, void* ws, size_t ws_bytes, void* stream);
+size_t disn_query_grid_fused_workspace_bytes(int64_t max_points);
+int disn_query_grid_fused(const disn_mlp_weights_t* w, const float* pmap, const float* pmap_amax,
+                          const float* embedding, const float* trans_mat, const double* sdf_params_host, int R,
+                          int64_t k0, int64_t k1, float sdf_weight, float* out, void* ws, size_t ws_bytes,
+                          void* stream);
 
 /* disn_query_grid, chunk-pipelined over the context's two streams: the HBM-bound front of chunk
  * i+1 (grid points, projection, gather) runs under the MFMA-bound MLP of chunk i.  Same result. */

@@ -1,0 +1,77 @@
+"""CPU check of the fused point-MLP kernel's layout contract (disn_amd/csrc/mlp_fused.hip) through the
+lane-level emulation in tests/fused_emulation.py: packed stream order, slot <-> feature permutation,
+C-layout chaining, power-of-two scaling and the two-term fp16 split reproduce the plain MLP."""
+import numpy as np
+import pytest
+
+from tests import fused_emulation as E
+
+
+def _mlp_ref(w, consts, pts, add4, dtype=np.float64):
+    c = {k: np.asarray(v, dtype) for k, v in consts.items() if k != "addmax4"}
+    h = np.maximum(pts.astype(dtype) @ c["w1"] + c["b1"], 0)
+    h = np.maximum(h @ w[0].astype(dtype) + c["b2"], 0)
+    h = np.maximum(h @ w[1].astype(dtype) + c["b3"], 0)
+    z = h @ w[2].astype(dtype) + c["b4"]
+    if add4 is not None:
+        z = z + add4.astype(dtype)
+    h = np.maximum(z, 0)
+    h = np.maximum(h @ w[3].astype(dtype) + c["b5"], 0)
+    return h @ c["w6"] + c["b6"]
+
+
+def _make(seed, scale=1.0, with_add=True):
+    rng = np.random.default_rng(seed)
+    w = [(rng.standard_normal((k, n)) * np.sqrt(2.0 / k) * scale).astype(np.float32) for k, n in E.LAYER_DIMS]
+    consts = {"w1": (rng.standard_normal((3, 64)) * 0.8).astype(np.float32),
+              "b1": (rng.standard_normal(64) * 0.1).astype(np.float32),
+              "b2": (rng.standard_normal(256) * 0.1).astype(np.float32),
+              "b3": (rng.standard_normal(512) * 0.1).astype(np.float32),
+              "b4": (rng.standard_normal(512) * 0.1).astype(np.float32),
+              "b5": (rng.standard_normal(256) * 0.1).astype(np.float32),
+              "w6": (rng.standard_normal(256) * np.sqrt(1.0 / 256)).astype(np.float32),
+              "b6": np.float32(0.05)}
+    pts = (rng.random((32, 3)) * 2 - 1).astype(np.float32)
+    add4 = (rng.standard_normal((32, 512)) * 0.7).astype(np.float32) if with_add else None
+    consts["addmax4"] = float(np.abs(consts["b4"]).max() + (np.abs(add4).max() if with_add else 0.0))
+    return w, consts, pts, add4
+
+
+def test_pair_coords_cover_every_block_once():
+    seen = set()
+    for p in range(E.PAIRS):
+        seen.add(E.pair_coords(p))
+    assert len(seen) == E.PAIRS
+    for layer, (K, N) in enumerate(E.LAYER_DIMS):
+        assert sum(1 for c in seen if c[0] == layer) == (K // 16) * (N // 32)
+
+
+def test_phi_is_a_permutation_of_each_block():
+    g, t = np.meshgrid(np.arange(2), np.arange(8), indexing="ij")
+    for kb in (0, 3, 31):
+        assert sorted(E.phi(kb, g, t).ravel().tolist()) == list(range(16 * kb, 16 * kb + 16))
+
+
+def test_split_is_23_bit():
+    rng = np.random.default_rng(0)
+    v = (rng.standard_normal(100000) * 3000).astype(np.float32)
+    h, l = E.split16(v)
+    err = np.abs(v.astype(np.float64) - h.astype(np.float64) - l.astype(np.float64))
+    big = np.abs(v) > 0.125            # below 2^-3 the low term is subnormal: absolute error <= 2^-25
+    assert (err[big] <= np.abs(v[big]) * 2.0 ** -23).all()
+    assert (err[~big] <= 2.0 ** -25).all()
+
+
+@pytest.mark.parametrize("seed,scale,with_add", [(0, 1.0, True), (1, 1.0, False), (2, 0.05, True), (3, 30.0, True)])
+def test_emulated_kernel_matches_the_mlp(seed, scale, with_add):
+    w, consts, pts, add4 = _make(seed, scale, with_add)
+    img, meta = E.pack_image(*w)
+    got = E.fused_stream(img, meta, consts, pts, add4)
+    ref = _mlp_ref(w, consts, pts, add4)
+    ref32 = _mlp_ref(w, consts, pts, add4, np.float32)
+    sc = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max()) / sc
+    err32 = float(np.abs(ref32 - ref).max()) / sc
+    # the two-term path is as close to float64 as a plain float32 evaluation is (same order of magnitude)
+    assert err <= 3e-6, (err, err32)
+    assert err <= 4 * err32 + 2e-7, (err, err32)

@@ -44,7 +44,7 @@ def test_query_folded_vs_unfolded_and_oracle(eng_store, B, N):
     tms = np.stack([O.DEMO_TRANS_MAT[0], O.synth_trans_mat(30, 25, 0.8), O.synth_trans_mat(201.5, 30, 0.65)])[:B]
     enc = eng.encode(imgs)
     a = eng.query(enc, pts, tms, fold=False)
-    f = eng.query(enc, pts, tms, fold=True)
+    f = eng.query(enc, pts, tms, fold=True, fused=False)
     torch.cuda.synchronize()
     scale = float(a.abs().max())
     d = float((a - f).abs().max())
@@ -66,8 +66,8 @@ def test_grid_folded_vs_unfolded(eng_store):
     R, sp = 44, [-1, -0.9, -0.8, 1, 0.9, 0.8]          # 45^3 = 91125 points: one full chunk + a ragged one
     total = (R + 1) ** 3
     a = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, fold=False)
-    f = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R)             # default: folded
-    part = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, 70000, total)
+    f = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, fused=False)            # folded, layer-by-layer GEMMs
+    part = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, 70000, total, fused=False)
     torch.cuda.synchronize()
     assert f.shape == (total,)
     d = float((a - f).abs().max())

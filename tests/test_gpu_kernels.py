@@ -168,17 +168,17 @@ def test_conv3x3_vs_oracle(ops, B, H, W, Cin, Cout):
 @pytest.mark.parametrize("force", ["128,128,6", "128,64,12", "64,128,12", "64,64,24",   # data-parallel (W = tiles)
                                    "64,64,96", "128,128,18",                              # split-K (W = tiles*S)
                                    "128,128,7", "64,128,256", "64,64,500", "128,64,1", "64,64,864"])  # stream-K
-def test_conv3x3_every_tile_config_and_splitk(ops, force, monkeypatch):
+def test_conv3x3_every_tile_config_and_splitk(ops, force):
     """every tile shape and every stream-K workgroup count (BM,BN,W) gives the same answer: the
-    plan is a pure speed knob.  M = 380 rows, N = 256, 36 k-steps."""
-    monkeypatch.setenv("DISN_GEMM_FORCE", force)
+    plan is a pure speed knob (disn_conv3x3_planned).  M = 380 rows, N = 256, 36 k-steps."""
+    plan = tuple(int(v) for v in force.split(","))
     rng = np.random.default_rng(11)
     B, H, W, Cin, Cout = 1, 20, 19, 128, 256          # M = 380 (ragged), ksteps = 36
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
     w = (rng.standard_normal((3, 3, Cin, Cout)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
     ref = O.conv2d(x, w, b, "SAME", True, dtype=np.float64)
-    got = host(ops.conv3x3(dev(x), ops.pack_kn(dev(w.reshape(-1, Cout))), dev(b), Cout, True))
+    got = host(ops.conv3x3(dev(x), ops.pack_kn(dev(w.reshape(-1, Cout))), dev(b), Cout, True, plan=plan))
     report_close("conv3x3 force=%s" % force, got, ref, atol=2e-5, rtol=1e-5)
 
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, name), "library does not export %s" % name
     from disn_amd import _lib
     assert set(_lib.SIGNATURES) == declared, (set(_lib.SIGNATURES) ^ declared)
-    assert _lib.lib().disn_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib().disn_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_code_object_targets_gfx950():
@@ -203,3 +203,19 @@ def test_bench_and_entry_contract_static():
         assert key in src, key
     ent = open(os.path.join(ROOT, "__graft_entry__.py")).read()
     assert "def build(" in ent and "def smoke(" in ent
+
+
+def test_product_library_has_no_tuning_knobs():
+    """no environment variable is read and no knob is exported by the product library:
+    the knobs of csrc/tuning.hpp exist only in `build.py --tuning` builds"""
+    path = _build()
+    h = ctypes.CDLL(path)
+    assert not hasattr(h, "disn_tuning_set")
+    blob = open(path, "rb").read()
+    assert b"getenv" not in blob
+    for name in (b"DISN_X3", b"DISN_OVERLAP", b"DISN_BF_SPLITS", b"DISN_BF16_SKIP_PACK", b"DISN_GEMM_FORCE"):
+        assert name not in blob, name
+    csrc = os.path.join(ROOT, "disn_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".hpp")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f

@@ -1,0 +1,26 @@
+"""Knobs of the tuning build (disn_amd/csrc/tuning.hpp).  Tools only: build it with
+`python -m disn_amd.csrc.build --tuning` and run the tool with
+DISN_AMD_LIB=disn_amd/csrc/libdisn_amd_tuning.so (the product library has no knobs)."""
+import ctypes as C
+
+KEYS = {"x3": 0, "overlap": 1, "bf_splits": 2, "skip_pack": 3, "fused_safe": 4,
+        "gemm_bm": 5, "gemm_bn": 6, "gemm_wgs": 7}
+
+
+def set_knob(name: str, value: int) -> None:
+    from disn_amd import _lib
+    h = _lib.lib()
+    try:
+        fn = h.disn_tuning_set
+    except AttributeError:
+        raise SystemExit("this tool needs the tuning build: python -m disn_amd.csrc.build --tuning and "
+                         "DISN_AMD_LIB=disn_amd/csrc/libdisn_amd_tuning.so")
+    fn.restype, fn.argtypes = C.c_int, [C.c_int, C.c_int]
+    if fn(KEYS[name], int(value)) != 0:
+        raise ValueError(name)
+
+
+def gemm_force(bm: int = 0, bn: int = 0, wgs: int = 0) -> None:
+    set_knob("gemm_bn", bn)
+    set_knob("gemm_wgs", wgs)
+    set_knob("gemm_bm", bm)

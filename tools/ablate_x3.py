@@ -25,7 +25,7 @@ if sys.argv[1] == "build":
         objs[src] = os.path.join(CSRC, "build", "%s.%s.o" % (src, tag))
     for m in MASKS[1:]:
         o = os.path.join(CSRC, "build", "abl%d.o" % m)
-        subprocess.check_call([B.HIPCC] + B.COMMON + ["-DDISN_ABL=%d" % m, "-c", os.path.join(CSRC, "gemm_bf16_mfma.hip"), "-o", o])
+        subprocess.check_call([B.HIPCC] + B.COMMON + ["-DDISN_TUNING", "-DDISN_ABL=%d" % m, "-c", os.path.join(CSRC, "gemm_bf16_mfma.hip"), "-o", o])
         link = [o if s == "gemm_bf16_mfma.hip" else p for s, p in objs.items()]
         subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
                                os.path.join(CSRC, "build", "libdisn_abl%d.so" % m)] + link)

@@ -1,4 +1,5 @@
-"""Time the full step (disn_encode_query) on one stream (DISN_OVERLAP=0) and on two (default).
+"""Time the full step (disn_encode_query) on one stream (tuning knob overlap = 0) and on two (default).
+Needs the tuning build (tools/_tuning.py).
 (History: build r01c also had the tap up-samples on the auxiliary stream, bit 0 of the then bitmask,
 at several grid throttles -- 0.86-0.98 ms against 0.797 ms without; that path was removed.)"""
 import os, subprocess, sys
@@ -8,6 +9,8 @@ if len(sys.argv) > 1:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from disn_amd.engine import SdfEngine
     from disn_amd.weights import WeightStore
+    import _tuning
+    _tuning.set_knob("overlap", int(sys.argv[1]))
     eng = SdfEngine(WeightStore.random_init(0))
     rng = np.random.default_rng(0)
     img = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32)).cuda()
@@ -20,6 +23,5 @@ if len(sys.argv) > 1:
     torch.cuda.synchronize(); print("%.4f ms/step" % ((time.perf_counter() - t0) / 200 * 1e3))
 else:
     for ov in ("0", "1", "0", "1"):      # the switch is read once per process
-        env = dict(os.environ, DISN_OVERLAP=ov)
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "run"], env=env, capture_output=True, text=True)
-        print("DISN_OVERLAP=%s : %s" % (ov, out.stdout.strip() or out.stderr[-200:]), flush=True)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), ov], capture_output=True, text=True)
+        print("overlap=%s : %s" % (ov, out.stdout.strip() or out.stderr[-200:]), flush=True)

@@ -3,6 +3,7 @@ best plan per shape (input for the planner table in gemm_mfma.hip).  Timing: eve
 launch stream, includes the split-K reduce when S > 1."""
 import json, os, sys
 import torch
+import _tuning  # tuning build: DISN_AMD_LIB=disn_amd/csrc/libdisn_amd_tuning.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from disn_amd import ops
 
@@ -50,10 +51,10 @@ for cin, cout, hw in conv:
         if cout % bn:
             continue
         for s in wlist(B * hw * hw, cout, bm, bn, ksteps):
-            os.environ["DISN_GEMM_FORCE"] = "%d,%d,%d" % (bm, bn, s)
+            _tuning.gemm_force(bm, bn, s)
             us = timeit(lambda: ops.conv3x3(x, w, b, cout, True))
             rows.append((us, bm, bn, s))
-    os.environ.pop("DISN_GEMM_FORCE", None)
+    _tuning.gemm_force()
     auto = timeit(lambda: ops.conv3x3(x, w, b, cout, True))
     rows.sort()
     key = "conv B%d %dx%d %d->%d" % (B, hw, hw, cin, cout)
@@ -73,10 +74,10 @@ for M in (2048, 16384, 65536):
         rows = []
         for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
             for s in wlist(M, n, bm, bn, ksteps):
-                os.environ["DISN_GEMM_FORCE"] = "%d,%d,%d" % (bm, bn, s)
+                _tuning.gemm_force(bm, bn, s)
                 us = timeit(lambda: ops.dense(a1, w, b, n, True, a2))
                 rows.append((us, bm, bn, s))
-        os.environ.pop("DISN_GEMM_FORCE", None)
+        _tuning.gemm_force()
         auto = timeit(lambda: ops.dense(a1, w, b, n, True, a2))
         rows.sort()
         key = "dense M%d K%d N%d" % (M, k1 + k2, n)
