@@ -11,13 +11,24 @@ for 2048 random query points (BASELINE config 2: "1xMI355X: VGG-16 encode + 2048
 points, img_feat_twostream, fp32, random-init weights").  Inputs are resident in HBM before the
 timed region.  With N>1 every rank runs the same per-GPU workload on its own image / points
 (replicas: the 2048-point step has no exchange step), value = N*2048*K / max-over-ranks time.
+`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N
+ranks (one per GPU; on a box with fewer GPUs the ranks share devices -- plumbing only, it says so).
+
+--workload grid: BASELINE configs 3 / 4 end to end.  One STEP = encode the image batch (every rank,
+redundantly), evaluate the (R+1)^3 dense grid of every image with the flat index range sharded
+contiguously over the ranks (disn_amd/parallel.py: no data-path collective), ONE all_gather of the
+slices (RCCL over xGMI), marching cubes of image b on rank b % N.  N = 1: one image (config 3);
+N > 1: eight images (config 4).  value = grid points evaluated per second, whole job.
 
 Besides the contract line's fields the JSON carries
   roofline      -- the dominant kernel family (implicit-GEMM 3x3 conv, fp32 MFMA): algorithmic
                    FLOP of the 13 conv launches of one step / their summed duration measured with
                    events on the launch stream, against the 157.3 TFLOP/s fp32-MFMA peak;
-  roofline_gather / roofline_mlp -- the same for the gather (HBM-bound, 29 440 B/point) and the
-                   point MLP (fp32 MFMA, 3.67 MFLOP/point with the global block folded);
+  roofline_gather -- the gathers that are actually on the timed paths: project_gather_taps_kernel (the
+                   step), gather_fold_kernel (layer-by-layer dense grid), and gather_kernel from
+                   materialised maps incl. a 3-image case that exceeds the 256 MB Infinity Cache;
+  roofline_mlp  -- the fused point-MLP kernels (f16 MFMA pipes, two-term split: 3 MFMAs per block,
+                   ceiling 2500/3 = 833 TFLOP/s fp32-equivalent) and the layer-by-layer chain;
   query_only    -- encoder amortised (the >=1e7 pts/s target of north_star applies here);
   grid256       -- wall-clock of a full 257^3 dense-grid evaluation on this GPU (config 3, no MC);
   cpu_baseline  -- the oracle (numpy/torch-CPU restatement of the reference's algorithm as
@@ -117,6 +128,137 @@ def train_bench(args, torch, dist, dev, world, rank, launched):
             "final_loss": loss}
 
 
+def self_launch(args, argv):
+    """python bench.py --gpus N (N > 1) without a launcher: run N ranks of this script on this node"""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+DEMO_TM = [[-68.453156, 5.5086656, -0.37556022], [-17.138561, -84.685486, -0.250198],
+           [-47.284092, -3.6569588, 0.2493176], [101.133705, 101.34268, 1.4305686]]      # demo/demo.py:272-276
+PEAK_F16X2_TFLOPS = 2500.0 / 3.0   # two-term fp16 split: 3 MFMAs (2.5 PFLOP/s dense) per product block
+
+
+def grid_bench(args, torch, dist, dev, world, rank, launched, shared_gpu, backend):
+    """BASELINE config 3 (N = 1) / config 4 (N > 1), end to end, nothing cached between steps"""
+    from disn_amd import isosurface as iso
+    from disn_amd import parallel
+    from disn_amd.engine import SdfEngine
+    from disn_amd.weights import WeightStore
+    B = args.grid_images or (1 if world == 1 else 8)
+    R = args.grid_res
+    total = (R + 1) ** 3
+    eng = SdfEngine(WeightStore.random_init(0, mode="xavier"), dev, fused=not args.unfused)
+    rng = np.random.default_rng(7)                      # the same images on every rank (config 4 shards points)
+    imgs = torch.from_numpy(rng.random((B, 137, 137, 3), dtype=np.float32)).to(dev)
+    tms = torch.tensor([DEMO_TM] * B, dtype=torch.float32, device=dev)
+    params = [[-1, -1, -1, 1, 1, 1]] * B
+    mine = list(range(rank, B, world))
+
+    def step():
+        full = parallel.sharded_create_sdf(eng, imgs, tms, params, R)          # [B, total] on every rank
+        meshes = [iso.marching_cubes(full[b], params[b], R, 0.0) for b in mine]
+        return full, meshes
+
+    for _ in range(args.warmup):
+        full, meshes = step()
+    torch.cuda.synchronize()
+    if launched:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full, meshes = step()
+    torch.cuda.synchronize()
+    if launched:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if launched:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(full).all())
+    # ---- one instrumented step: where the time goes (synchronised phases; not part of the timed region) ----
+    def timed(fn):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - a
+    from disn_amd.create_sdf import dense_grid_sdf
+    enc, t_enc = timed(lambda: eng.encode(imgs))
+    k0, k1 = parallel.shard_range(total, world, rank)
+    pad = (total + world - 1) // world
+    mine_buf = torch.zeros((B, pad), dtype=torch.float32, device=dev)
+
+    def fill():
+        for b in range(B):
+            dense_grid_sdf(eng, enc, b, tms, params[b], R, out=mine_buf[b, :k1 - k0], k_range=(k0, k1))
+    _, t_fold = timed(lambda: [eng.pmap_amax_of(enc, b) for b in range(B)])
+    _, t_grid = timed(fill)
+    gath, t_gather = None, None
+    if launched:
+        gath = torch.empty((world, B, pad), dtype=torch.float32, device=dev)
+
+        def ag():
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gath.view(-1), mine_buf.view(-1))
+            else:
+                dist.all_gather(list(gath.unbind(0)), mine_buf)
+        _, t_gather = timed(ag)
+    _, t_mc = timed(lambda: [iso.marching_cubes(full[b], params[b], R, 0.0) for b in mine])
+    pts_rank = B * (k1 - k0)
+    flop_pt = MLP_FLOP_PER_PT - 2 * 1472 * 512           # executed: local fold2/conv1 folded into the map
+    peak = PEAK_FP32_MFMA_TFLOPS if args.unfused else PEAK_F16X2_TFLOPS
+    mlp_tf = pts_rank * flop_pt / t_grid / 1e12
+    value = B * total * args.steps / dt
+    nv = int(sum(m[0].shape[0] for m in meshes))
+    nf = int(sum(m[1].shape[0] for m in meshes))
+    return {
+        "metric": "dense-grid SDF points/sec, end to end (encode + %d^3 grid + RCCL gather + marching cubes)" % (R + 1),
+        "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True,
+        "scaling": "strong" if args.grid_images else ("weak" if world == 1 else "strong"),
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config %s: %d image(s) x %d^3 dense grid, query chunks sharded over %d "
+                               "rank(s), one all_gather, marching cubes; img_feat_twostream, fp32, random-init "
+                               "(xavier) weights, nothing cached between steps" % (
+                                   "3" if world == 1 else "4", B, R + 1, world),
+                   "images": B, "grid_points_per_image": total, "seconds_per_step": dt / args.steps,
+                   "seconds_per_image": dt / args.steps / B,
+                   "point_mlp": "layer-by-layer GEMMs (three-term bf16)" if args.unfused else
+                                "fused kernels (two-term fp16, activations in registers)",
+                   "parallelism": "contiguous flat-index slices x%d, redundant encode, one all_gather (%s)%s" % (
+                       world, backend if launched else "none: single process",
+                       "; ranks SHARE GPUs (plumbing run, not a scaling measurement)" if shared_gpu else "")},
+        "phases_rank0": {"encode_s": t_enc, "fold_local_s": t_fold, "grid_slice_s": t_grid,
+                         "all_gather_s": t_gather, "marching_cubes_s": t_mc,
+                         "note": "one extra step with a host sync between phases (their sum exceeds the "
+                                 "overlapped step)"},
+        "roofline": {"kernel": "mlp_fused_kernel<global> + <local>" if not args.unfused else "gemm_bf16_mfma<128,128,DENSE,3> chain",
+                     "bound": "mfma", "achieved": mlp_tf, "peak": peak, "unit": "TFLOP/s", "frac": mlp_tf / peak,
+                     "traffic": None, "flop_per_point": flop_pt, "points_this_rank": pts_rank,
+                     "seconds_this_rank": t_grid,
+                     "frac_of_f32_mfma_peak": mlp_tf / PEAK_FP32_MFMA_TFLOPS,
+                     "note": "executed flops of this rank's grid slices / their wall time (gather from the "
+                             "folded map and the final dot included in the time)"},
+        "all_gather": None if t_gather is None else {
+            "bytes_received_per_rank": int(world * B * pad * 4), "seconds": t_gather,
+            "GB_per_s": world * B * pad * 4 / t_gather / 1e9, "backend": backend},
+        "mesh": {"vertices": nv, "triangles": nf, "images_meshed_on_rank0": len(mine)},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,8 +266,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / grid / cpu legs")
     ap.add_argument("--cpu-runs", type=int, default=5)
-    ap.add_argument("--workload", choices=("query", "train"), default="query",
-                    help="query: BASELINE.json metric (default); train: config-5 training step")
+    ap.add_argument("--workload", choices=("query", "grid", "train"), default="query",
+                    help="query: BASELINE.json metric (default); grid: configs 3/4 (dense grid + gather + marching "
+                         "cubes); train: config-5 training step")
+    ap.add_argument("--grid-res", type=int, default=256)
+    ap.add_argument("--grid-images", type=int, default=0, help="0: 1 image at N=1 (config 3), 8 at N>1 (config 4)")
+    ap.add_argument("--unfused", action="store_true",
+                    help="dense-grid / large queries through the layer-by-layer GEMM chain instead of the fused kernels")
+    ap.add_argument("--dist-backend", choices=("auto", "nccl", "gloo"), default="auto",
+                    help="auto: nccl (= RCCL); gloo when ranks must share a GPU (RCCL rejects duplicate devices)")
     ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step")
     ap.add_argument("--train-dtype", choices=("f32", "f32_mfma", "bf16"), default="f32",
                     help="--workload train: f32 = the reference's precision (forward / data-gradient GEMMs as "
@@ -133,18 +282,27 @@ def main():
                          "on the f32-input MFMA); bf16 = mixed precision (bf16 multiply, fp32 accumulate / "
                          "master weights / optimizer)")
     args = ap.parse_args()
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # torch.distributed.run / torchrun
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # torch.distributed.run / torchrun
+    shared_gpu, backend = False, "nccl"
     if launched:       # also with one rank: same RCCL init / barrier / all-reduce sequence as N ranks
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        ndev = torch.cuda.device_count()
+        shared_gpu = world > ndev            # fewer GPUs than ranks: ranks share devices (plumbing runs only)
+        torch.cuda.set_device(local % ndev)
+        backend = args.dist_backend if args.dist_backend != "auto" else ("gloo" if shared_gpu else "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
@@ -155,6 +313,14 @@ def main():
     from disn_amd.engine import SdfEngine
     from disn_amd.weights import WeightStore
 
+    if args.workload == "grid":
+        line = grid_bench(args, torch, dist, dev, world, rank, launched, shared_gpu, backend)
+        if rank == 0:
+            print(json.dumps(line))
+        if launched:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload == "train":
         # BASELINE config 5 (not the north-star metric): data-parallel training step, B images x 2048
         # points per GPU, fp32, TF Adam; gradients exchanged by RCCL under the convolution backward
@@ -171,9 +337,7 @@ def main():
     rng = np.random.default_rng(1000 + rank)
     img = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32)).to(dev)
     pts = torch.from_numpy((rng.random((1, N_POINTS, 3), dtype=np.float32) * 2 - 1).astype(np.float32)).to(dev)
-    tm = torch.tensor([[[-68.453156, 5.5086656, -0.37556022], [-17.138561, -84.685486, -0.250198],
-                        [-47.284092, -3.6569588, 0.2493176], [101.133705, 101.34268, 1.4305686]]],
-                      dtype=torch.float32, device=dev)       # demo/demo.py:272-276
+    tm = torch.tensor([DEMO_TM], dtype=torch.float32, device=dev)
 
     def step():
         # rows A..H, every step, through the single overlapped entry (disn_encode_query)
@@ -207,7 +371,8 @@ def main():
         "config": {"workload": "BASELINE config 2: VGG-16 encode + 2048 random query points, img_feat_twostream, "
                                "fp32, random-init (xavier) weights, nothing cached between steps",
                    "images_per_step_per_gpu": 1, "points_per_step_per_gpu": N_POINTS,
-                   "parallelism": "replicas x%d (no data-path collective)" % world},
+                   "parallelism": "replicas x%d (no data-path collective)%s" % (
+                       world, "; ranks SHARE GPUs (plumbing run)" if shared_gpu else "")},
     }
 
     if rank == 0:
@@ -218,12 +383,11 @@ def main():
         # split ("x3": fp32-accurate, bf16 MFMA pipes) wherever api.hip selects it, else the
         # f32-input MFMA kernel (conv1_1, K = 27).
         layers, tot_ms, tot_flop = [], 0.0, 0.0
-        x3_off = os.environ.get("DISN_X3", "1") == "0"
         for cin, cout, hw in VGG_LAYERS:
             x = torch.rand((1, hw, hw, cin), device=dev)
             wraw = torch.randn((9 * cin, cout), device=dev) * (2.0 / (9 * cin)) ** 0.5
             b = torch.zeros(cout, device=dev)
-            use_x3 = cin != 3 and not x3_off
+            use_x3 = cin != 3
             if use_x3:
                 w3 = ops.pack_kn_x3(wraw)
                 wsb = torch.empty(max(ops.lib().disn_conv3x3_x3_workspace_bytes(1, hw, hw, cin, cout), 256),
@@ -239,9 +403,10 @@ def main():
             tot_ms += ms
             tot_flop += fl
         ach = tot_flop / tot_ms / 1e9
-        # HBM-side bytes of the same 13 launches from the PMC passes of the last profiled round
-        # (profiles/pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch
-        # correction, write counter calibrated on the gather's known output bytes); None if absent
+        # HBM-side bytes of the same 13 launches from the PMC passes of the last profiled build
+        # (profiles/pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/gpu_pmc_traffic.sh,
+        # gfx950 x2 fetch correction, write counter calibrated on the gather's known output bytes); the file
+        # names the build it was measured on -- None if absent
         traffic, pmc = None, {}
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -258,58 +423,117 @@ def main():
                                          "the three-term kernels issue bf16 MFMAs whose fp32-equivalent ceiling is "
                                          "2500/6 = 417 TFLOP/s",
                             "frac_of_three_term_ceiling": ach / peak_x3, "traffic": traffic,
+                            "traffic_measured_on": pmc.get("build"),
                             "traffic_note": "memory-side bytes per step of the 13 conv launches + their split-K "
                                             "reduces (FETCH_SIZE x2 + calibrated WRITE_SIZE; L2 misses served by MALL "
-                                            "count), PMC passes tools/gpu_pmc_traffic.sh -> profiles/pmc_traffic.json; "
+                                            "count), replayed from profiles/pmc_traffic.json (PMC passes of "
+                                            "tools/gpu_pmc_traffic.sh on the build named in traffic_measured_on); "
                                             "algorithmic ~180 MB (three-plane bf16 weights 88 + inputs 36 + outputs 54)",
                             "flop_per_step": tot_flop, "ms_per_step": tot_ms, "layers": layers}
-        # ---- gather (HBM bound) -----------------------------------------------------------------
+        # ---- gathers (HBM / cache bound): the kernels that ARE on the timed paths ---------------------
+        ACHIEVABLE = 6300.0      # MI355X_MICROARCH.md: measured float4-copy HBM rate; above it = cache bandwidth
         enc = eng.encode(img)
+        eng.featmap_of(enc)
         g = {}
-        for n in (N_POINTS, 262144):
-            p = torch.rand((1, n, 3), device=dev) * 2 - 1
-            xy = ops.project(p, tm)
-            feat = torch.empty((1, n, 1472), device=dev)
-            ms = ev_time_ms(lambda: ops.gather(enc.featmap, xy, feat), 20, torch)
-            gbs = n * GATHER_BYTES_PER_PT / ms / 1e6
-            g["n%d" % n] = {"ms": ms, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS,
-                            "traffic": (pmc.get("gather_n%d" % n) or {}).get("hbm_bytes"),
-                            "algorithmic_bytes": n * GATHER_BYTES_PER_PT}
-        line["roofline_gather"] = {"kernel": "gather_kernel", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "bytes_per_point": GATHER_BYTES_PER_PT, **g}
-        # ---- point MLP + query-only (encoder amortised) ------------------------------------------
+
+        def gline(ms, alg_bytes, note, traffic_key=None):
+            gbs = alg_bytes / ms / 1e6
+            d = {"ms": ms, "algorithmic_bytes": alg_bytes, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS,
+                 "traffic": (pmc.get(traffic_key) or {}).get("hbm_bytes") if traffic_key else None, "note": note}
+            if gbs > ACHIEVABLE:
+                d["exceeds_achievable_hbm"] = ("%.0f GB/s is above the ~6300 GB/s HBM can stream: the source is "
+                                               "served by L2 / the 256 MB Infinity Cache" % gbs)
+            return d
+        # (1) the step's gather: project_gather_taps_kernel, 2048 points, taps resident in L2 / MALL.  Its
+        #     algorithmic bytes in SURVEY 8(d)'s terms (a materialised map): 29 440 B/point; what it actually
+        #     reads are 16 tap pixels per output float4 = 94 208 B/point of (cached) tap data + 5 888 written
+        p2k = torch.rand((1, N_POINTS, 3), device=dev) * 2 - 1
+        feat2k = torch.empty((1, N_POINTS, 1472), device=dev)
+        ms = ev_time_ms(lambda: ops.gather_taps(enc.taps, tm, p2k, feat2k), 20, torch)
+        g["step_project_gather_taps_n2048"] = gline(
+            ms, N_POINTS * GATHER_BYTES_PER_PT,
+            "the gather of the timed step (hidden under fc6 on the auxiliary stream); 29 440 B/point convention; "
+            "it reads %d B/point of L2/MALL-resident tap pixels" % (94208 + 5888), "gather_taps_n2048")
+        # (2) the dense grid's gather in the layer-by-layer path: gather_fold_kernel, 65 536 points of one
+        #     chunk: 4 x 2 KB pmap rows + 2 KB pre-activation read + 2 KB written per point = 12 288 B/point
+        p64k = torch.rand((65536, 3), device=dev) * 2 - 1
+        pm = eng.pmap_of(enc, 0)
+        pre = torch.rand((65536, 512), device=dev)
+        bias = torch.zeros(512, device=dev)
+        h = torch.empty((65536, 512), device=dev)
+        ms = ev_time_ms(lambda: ops.gather_fold(pm, tm[0].contiguous(), p64k, pre, bias, h), 20, torch)
+        g["grid_gather_fold_n65536"] = gline(
+            ms, 65536 * 12288, "layer-by-layer dense-grid path (--unfused); the 38 MB pmap is cache resident, "
+            "only the 2 x 134 MB activation rows stream; in the fused kernels this gather is 16 LDS-DMA loads per "
+            "tile inside mlp_fused_kernel<local> and has no launch of its own", "gather_fold_n65536")
+        # (3) gather_kernel from a materialised map (disn_query): 1 image (110 MB map: Infinity-Cache resident)
+        #     and 3 images (331 MB of maps: exceeds the 256 MB cache, so the reads are HBM reads)
+        for nimg, n in ((1, N_POINTS), (1, 262144), (3, 262144)):
+            fm = enc.featmap if nimg == 1 else enc.featmap.expand(3, -1, -1, -1).contiguous()
+            p = torch.rand((nimg, n, 3), device=dev) * 2 - 1
+            xy = ops.project(p, tm.expand(nimg, -1, -1).contiguous())
+            feat = torch.empty((nimg, n, 1472), device=dev)
+            ms = ev_time_ms(lambda: ops.gather(fm, xy, feat), 10, torch)
+            g["gather_kernel_%dimg_n%d" % (nimg, n)] = gline(
+                ms, nimg * n * GATHER_BYTES_PER_PT,
+                "disn_gather from %d materialised map(s) of 110.5 MB%s" % (
+                    nimg, " (> Infinity Cache: an HBM measurement)" if nimg == 3 else " (cache resident)"),
+                "gather_n%d" % n if nimg == 1 else None)
+            del fm, p, xy, feat
+        line["roofline_gather"] = {"bound": "hbm", "peak": PEAK_HBM_GBS, "achievable": ACHIEVABLE, "unit": "GB/s",
+                                   "bytes_per_point_convention": GATHER_BYTES_PER_PT, **g}
+        del pre, h, p64k, feat2k
+        # ---- point MLP + query-only (encoder amortised): fused kernels and the layer-by-layer chain ----------
+        from disn_amd.engine import FOLD_MIN_POINTS
         q = {}
-        for n in (N_POINTS, 65536, 262144):
+        for n in (N_POINTS, 65536, 262144, 1048576):
             p = torch.rand((1, n, 3), device=dev) * 2 - 1
-            from disn_amd.engine import FOLD_MIN_POINTS
             folded = n >= FOLD_MIN_POINTS       # engine default: local fold2/conv1 folded into the feature map
-            eng.query(enc, p, tm)               # (builds the folded map once; it is per-image state)
-            ms = ev_time_ms(lambda: eng.query(enc, p, tm), 10, torch)
             flop = MLP_FLOP_PER_PT - (2 * 1472 * 512 if folded else 0)
-            q["n%d" % n] = {"ms": ms, "points_per_s": n / ms * 1e3, "folded_local_stream": folded,
-                            "executed_flop_per_point": flop,
-                            "mlp_tflops_lower_bound": n * flop / ms / 1e9}
+            e = {"folded_local_stream": folded, "executed_flop_per_point": flop}
+            for name, kw in (("fused", {"fused": True}), ("layer_by_layer", {"fused": False})):
+                if name == "fused" and not folded:
+                    continue                     # the engine uses the fused kernels for the folded form only
+                if name == "layer_by_layer" and n > 262144:
+                    continue
+                eng.query(enc, p, tm, **kw)      # (builds the folded map once; it is per-image state)
+                ms = ev_time_ms(lambda: eng.query(enc, p, tm, **kw), 10 if n <= 262144 else 5, torch)
+                e[name] = {"ms": ms, "points_per_s": n / ms * 1e3, "mlp_tflops_lower_bound": n * flop / ms / 1e9}
+            e["points_per_s"] = max(v["points_per_s"] for k, v in e.items() if isinstance(v, dict))
+            q["n%d" % n] = e
         line["query_only"] = q
-        best = max(v["mlp_tflops_lower_bound"] for v in q.values())
-        line["roofline_mlp"] = {"kernel": "gemm_bf16_mfma<128,128,DENSE,3> x8 (+gather, embed, final) per chunk",
-                                "bound": "mfma", "achieved": best, "peak": PEAK_FP32_MFMA_TFLOPS,
-                                "unit": "TFLOP/s", "frac": best / PEAK_FP32_MFMA_TFLOPS,
-                                "flop_per_point": MLP_FLOP_PER_PT - 2 * 1472 * 512,
-                                "note": "EXECUTED flops: from 32768 points per image on the 1472 feature rows "
-                                        "of the local fold2/conv1 are pre-multiplied into the feature map once per "
-                                        "image (disn_fold_local, 28 GFLOP), which removes 1.51 of the 3.67 "
-                                        "MFLOP/point as written; the whole chunk (gather, embed, final) is in "
-                                        "the time, so this is a lower bound on the GEMM rate"}
+        bf = max(v["fused"]["mlp_tflops_lower_bound"] for v in q.values() if "fused" in v)
+        bl = max(v["layer_by_layer"]["mlp_tflops_lower_bound"] for v in q.values() if "layer_by_layer" in v)
+        line["roofline_mlp"] = {
+            "kernel": "mlp_fused_kernel<global> + mlp_fused_kernel<local> (two launches per point set)",
+            "bound": "mfma", "achieved": bf, "peak": PEAK_F16X2_TFLOPS, "unit": "TFLOP/s", "frac": bf / PEAK_F16X2_TFLOPS,
+            "frac_of_f32_mfma_peak": bf / PEAK_FP32_MFMA_TFLOPS,
+            "flop_per_point": MLP_FLOP_PER_PT - 2 * 1472 * 512,
+            "layer_by_layer": {"kernel": "gemm_bf16_mfma<128,128,DENSE,3> x8 (+gather, embed, final) per chunk",
+                               "achieved": bl, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": bl / PEAK_FP32_MFMA_TFLOPS},
+            "note": "EXECUTED fp32-equivalent flops (2.16 MFLOP/point: the 1472 feature rows of the local "
+                    "fold2/conv1 are pre-multiplied into the feature map once per image, disn_fold_local) / wall "
+                    "time of the whole query (projection, gather, final dot included): a lower bound on the MFMA "
+                    "rate.  Peak of the fused kernels = f16 MFMA dense peak / 3 MFMAs per product block"}
         # ---- config 3: full 257^3 grid on one GPU (no marching cubes yet) -----------------------
         from disn_amd import create_sdf as cs
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        enc3 = eng.encode(img)
-        full = cs.dense_grid_sdf(eng, enc3, 0, tm, [-1, -1, -1, 1, 1, 1], 256)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter() - t0
-        line["grid256"] = {"points": 257 ** 3, "seconds": t1, "points_per_s": 257 ** 3 / t1,
-                           "includes": "encode + all chunks + /10, single GPU, no marching cubes"}
+        g256 = {}
+        for name, fz in (("fused", True), ("layer_by_layer", False)):
+            eng.fused = fz
+            cs.dense_grid_sdf(eng, eng.encode(img), 0, tm, [-1, -1, -1, 1, 1, 1], 256)   # warm-up (workspaces)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            enc3 = eng.encode(img)
+            full = cs.dense_grid_sdf(eng, enc3, 0, tm, [-1, -1, -1, 1, 1, 1], 256)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter() - t0
+            g256[name] = {"seconds": t1, "points_per_s": 257 ** 3 / t1}
+        eng.fused = True
+        line["grid256"] = {"points": 257 ** 3, "seconds": g256["fused"]["seconds"],
+                           "points_per_s": g256["fused"]["points_per_s"], **g256,
+                           "includes": "encode + feature-map fold + every grid point + /10, single GPU, no marching "
+                                       "cubes; `fused`: mlp_fused_kernel (engine default), `layer_by_layer`: the "
+                                       "65536-point chunks of GEMM launches (round-1 path)"}
         # config 3 end to end: + marching cubes on the device (+ the .obj the reference writes)
         from disn_amd import isosurface as iso
         iso.marching_cubes(full, [-1, -1, -1, 1, 1, 1], 256, 0.0)         # warm-up (workspace, code)
@@ -363,36 +587,49 @@ def main():
         except Exception as e:  # the north-star line must survive a failure of this leg
             line["train_step"] = {"error": repr(e)}
         # ---- CPU baseline: the oracle on the same workload, host cores -----------------------------
+        # The reference's algorithm as written (VGG + five materialised 137x137 up-samples + resampler +
+        # unfused MLPs), stage by stage.  The two numpy-bound stages (legacy resize, resampler) are timed
+        # through their torch-CPU forms (bit-identical, tests/test_oracle.py) so that they use the host's
+        # threads like the conv / MLP stages (MKL / oneDNN) do.
         from oracle import disn_oracle as O
         Wn = store.arrays
-        feed = {"imgs": img.cpu().numpy(), "sample_pc": pts.cpu().numpy(), "sample_pc_rot": pts.cpu().numpy(),
-                "trans_mat": tm.cpu().numpy()}
-        O.get_model(feed, Wn)
-        ts = []
+        f_img, f_pts, f_tm = img.cpu().numpy(), pts.cpu().numpy(), tm.cpu().numpy()
+
+        def cpu_step(stages=None):
+            t = [time.perf_counter()]
+            resized = O.resize_bilinear_legacy_mt(f_img, 224, 224); t.append(time.perf_counter())
+            emb, eps = O.vgg16(resized, Wn); t.append(time.perf_counter())
+            maps = [O.resize_bilinear_legacy_mt(np.asarray(eps["vgg_16/%s/%s" % (nm[:5], nm)], np.float32), 137, 137)
+                    for nm in O.TAP_NAMES]; t.append(time.perf_counter())
+            xy = O.get_img_points(f_pts, f_tm)
+            feat = np.concatenate([O.resampler_mt(m, xy) for m in maps], axis=2)[:, :, None, :]; t.append(time.perf_counter())
+            pred = (O.get_sdf_basic2(f_pts, emb, Wn) + O.get_sdf_basic2_imgfeat_twostream(f_pts, feat, Wn))
+            t.append(time.perf_counter())
+            if stages is not None:
+                for k, (a_, b_) in zip(("resize_224", "vgg16", "upsample_5_taps", "project_resample", "point_mlps"),
+                                       zip(t[:-1], t[1:])):
+                    stages.setdefault(k, []).append(b_ - a_)
+            return t[-1] - t[0], pred
+        _, pred_cpu = cpu_step()
+        ts, stages = [], {}
         for _ in range(max(1, args.cpu_runs)):
-            t0 = time.perf_counter()
-            O.get_model(feed, Wn)
-            ts.append(time.perf_counter() - t0)
+            ts.append(cpu_step(stages)[0])
         med = float(np.median(ts))
         cpu_name = ""
         try:
             cpu_name = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
         except Exception:
             pass
-        # one-thread figure: torch intra-op threads = 1; numpy's BLAS pool is limited through
-        # threadpoolctl when available
         nthreads = torch.get_num_threads()
         one = None
-        try:
+        try:   # one-thread figure
             torch.set_num_threads(1)
             try:
                 from threadpoolctl import threadpool_limits
                 limiter = threadpool_limits(limits=1)
             except Exception:
                 limiter = None
-            t0 = time.perf_counter()
-            O.get_model(feed, Wn)
-            one = time.perf_counter() - t0
+            one = cpu_step()[0]
             if limiter is not None:
                 limiter.unregister() if hasattr(limiter, "unregister") else limiter.restore_original_limits()
         except Exception:
@@ -401,7 +638,9 @@ def main():
             torch.set_num_threads(nthreads)
         line["cpu_baseline"] = {"value": N_POINTS / med, "unit": "points/s", "cores": nthreads,
                                 "kind": "port", "seconds_per_step": med,
+                                "stage_seconds_median": {k: float(np.median(v)) for k, v in stages.items()},
                                 "value_1thread": (N_POINTS / one) if one else None,
+                                "max_abs_gpu_minus_cpu_oracle": float(np.abs(out.cpu().numpy() - pred_cpu[..., 0]).max()),
                                 "sample": "%d full steps (encode + 2048 points) of the numpy/torch-CPU oracle after "
                                           "1 warm-up, median; nproc=%d; %s" % (len(ts), os.cpu_count(), cpu_name)}
     if rank == 0:

@@ -181,6 +181,7 @@ struct BfDev {
   float* ws;
   int nsplit;  // 1: bf16 product; 3: fp32-accurate product from three bf16 terms per operand
   float* pool_out;  // CONV3 with S > 1: the split-K reduce also writes the 2x2 max pool here
+  int nmajor;       // workgroup order n-tile major (weight-stationary per XCD) instead of m-tile major
 };
 
 // NS = 1: plain bf16 multiply.  NS = 3: fp32-accurate product on the bf16 pipes ("3xBF16"): every
@@ -207,15 +208,33 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  int w = blockIdx.x;
-  {  // XCD-aware: consecutive tiles (sharing A rows) on the same XCD / L2
+  // XCD-aware placement (hardware workgroup L runs on XCD L % 8; each XCD has its own 4 MB L2).
+  int mt, nt, ks;
+  if (d.nmajor) {
+    // weight-stationary: the operand worth keeping in one L2 is B (the 14x14 / 28x28 convolutions: 14 MB of
+    // three-plane weights against <= 1.6 MB of input).  Every XCD gets a CONTIGUOUS eighth of the order
+    // (n-tile, k-split, m-tile): all m-tiles of one (n-tile, k-split) -- the workgroups that read the same
+    // weight slice -- sit on one XCD, and with N/BN == 8 an XCD reads one n-tile's columns only: B crosses
+    // the fabric once instead of eight times (measured r01: 117 MB fetched per conv4_x layer for 14.2 MB).
+    const int T = gridDim.x * gridDim.y, L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = L & 7, idx = L >> 3;
+    const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per = d.S * d.mtiles;
+    nt = l / per;
+    const int rem = l - nt * per;
+    ks = rem / d.mtiles;
+    mt = rem - ks * d.mtiles;
+  } else {  // consecutive tiles (sharing A rows) on the same XCD
+    int w = blockIdx.x;
     const int W = gridDim.x, q = W >> 3, r = W & 7, xcd = w & 7, idx = w >> 3;
     w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    mt = w / d.ntiles;
+    nt = w - mt * d.ntiles;
+    ks = blockIdx.y;
   }
-  const int mt = w / d.ntiles, nt = w - mt * d.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
   const int KS_all = p.K >> 5;
-  const int s0 = (int)(((long)KS_all * blockIdx.y) / d.S), s1 = (int)(((long)KS_all * (blockIdx.y + 1)) / d.S);
+  const int s0 = (int)(((long)KS_all * ks) / d.S), s1 = (int)(((long)KS_all * (ks + 1)) / d.S);
 
   // ---- A loader: one row per 8-lane octet (+ 32 rows per pass), float4 column (tid&7) -------------
   // each 8-lane octet takes one row; the octets of a wave take rows 0,4,1,5,2,6,3,7 of its 8-row band, so
@@ -409,7 +428,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
           const int row = m0 + wm * (BM / 2) + i * 32 + rr;
           if (row < p.M) {
             if (d.S > 1) {
-              *reinterpret_cast<float4*>(d.ws + ((size_t)blockIdx.y * p.M + row) * p.N + col) = v;
+              *reinterpret_cast<float4*>(d.ws + ((size_t)ks * p.M + row) * p.N + col) = v;
             } else {
               v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
               if (p.relu) {
@@ -434,7 +453,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
         const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < p.M) {
           if (d.S > 1) {
-            d.ws[((size_t)blockIdx.y * p.M + row) * p.N + col] = acc[i][j][r];
+            d.ws[((size_t)ks * p.M + row) * p.N + col] = acc[i][j][r];
           } else {
             float v = acc[i][j][r] + bv;
             if (p.relu) v = fmaxf(v, 0.f);
@@ -499,6 +518,7 @@ hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk,
                             size_t ws_bytes, hipStream_t st, int nsplit, float* pool_out, bool* pooled) {
   BfDev d;
   d.pool_out = nullptr;
+  d.nmajor = 0;
   if (pooled) *pooled = false;
   d.p = p;
   d.nsplit = nsplit == 3 ? 3 : 1;
@@ -515,6 +535,11 @@ hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk,
   }
   d.mtiles = (p.M + 63) / 64; d.ntiles = p.N / 64;
   d.S = ws ? bf_splits((long)d.mtiles * d.ntiles, p.K / 32, p.M, p.N, ws_bytes) : 1;
+  {  // keep the LARGER operand stationary in the XCDs' L2s: bytes of the weight image vs bytes of the input
+    const size_t b_bytes = (size_t)p.K * p.N * 2 * (nsplit == 3 ? 3 : 1);
+    const size_t a_bytes = (size_t)p.M * (mode == GEMM_CONV3 ? p.Cin : p.K) * sizeof(float);
+    d.nmajor = b_bytes > a_bytes;
+  }
   if (pool_out && pooled && d.S > 1 && mode == GEMM_CONV3 && p.ldc == p.N && !(p.H & 1) && !(p.W & 1)) {
     d.pool_out = pool_out;
     *pooled = true;

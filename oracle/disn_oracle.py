@@ -156,6 +156,58 @@ def resize_bilinear_legacy(img: np.ndarray, out_h: int, out_w: int) -> np.ndarra
     return (top + (bot - top) * yl).astype(np.float32)
 
 
+def resize_bilinear_legacy_mt(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """resize_bilinear_legacy with torch-CPU element-wise ops (multi-threaded): the same expressions in the
+    same order, one float32 rounding per operation, so the result is bit-identical to the numpy form
+    (tests/test_oracle.py).  Only bench.py's cpu_baseline leg uses it, so that the CPU figure is not
+    dominated by single-threaded numpy fancy indexing."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))
+    B, H, W, C = t.shape
+    ylo, yhi, yl = resize_index_table(H, out_h)
+    xlo, xhi, xl = resize_index_table(W, out_w)
+    ylo, yhi, xlo, xhi = (torch.from_numpy(a) for a in (ylo, yhi, xlo, xhi))
+    xl = torch.from_numpy(xl)[None, None, :, None]
+    yl = torch.from_numpy(yl)[None, :, None, None]
+    rows_lo, rows_hi = t.index_select(1, ylo), t.index_select(1, yhi)
+    tl, tr = rows_lo.index_select(2, xlo), rows_lo.index_select(2, xhi)
+    bl, br = rows_hi.index_select(2, xlo), rows_hi.index_select(2, xhi)
+    top = tl + (tr - tl) * xl
+    bot = bl + (br - bl) * xl
+    return (top + (bot - top) * yl).numpy()
+
+
+def resampler_mt(data: np.ndarray, warp: np.ndarray) -> np.ndarray:
+    """resampler with torch-CPU ops (multi-threaded), same expressions / order as the numpy form: bit-identical"""
+    import torch
+    d = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
+    w = torch.from_numpy(np.ascontiguousarray(warp, dtype=np.float32))
+    B, H, W, C = d.shape
+    out = torch.zeros((B, w.shape[1], C), dtype=torch.float32)
+    for b in range(B):
+        x, y = w[b, :, 0], w[b, :, 1]
+        ok = (x > -1.0) & (y > -1.0) & (x < W) & (y < H)
+        zero = torch.zeros((), dtype=torch.float32)
+        xs, ys = torch.where(ok, x, zero), torch.where(ok, y, zero)
+        fx, fy = torch.floor(xs), torch.floor(ys)
+        cx, cy = fx + 1.0, fy + 1.0
+        dx, dy = cx - xs, cy - ys
+        ifx, ify, icx, icy = (a.to(torch.int64) for a in (fx, fy, cx, cy))
+        flat = d[b].reshape(H * W, C)
+
+        def get(ix, iy):
+            inb = (ix >= 0) & (iy >= 0) & (ix < W) & (iy < H)
+            v = flat.index_select(0, iy.clamp(0, H - 1) * W + ix.clamp(0, W - 1))
+            return torch.where(inb[:, None], v, zero)
+
+        v = (dx * dy)[:, None] * get(ifx, ify)
+        v = v + ((1.0 - dx) * (1.0 - dy))[:, None] * get(icx, icy)
+        v = v + (dx * (1.0 - dy))[:, None] * get(ifx, icy)
+        v = v + ((1.0 - dx) * dy)[:, None] * get(icx, ify)
+        out[b] = torch.where(ok[:, None], v, zero)
+    return out.numpy()
+
+
 # --------------------------------------------------------------------------
 # row D : get_img_points  (models/model_normalization.py:241-251)
 # --------------------------------------------------------------------------

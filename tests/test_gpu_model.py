@@ -10,12 +10,15 @@ from oracle import disn_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-# Tolerance of the GEMM-shaped part of the path, against the float64 shadow of the oracle.
-# north_star asks for 1e-5 of the reference's float32 CPU path; two float32 implementations
-# that sum K<=25088-term dot products in different orders differ by ~1e-5 themselves (the
-# oracle's own float32-vs-float64 distance on this input is 8e-6, tests/golden), so parity is
-# asserted as |gpu - f64| <= 2e-5 + 1e-5*|ref|, and the measured maximum is printed.
-ATOL, RTOL = 2e-5, 1e-5
+# The bar of the GEMM-shaped part of the path (north_star: "within 1e-5 of the reference TF CPU path"):
+#   * what the path RETURNS (pred_sdf, the two stream sums, the embedding):  |gpu - f64| <= 1e-5 ABSOLUTE
+#     against the float64 shadow of the oracle on the He-weight configs (|pred| ~ 1.7; measured on MI355X
+#     3-5e-6, so a 2x regression fails), and against the float32 CPU path
+#     |gpu - oracle32| <= |oracle32 - f64| + 1e-5 (two float32 evaluations that sum up to 25088-term dot
+#     products in different orders differ from each other by their own distances to the truth);
+#   * intermediate tensors (taps, feature map: values up to O(10)): 1e-5 + 1e-5 |ref|.
+PRED_ATOL = 1e-5
+ATOL, RTOL = 1e-5, 1e-5
 
 
 def _session(mode):
@@ -45,11 +48,13 @@ def test_cfg2_against_golden(kat, mode):
     pred, xy, emb = sess.run([ep["pred_sdf"], ep["sample_img_points"], ep["img_embedding"]], _feed(pls, feed))
     assert pred.shape == (1, 2048, 1) and xy.shape == (1, 2048, 2) and emb.shape == (1, 1024)
     assert np.array_equal(xy, kat["cfg2_%s_xy" % mode])                                   # row D bit-exact
-    e_emb = report_close("embedding(%s)" % mode, emb, kat["cfg2_%s_emb64" % mode], ATOL, RTOL)
-    e_pred = report_close("pred_sdf(%s)" % mode, pred, kat["cfg2_%s_pred64" % mode], ATOL, RTOL)
+    e_emb = report_close("embedding(%s)" % mode, emb, kat["cfg2_%s_emb64" % mode], PRED_ATOL)
+    e_pred = report_close("pred_sdf(%s)" % mode, pred, kat["cfg2_%s_pred64" % mode], PRED_ATOL)
     e32 = float(np.abs(pred - kat["cfg2_%s_pred" % mode]).max())
-    print("\n[parity cfg2 %s] max|gpu-f64| pred %.3g emb %.3g ; max|gpu-oracle32| %.3g ; |pred| mean %.3g"
-          % (mode, e_pred, e_emb, e32, float(np.abs(pred).mean())))
+    o32 = float(np.abs(kat["cfg2_%s_pred" % mode].astype(np.float64) - kat["cfg2_%s_pred64" % mode]).max())
+    print("\n[parity cfg2 %s] max|gpu-f64| pred %.3g emb %.3g ; max|gpu-oracle32| %.3g ; max|oracle32-f64| %.3g ; "
+          "|pred| mean %.3g" % (mode, e_pred, e_emb, e32, o32, float(np.abs(pred).mean())))
+    assert e32 <= o32 + 1e-5, "GPU is further from the float32 CPU path than that path's own error allows"
 
 
 def test_cfg2_every_end_point_vs_oracle():
@@ -66,12 +71,16 @@ def test_cfg2_every_end_point_vs_oracle():
     assert np.array_equal(vals["ref_img"], feed["imgs"])                     # un-resized (Appendix C #4)
     assert np.array_equal(vals["resized_ref_img"], ref["resized_ref_img"])   # row A bit-exact
     assert np.array_equal(vals["sample_img_points"], ref["sample_img_points"])
-    report_close("img_embedding", vals["img_embedding"], ref64["img_embedding"], ATOL, RTOL)
+    report_close("img_embedding", vals["img_embedding"], ref64["img_embedding"], PRED_ATOL)
     # point_img_feat: the gather is bit-exact given the taps; the taps carry conv rounding
     report_close("point_img_feat", vals["point_img_feat"], ref64["point_img_feat"], ATOL, RTOL)
-    report_close("global", vals["pred_sdf_value_global"], ref64["pred_sdf_value_global"], ATOL, RTOL)
-    report_close("local", vals["pred_sdf_value_local"], ref64["pred_sdf_value_local"], ATOL, RTOL)
-    report_close("pred", vals["pred_sdf"], ref64["pred_sdf"], 2 * ATOL, RTOL)
+    report_close("global", vals["pred_sdf_value_global"], ref64["pred_sdf_value_global"], PRED_ATOL)
+    report_close("local", vals["pred_sdf_value_local"], ref64["pred_sdf_value_local"], PRED_ATOL)
+    e = report_close("pred", vals["pred_sdf"], ref64["pred_sdf"], PRED_ATOL)
+    e32 = float(np.abs(vals["pred_sdf"] - ref["pred_sdf"]).max())
+    o32 = float(np.abs(ref["pred_sdf"].astype(np.float64) - ref64["pred_sdf"]).max())
+    print("\n[parity every end point] max|gpu-f64| %.3g ; max|gpu-oracle32| %.3g ; max|oracle32-f64| %.3g" % (e, e32, o32))
+    assert e32 <= o32 + 1e-5
 
 
 def test_vgg_taps_vs_oracle():
@@ -189,7 +198,7 @@ def test_get_decoder_and_standalone_streams():
     W = sess.weights.arrays
     ref = (O.get_sdf_basic2(pc, emb.reshape(1, -1), W, dtype=np.float64)
            + O.get_sdf_basic2_imgfeat_twostream(pc, feat, W, dtype=np.float64))
-    report_close("get_decoder", got, ref, 2 * ATOL, RTOL)
+    report_close("get_decoder", got, ref, PRED_ATOL)
 
 
 def test_losses_vs_oracle():
@@ -254,7 +263,7 @@ def test_encode_query_equals_encode_plus_query(B, N):
             report_close("encode_query vs encode+query (rep %d)" % rep, sdf_a.cpu().numpy(), sdf_b.cpu().numpy(), ATOL, RTOL)
     ref = O.get_model({"imgs": imgs, "sample_pc": pts, "sample_pc_rot": pts, "trans_mat": tms},
                       eng.weights and WeightStore.random_init(0, mode="he").arrays, dtype=np.float64)
-    report_close("encode_query vs oracle", sdf_a.cpu().numpy(), ref["pred_sdf"][..., 0], ATOL, RTOL)
+    report_close("encode_query vs oracle", sdf_a.cpu().numpy(), ref["pred_sdf"][..., 0], PRED_ATOL)
 
 
 def test_vgg_stack_equals_standalone_layer_chain():

@@ -182,3 +182,44 @@ def test_fold_identities_behind_the_folded_local_stream():
     r1 = O.resize_bilinear_legacy(tap, 137, 137).astype(np.float64) @ W.astype(np.float64)
     r2 = O.resize_bilinear_legacy((tap.astype(np.float64) @ W.astype(np.float64)).astype(np.float32), 137, 137).astype(np.float64)
     assert np.abs(r1 - r2).max() <= 2e-5 * max(1.0, np.abs(r1).max())
+
+
+def test_multithreaded_resize_and_resampler_are_bit_identical():
+    """bench.py's cpu_baseline leg times torch-CPU (threaded) forms of the two numpy-bound oracle stages;
+    they must be the same functions: same expressions, same rounding order"""
+    rng = np.random.default_rng(5)
+    for h, c, o in ((224, 8, 137), (14, 16, 137), (137, 3, 224), (56, 4, 137)):
+        x = rng.standard_normal((2, h, h, c)).astype(np.float32)
+        assert np.array_equal(O.resize_bilinear_legacy(x, o, o), O.resize_bilinear_legacy_mt(x, o, o))
+    m = rng.standard_normal((2, 137, 137, 24)).astype(np.float32)
+    w = (rng.random((2, 500, 2)) * 141 - 2).astype(np.float32)
+    w[0, :4] = [[0, 0], [136, 136], [136, 0], [np.nan, 1]]
+    assert np.array_equal(O.resampler(m, w), O.resampler_mt(m, w))
+
+
+def _external_kat():
+    import json
+    import os
+    from conftest import GOLDEN
+    return json.load(open(os.path.join(GOLDEN, "external_kat.json")))
+
+
+def test_external_kat_tensorflow_resize_vectors():
+    """TensorFlow's own unit-test vectors for the legacy bilinear resize (image_ops_test.py,
+    ResizeImagesTest): the one pin of the TF-executed arithmetic that does not come from this repo"""
+    k = _external_kat()
+    for nm in ("resize_up", "resize_down"):
+        x = np.asarray(k[nm]["in"], np.float32).reshape(k[nm]["in_shape"])
+        oh, ow = k[nm]["out_hw"]
+        assert np.array_equal(O.resize_bilinear_legacy(x, oh, ow).ravel(), np.asarray(k[nm]["out"], np.float32)), nm
+
+
+def test_external_kat_hand_derived_resampler_cases():
+    k = _external_kat()
+    m = np.asarray(k["resampler_2x2"]["map"], np.float32)[None, :, :, None]
+    got = O.resampler(m, np.asarray(k["resampler_2x2"]["xy"], np.float32)[None])[0, :, 0]
+    assert np.array_equal(got, np.asarray(k["resampler_2x2"]["out"], np.float32))
+    yy, xx = np.meshgrid(np.arange(137), np.arange(137), indexing="ij")
+    m = (1 + xx + 1000 * yy).astype(np.float32)[None, :, :, None]
+    got = O.resampler(m, np.asarray(k["resampler_137"]["xy"], np.float32)[None])[0, :, 0]
+    assert np.array_equal(got, np.asarray(k["resampler_137"]["out"], np.float32))
