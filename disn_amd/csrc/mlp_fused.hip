@@ -456,9 +456,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
     else fm_wait_vm(issued - mark[0]);
     __builtin_amdgcn_s_barrier();
     FM_FENCE();
+    // the FIFO holds the DP slots in flight after a sync (DP + 1 only between the prologue and the first sync)
 #pragma unroll
     for (int i = 0; i < DP; ++i) mark[i] = mark[i + 1];
-    if (issue) ring_issue(DP);
+    if (issue) ring_issue(DP - 1);
     sa[parity] = cons_pos * fm::kSlotBytes + lane * 16;
     cons_pos = cons_pos + 1 == R ? 0 : cons_pos + 1;
   };

@@ -48,6 +48,14 @@ g_small = [i for i in gathers if int(fetch[i]["grid"]) < 1_000_000][-1]
 g_big = [i for i in gathers if int(fetch[i]["grid"]) >= 1_000_000][-1]
 cal = 262144 * 5888 / 1024.0 / write[g_big]["v"]
 g_taps = [i for i in ids if "project_gather_taps_kernel" in fetch[i]["name"]]
+g_fold = [i for i in ids if "gather_fold_kernel" in fetch[i]["name"]]
+fused = [i for i in ids if "mlp_fused_kernel" in fetch[i]["name"]]
+build = ""
+try:
+    build = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "disn_amd", "csrc", "build",
+                              "BUILD_ID")).read().strip()
+except Exception:
+    pass
 
 
 def hbm(idl):
@@ -57,7 +65,7 @@ def hbm(idl):
             "hbm_bytes": (2 * f + cal * w) * 1024.0}
 
 
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_kernels.py workload (PROF_STEPS=1)",
+out = {"build": build, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_kernels.py workload (PROF_STEPS=1)",
        "note": "KB as reported; gfx950: FETCH_SIZE x2 for wide coalesced reads; WRITE_SIZE calibrated on the gather",
        "conv_family_per_step": dict(hbm(conv), kernels=sorted({fetch[i]["name"].split("(")[0] for i in conv}),
                                     algorithmic_bytes_note="weights 88 MB (three bf16 planes, 6 B/weight) + layer inputs "
@@ -69,5 +77,11 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tool
                                        note="disn_encode_query: 16 tap reads + 1 write per output float4; the taps "
                                             "(24.5 MB) are L2 / MALL resident, so the memory-side bytes are far "
                                             "below the algorithmic reads") if g_taps else None),
+       "gather_taps_n2048": (dict(hbm(g_taps[-1:]), algorithmic_bytes=2048 * 29440) if g_taps else None),
+       "gather_fold_n65536": (dict(hbm(g_fold[-1:]), algorithmic_bytes=65536 * 12288) if g_fold else None),
+       "mlp_fused_n65536": ({"global": hbm([i for i in fused if "<false" in fetch[i]["name"] or "Lb0" in fetch[i]["name"]][-1:]),
+                             "local": hbm([i for i in fused if "<true" in fetch[i]["name"] or "Lb1" in fetch[i]["name"]][-1:]),
+                             "note": "per 65536 points: weights re-streamed per 128-point tile stay in L2; the local "
+                                     "stream adds 8 KB/point of pmap rows (L2 / MALL resident)"} if fused else None),
        "write_calibration": {"factor": cal, "basis": "gather_kernel at N=262144 writes exactly 262144*5888 B"}}
 print(json.dumps(out, indent=1))

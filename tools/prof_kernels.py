@@ -1,6 +1,6 @@
 """Small, bounded workload for rocprofv3 passes (kernel trace or one PMC counter at a time):
 PROF_STEPS x (encode + 2048-point query), one standalone gather at 2048 and 262144 points,
-one 65536-point query, one single-call step (disn_encode_query: no feature map, gather from the taps)."""
+one 65536-point query through the layer-by-layer chain and through the fused kernels, one single-call step (disn_encode_query: no feature map, gather from the taps)."""
 import os, sys
 import numpy as np
 import torch
@@ -26,7 +26,9 @@ for n in (2048, 262144):
         f = ops.gather(enc.featmap, xy)
 p = torch.rand((1, 65536, 3), device="cuda") * 2 - 1
 for _ in range(2):
-    eng.query(enc, p, tm)
+    eng.query(enc, p, tm, fused=False)      # layer-by-layer chunk: 8 GEMMs + gather_fold_kernel
+for _ in range(2):
+    eng.query(enc, p, tm, fused=True)       # mlp_fused_kernel<global>, <local>
 eng.encode_query(img, pts, tm)
 torch.cuda.synchronize()
 print("done")
