@@ -112,7 +112,9 @@ def test_fused_grid_equals_points_and_slices(eng_store):
     part = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, 70001, total, fused=True)
     u = eng.query_grid(enc, 0, O.DEMO_TRANS_MAT, sp, R, fused=False)
     pts = ops.grid_points(sp, R, 0, total, "cuda")
-    q = eng.query(enc, pts[None], O.DEMO_TRANS_MAT, fold=True, fused=True)[0] / 10.0
+    # true IEEE division as the kernel's `/ out_div` does (torch's `tensor / python_scalar` multiplies by 1/10 on the GPU)
+    q = torch.div(eng.query(enc, pts[None], O.DEMO_TRANS_MAT, fold=True, fused=True)[0],
+                  torch.tensor(10.0, device="cuda"))
     torch.cuda.synchronize()
     assert torch.equal(part, g[70001:]), "a slice of the grid differs from the whole grid"
     assert torch.equal(q, g), "grid mode differs from point mode on the same points"
