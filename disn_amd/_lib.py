@@ -14,7 +14,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # DISN_AMD_LIB: tools/ only -- points the binding at a tuning build (csrc/build.py --tuning), never set by the product
 LIB_PATH = os.environ.get("DISN_AMD_LIB") or os.path.join(HERE, "csrc", "libdisn_amd.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -34,7 +34,8 @@ class DisnError(RuntimeError):
 class VggWeights(C.Structure):  # disn_vgg_weights_t
     _fields_ = [("conv_w", C.c_void_p * 13), ("conv_b", C.c_void_p * 13),
                 ("fc_w", C.c_void_p * 3), ("fc_b", C.c_void_p * 3), ("num_classes", C.c_int),
-                ("conv_w_x3", C.c_void_p * 13)]   # optional three-term bf16 images (disn_pack_kn_x3)
+                ("conv_w_x3", C.c_void_p * 13),   # optional three-term bf16 images (disn_pack_kn_x3)
+                ("conv_w_h2", C.c_void_p * 13)]   # optional two-term f16 images (disn_pack_conv_h2)
 
 
 MLP_FIELDS = ("g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3", "g_w4_point", "g_w4_global", "g_b4",
@@ -74,6 +75,12 @@ SIGNATURES = {
     "disn_pack_kn_x3": (I, [P, I, I, P, P]),
     "disn_conv3x3_x3_workspace_bytes": (Z, [I, I, I, I, I]),
     "disn_conv3x3_x3": (I, [P, I, I, I, I, P, P, I, I, P, P, Z, P]),
+    "disn_pack_conv_h2_bytes": (Z, [I, I]),
+    "disn_pack_conv_h2": (I, [P, I, I, P, P]),
+    "disn_conv1_1_workspace_bytes": (Z, []),
+    "disn_conv1_1": (I, [P, I, I, I, P, P, I, P, P, P, Z, P]),
+    "disn_conv3x3_h2_workspace_bytes": (Z, []),
+    "disn_conv3x3_h2": (I, [P, I, I, I, I, P, P, I, I, P, P, P, I, P, Z, P]),
     "disn_resize_bilinear": (I, [P, I, I, I, I, P, I, I, I, I, P]),
     "disn_vgg16_workspace_bytes": (Z, [I]),
     "disn_vgg16_forward": (I, [C.POINTER(VggWeights), P, I, P, C.POINTER(C.c_void_p * 5), P, P, Z, P]),

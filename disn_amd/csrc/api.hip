@@ -45,6 +45,7 @@ inline int conv_k(int cin) { return cin == 3 ? 32 : 9 * cin; }
 
 struct VggWs {
   float *resized, *bufA, *bufB, *bufP, *gemm_ws, *fc_ws, *fc6, *fc7;
+  float* amax;  // [14][64]: slot group i = max |input of conv layer i| (conv_h2.hip), written by layer i - 1
   size_t total;
 };
 
@@ -73,6 +74,7 @@ VggWs vgg_layout(void* ws, int B, int num_classes) {
   w.fc_ws = b.take(fws);
   w.fc6 = b.take((size_t)B * 4096 * sizeof(float));
   w.fc7 = b.take((size_t)B * 4096 * sizeof(float));
+  w.amax = b.take(14 * 64 * sizeof(float));
   w.total = (b.off + 255) & ~size_t(255);
   return w;
 }
@@ -475,15 +477,29 @@ int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* re
   const float* x = resized;
   bool toggle = false;
   const size_t gws_cap = (size_t)((char*)s.fc_ws - (char*)s.gemm_ws);
+  // the single-image kernels (conv_h2.hip) when every layer has its image: each layer's epilogue leaves the
+  // maximum of its output in the slots the next layer scales its f16 split by
+  bool h2 = x3_enabled();
+  for (int i = 0; i < 13; ++i) h2 = h2 && w->conv_w_h2[i] != nullptr;
+  if (h2) DISN_TRY(hipMemsetAsync(s.amax, 0, 14 * 64 * sizeof(float), st));
   for (int i = 0; i < 13; ++i) {
     const VggLayer& L = kVgg[i];
     float* out = L.tap >= 0 ? taps[L.tap] : (L.hw >= 112 ? s.bufA : (toggle ? s.bufB : s.bufA));
     if (L.tap < 0 && L.hw < 112) toggle = !toggle;
     // a layer the pool follows: when its split-K reduce runs anyway, that pass also emits the pool
     bool pooled = false;
-    const int rc = conv3x3_impl(x, B, L.hw, L.hw, L.cin, w->conv_w[i], w->conv_b[i], L.cout, 1,
-                                out, s.gemm_ws, gws_cap, st, w->conv_w_x3[i],
-                                kPoolAfter[i] ? s.bufP : nullptr, &pooled);
+    int rc = 0;
+    if (h2 && i == 0) {
+      DISN_TRY(conv1_1_direct_launch(x, B, L.hw, L.hw, static_cast<const float*>(w->conv_w_h2[0]), w->conv_b[0], 1, out,
+                                     s.amax + 64, st));
+    } else if (h2) {
+      DISN_TRY(conv_h2_launch(x, B, L.hw, L.hw, L.cin, w->conv_w_h2[i], w->conv_b[i], L.cout, 1, s.amax + 64 * i, out,
+                              kPoolAfter[i] ? s.bufP : nullptr, s.amax + 64 * (i + 1), st));
+      pooled = kPoolAfter[i];
+    } else {
+      rc = conv3x3_impl(x, B, L.hw, L.hw, L.cin, w->conv_w[i], w->conv_b[i], L.cout, 1, out, s.gemm_ws, gws_cap, st,
+                        w->conv_w_x3[i], kPoolAfter[i] ? s.bufP : nullptr, &pooled);
+    }
     if (rc) return rc;
     x = out;
     if (L.tap >= 0 && featmap)
@@ -1052,8 +1068,14 @@ namespace disn {
 namespace tune {
 int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0;
 int gemm_force[3] = {0, 0, 0};
+long long* ch2_stamps = nullptr;
 }
 }  // namespace disn
+extern "C" int disn_tuning_set_ptr(int key, void* p) {
+  if (key != 0) return DISN_E_ARG;
+  disn::tune::ch2_stamps = static_cast<long long*>(p);
+  return 0;
+}
 // tuning builds only (build.py --tuning -> libdisn_amd_tuning.so): 0 x3, 1 overlap, 2 bf_splits, 3 skip_pack,
 // 4 fused_safe
 extern "C" int disn_tuning_set(int key, int value) {

@@ -32,6 +32,7 @@ SOURCES = {
     "cam_head.hip": [],
     "mlp_small.hip": [],
     "mlp_fused.hip": [],
+    "conv_h2.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],
     "marching_cubes.hip": ["-ffp-contract=off"],
     "api.hip": [],

@@ -1,0 +1,569 @@
+// 3x3 SAME convolution of the VGG-16 stack (models/CNN/vgg.py:187-196, 'conv1_2' .. 'conv5_3'; called from
+// models/model_normalization.py:74-76) for a SINGLE image (or a few): fp32 in, fp32 out, fp32-accurate
+// products on the f16 matrix pipes, no split-K pass and no im2col re-reads.
+//
+// Why a second convolution kernel.  At B = 1 a VGG layer is a skinny GEMM (M = 196 .. 50176 pixels,
+// N = 64 .. 512, K = 576 .. 4608).  The implicit-GEMM kernel of gemm_bf16_mfma.hip cuts it into 64x64
+// tiles x 3..11 K-splits of short-lived workgroups plus a reduce launch, re-reads every input pixel nine
+// times (im2col) and every weight once per WAVE ROW; measured 23-45 us per layer + 5-7 us per reduce,
+// 0.47 of the f32 MFMA peak (profiles/r02b_*).  Here:
+//
+//  * Two-term f16 split (as mlp_fused.hip): x = h + l, h = f16(x s), l = f16(x s - h), s a power of two
+//    that puts the tensor's largest magnitude at 2^14 (activations: from the producer's atomic max;
+//    weights: at pack time, 2^13).  a b is accumulated in fp32 from l_a h_b + h_a l_b + h_a h_b: three
+//    v_mfma_f32_32x32x16_f16 per 32x32x16 block instead of six bf16 ones, 4 instead of 6 bytes per weight.
+//  * The M tile is a 2-D patch of the image (TH x TW pixels, TW a multiple of the lane-group size, see
+//    below); its (TH+2) x (TW+2) halo of 64 input channels is split ONCE into h / l planes in LDS and all
+//    nine taps read it there at shifted addresses: each input element is fetched ~1.3-2x instead of 9x and
+//    split once instead of nine times.
+//  * All K parallelism is INSIDE the workgroup: the four k16 blocks of a 64-channel chunk belong to four
+//    waves (wk = 0..3), each of which owns the whole BM x 32 output tile of its n-block and streams ITS
+//    weight fragments straight from L2 into registers -- one contiguous 2 KiB per (chunk, tap), nine
+//    (chunk, tap) steps ahead.  No operand is fetched twice by a workgroup, nothing but the halo goes
+//    through LDS, and the four partial tiles are summed through LDS in a fixed order at the end
+//    ((w0 + w2) + (w1 + w3)): deterministic, no partials in HBM, no second launch.
+//  * Tiles are small (32..128 pixels x 32..64 channels) so that a single image still gives 112..392
+//    workgroups; n-tile-major XCD placement keeps the workgroups that stream the same weights on one L2.
+//  * Epilogue: bias, ReLU, fp32 NHWC store, optional 2x2 max pool of the same tile (the five pooled
+//    layers are the five taps: both are needed), and the atomic max |out| that gives the NEXT layer its
+//    activation scale.
+//
+// LDS layout of a halo pixel: 128 B of h (64 channels), 128 B of l, 16 B pad -> 272 B = 17 x 16 B, so 16
+// CONSECUTIVE pixels land on 16 different 16-byte slots: ds_read_b128 is conflict-free when each of its
+// 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31} per half wave; MI355X_MICROARCH.md, LDS) reads 16
+// consecutive pixels of one halo row.  The A-fragment row <-> pixel map is chosen for that: hardware row i
+// of a 32-row block is LOGICAL row sigma(i) (group-1 lanes in ascending order are logical 0..15, group-2
+// lanes 16..31); logical rows are `32 / SEG` runs of SEG consecutive pixels of one patch row (SEG = 16:
+// two patch rows of <= 16 pixels; SEG = 32: one patch row of <= 32).  The C layout of the MFMA then gives
+// lane (j, g) and register quad q the four consecutive logical rows L0(q, g) .. L0 + 3 of column j.
+#include "kernels.hpp"
+#include "tuning.hpp"
+
+#include <type_traits>
+
+namespace disn {
+
+typedef _Float16 ch_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ch_h4 __attribute__((ext_vector_type(4)));
+typedef float ch_f16v __attribute__((ext_vector_type(16)));
+
+namespace ch2 {
+constexpr int kPix = 272;  // bytes per halo pixel in LDS
+// power of two s with amax * s in [2^target, 2^(target+1)); 1 for amax == 0 / non-finite / extreme
+__host__ __device__ inline float pow2_scale(float amax, int target_exp) {
+  union { float f; unsigned u; } a;
+  a.f = amax;
+  const int e = (int)((a.u >> 23) & 0xffu) - 127;
+  if (!(amax > 0.f) || e > 100 || e < -100) return 1.0f;
+  a.u = (unsigned)(127 + target_exp - e) << 23;
+  return a.f;
+}
+// logical row of hardware row i (0..31) of a 32-row block
+__host__ __device__ constexpr int sigma(int i) {
+  return i < 4 ? i : (i < 12 ? i + 12 : (i < 16 ? i - 8 : (i < 20 ? i + 8 : (i < 28 ? i - 12 : i))));
+}
+// first logical row of the four held by accumulator quad q (registers 4q..4q+3) of lane half g
+__host__ __device__ constexpr int quad_row(int q, int g) {
+  return sigma(8 * q + 4 * g);
+}
+}  // namespace ch2
+
+// ---------------------------------------------------------------------------------------------------
+// weight image: for n-block nb (32 output channels), k-wave wk, step s = chunk * 9 + tap:
+//   two 1-KiB planes (h, l), lane (j, g) holds W[tap][64 chunk + 16 wk + 8 g + e][32 nb + j] * s_w, e = 0..7
+// at byte ((((nb * 4 + wk) * S + s) * 2 + plane) * 64 + lane) * 16.  Behind the image: {s_w, 1 / s_w}.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restrict__ w, int Cin, int Cout,
+                                                           const float* __restrict__ amax,
+                                                           unsigned char* __restrict__ image) {
+  const int S = 9 * (Cin >> 6);
+  const size_t frags = (size_t)(Cout >> 5) * 4 * S;
+  const float s = ch2::pow2_scale(amax[0], 13);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float* meta = reinterpret_cast<float*>(image + (size_t)Cin * 9 * Cout * 4);
+    meta[0] = s;
+    meta[1] = 1.0f / s;
+  }
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < frags * 64; idx += (size_t)gridDim.x * 256) {
+    const int lane = (int)(idx & 63);
+    const size_t f = idx >> 6;
+    const int st = (int)(f % S);
+    const int wk = (int)((f / S) & 3);
+    const int nb = (int)(f / ((size_t)S * 4));
+    const int c = st / 9, t = st - 9 * c;
+    const int j = lane & 31, g = lane >> 5;
+    ch_h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ci = 64 * c + 16 * wk + 8 * g + e;
+      const float v = w[((size_t)t * Cin + ci) * Cout + 32 * nb + j] * s;
+      const _Float16 h = (_Float16)v;
+      hi[e] = h;
+      lo[e] = (_Float16)(v - (float)h);
+    }
+    ch_h8* out = reinterpret_cast<ch_h8*>(image);
+    out[(f * 2) * 64 + lane] = hi;
+    out[(f * 2 + 1) * 64 + lane] = lo;
+  }
+}
+
+size_t conv_h2_image_bytes(int Cin, int Cout) { return (size_t)Cin * 9 * Cout * 4 + 256; }
+
+// w: TF HWIO [3][3][Cin][Cout]; scratch: one float (max |w|)
+hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, float* scratch, hipStream_t st) {
+  hipError_t e = amax_launch(w, (size_t)9 * Cin * Cout, scratch, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(conv_h2_pack_kernel, dim3(1024), dim3(256), 0, st, w, Cin, Cout, scratch,
+                     static_cast<unsigned char*>(image));
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct ConvH2Dev {
+  const float* in;            // [B][H][W][Cin]
+  const unsigned char* wimg;  // conv_h2_pack image
+  const float* bias;          // [Cout]
+  const float* in_amax;       // 64 floats whose maximum is max |in|
+  float* out;                 // [B][H][W][Cout]
+  float* pool_out;            // [B][H/2][W/2][Cout] or nullptr
+  float* out_amax;            // 64 floats (zeroed by the caller): atomic max |out| spread over the slots, or nullptr
+  int B, H, W, Cin, Cout;
+  int tiles_x, tiles_y;
+  int relu;
+  long long* stamps;  // tuning builds: 16 clock stamps per workgroup (nullptr in the product)
+};
+
+#ifdef DISN_TUNING
+#define CH2_STAMP(i) \
+  if (P.stamps && threadIdx.x == 0) P.stamps[(size_t)blockIdx.x * 16 + (i)] = (i) == 0 ? (long long)wall_clock64() : (long long)clock64()
+#else
+#define CH2_STAMP(i)
+#endif
+
+template <int MB, int NW, int SEG, int TW, int D>
+__global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P) {
+  constexpr int RPS = 32 / SEG;       // patch rows per 32-row block
+  constexpr int TH = MB * RPS;        // patch rows
+  constexpr int RP = TW + 2;          // halo row pitch in pixels
+  constexpr int HP = (TH + 2) * RP;   // halo pixels
+  constexpr int BUF = HP * ch2::kPix;
+  constexpr int NT = 256 * NW;
+  constexpr int LP = (HP * 16 + NT - 1) / NT;  // float4 units per thread and chunk
+  constexpr int XCH = NW * 4 * MB * 4096;      // exchange area of the final K reduction
+  // reads of the rows beyond TW (never stored) run up to 34 - RP pixels past a buffer
+  constexpr int LDS_BYTES = (2 * BUF + 8 * ch2::kPix) > XCH ? (2 * BUF + 8 * ch2::kPix) : XCH;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave & 3, wn = wave >> 2;
+  const int j = lane & 31, g = lane >> 5;
+  CH2_STAMP(0);
+  CH2_STAMP(1);
+
+  // ---- tile: n-tile major, every XCD (hardware workgroup L runs on XCD L % 8) a contiguous eighth --------
+  int l;
+  {
+    const int T = gridDim.x, L = blockIdx.x, q = T >> 3, r = T & 7, xcd = L & 7, idx = L >> 3;
+    l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int per_img = P.tiles_y * P.tiles_x;
+  const int mtiles = P.B * per_img;
+  const int nt = l / mtiles;
+  int mt = l - nt * mtiles;
+  const int b = mt / per_img;
+  mt -= b * per_img;
+  const int tyi = mt / P.tiles_x, txi = mt - tyi * P.tiles_x;
+  const int y0 = tyi * TH, x0 = txi * TW;
+  const int n0 = (nt * NW + wn) * 32;
+  const int H = P.H, W = P.W, Cin = P.Cin, Cout = P.Cout;
+  const int NC = Cin >> 6;
+  const float* inb = P.in + (size_t)b * H * W * Cin;
+
+  // ---- halo loader: unit u = (pixel, float4 of the chunk's 64 channels); 16 lanes = one pixel ----------------
+  // every load is unconditional and every loaded value is used (an out-of-image unit reads a valid pixel and is
+  // ANDed with 0): no exec-mask branches, so the compiler can count the loads in flight (s_waitcnt vmcnt(N))
+  int goff[LP], woff[LP];
+  unsigned gmask[LP];
+#pragma unroll
+  for (int k = 0; k < LP; ++k) {
+    const int u = tid + k * NT;
+    const int hp = u >> 4, c4 = u & 15;
+    const int hy = hp / RP, hx = hp - hy * RP;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool in_halo = u < HP * 16;
+    const bool ok = in_halo && y >= 0 && y < H && x >= 0 && x < W;
+    goff[k] = ok ? (y * W + x) * Cin + 4 * c4 : 4 * c4;
+    gmask[k] = ok ? 0xffffffffu : 0u;
+    woff[k] = in_halo ? hp * ch2::kPix + 8 * c4 : -1;
+  }
+  auto load_chunk = [&](int c, float4 (&ra)[LP]) {
+#pragma unroll
+    for (int k = 0; k < LP; ++k) ra[k] = *reinterpret_cast<const float4*>(inb + goff[k] + 64 * c);
+  };
+  float sa = 1.0f;
+  auto store_unit = [&](int buf, const float4 (&ra)[LP], int k) {
+    if (woff[k] < 0) return;
+    const float x[4] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w};
+    ch_h4 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = __uint_as_float(__float_as_uint(x[e]) & gmask[k]) * sa;
+      const _Float16 h = (_Float16)v;
+      hh[e] = h;
+      ll[e] = (_Float16)(v - (float)h);
+    }
+    *reinterpret_cast<ch_h4*>(&lds[buf * BUF + woff[k]]) = hh;
+    *reinterpret_cast<ch_h4*>(&lds[buf * BUF + woff[k] + 128]) = ll;
+  };
+
+  // the first halo is requested before anything else (loads return in order: nothing may queue in front of it)
+  float4 ra0[LP];
+  load_chunk(0, ra0);
+
+  // ---- scales: the producer's maximum (64 slots, see the epilogue) and the weight image's ------------------------
+  const float* meta = reinterpret_cast<const float*>(P.wimg + (size_t)Cin * 9 * Cout * 4);
+  float descale;
+  {
+    float m = P.in_amax[lane];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    sa = ch2::pow2_scale(m, 14);
+    descale = (1.0f / sa) * meta[1];
+  }
+
+  // ---- A rows of this lane: logical row sigma(i) of block mb -> centre pixel in the halo -----------------------
+  int arow[MB];
+  {
+    const int Lr = ch2::sigma(lane & 31);
+    const int seg = SEG == 16 ? (Lr >> 4) : 0, pos = SEG == 16 ? (Lr & 15) : Lr;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      arow[mb] = ((mb * RPS + seg + 1) * RP + pos + 1) * ch2::kPix + (16 * wk + 8 * g) * 2;
+  }
+
+  // ---- this wave's weight stream -----------------------------------------------------------------------------
+  // queue of D fragment pairs (D divides 9): step s = 9 chunk + tap sits in slot tap % D; step s + D is
+  // requested into the slot step s just freed
+  static_assert(9 % D == 0, "queue depth");
+  const int S = 9 * NC;
+  const unsigned char* wp = P.wimg + ((size_t)((n0 >> 5) * 4 + wk) * S) * 2048 + lane * 16;
+  ch_h8 qh[D], ql[D];
+#pragma unroll
+  for (int t = 0; t < D; ++t) {
+    qh[t] = *reinterpret_cast<const ch_h8*>(wp + (size_t)t * 2048);
+    ql[t] = *reinterpret_cast<const ch_h8*>(wp + (size_t)t * 2048 + 1024);
+  }
+
+  ch_f16v acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+  CH2_STAMP(2);
+#pragma unroll
+  for (int k = 0; k < LP; ++k) store_unit(0, ra0, k);
+  __syncthreads();
+  CH2_STAMP(3);
+
+  // one 64-channel chunk: nine taps from LDS buffer c & 1.  MORE: the next chunk's halo is requested at the top
+  // and split into the other buffer one unit at a time BETWEEN the MFMAs of taps 1..8 (a wave issues in order:
+  // the ~7 VALU slots between two 8-pass MFMAs are free), and each tap requests the fragment pair D steps
+  // ahead into the queue slot it just freed.  The A fragments of tap t + 1 are read while the MFMAs of tap t run.
+  auto read_a = [&](const unsigned char* A, int t, ch_h8 (&ah)[MB], ch_h8 (&al)[MB]) {
+    const int shift = ((t / 3 - 1) * RP + (t % 3 - 1)) * ch2::kPix;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      ah[mb] = *reinterpret_cast<const ch_h8*>(A + arow[mb] + shift);
+      al[mb] = *reinterpret_cast<const ch_h8*>(A + arow[mb] + shift + 128);
+    }
+  };
+  constexpr int T0 = 5;
+  auto chunk = [&](int c, auto more_c) {
+    constexpr bool MORE = decltype(more_c)::value;
+    float4 ra[LP];
+    if (MORE) load_chunk(c + 1, ra);
+    const unsigned char* A = &lds[(c & 1) * BUF];
+    const unsigned char* wnext = wp + ((size_t)c * 9 + D) * 2048;
+    ch_h8 ah[2][MB], al[2][MB];
+    read_a(A, 0, ah[0], al[0]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const ch_h8 bh = qh[t % D], bl = ql[t % D];
+      if (MORE || t + D < 9) {
+        qh[t % D] = *reinterpret_cast<const ch_h8*>(wnext + (size_t)t * 2048);
+        ql[t % D] = *reinterpret_cast<const ch_h8*>(wnext + (size_t)t * 2048 + 1024);
+      }
+      if (t < 8) read_a(A, t + 1, ah[(t + 1) & 1], al[(t + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);  // the loads above are ISSUED here, not sunk next to their uses
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t & 1][mb], bh, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t & 1][mb], bl, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t & 1][mb], bh, acc[mb], 0, 0, 0);
+      }
+      if (MORE && t >= T0) {  // units k with T0 + (9 - T0) k / LP == t: not before the loads had time to return
+#pragma unroll
+        for (int k = 0; k < LP; ++k)
+          if (T0 + ((9 - T0) * k) / LP == t) store_unit((c + 1) & 1, ra, k);
+#pragma unroll
+        for (int i = 0; i < 3 * MB; ++i) {  // one MFMA, then up to 7 VALU instructions of the split
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 2 * ((LP + 8 - T0) / (9 - T0)), 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  };
+#pragma unroll 1
+  for (int c = 0; c + 1 < NC; ++c) {
+    chunk(c, std::true_type{});
+    if (c < 8) { CH2_STAMP(4 + c); }
+  }
+  chunk(NC - 1, std::false_type{});
+  CH2_STAMP(12);
+
+  // ---- sum of the four k-waves through LDS, (w0 + w2) + (w1 + w3); wave wk finishes register quad q = wk of every
+  // block: a quarter of the tile's rows each, so the stores, the pool and the maximum are spread over all waves ----
+  float* xch = reinterpret_cast<float*>(lds);
+  auto xaddr = [&](int slot, int mb, int r) { return (((wn * 4 + slot) * MB + mb) * 16 + r) * 64 + lane; };
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xch[xaddr(wk, mb, r)] = acc[mb][r];
+  __syncthreads();
+  CH2_STAMP(13);
+
+  const float bias_j = P.bias[n0 + j];
+  float* outb = P.out + (size_t)b * H * W * Cout + n0 + j;
+  const int L0 = ch2::sigma(8 * wk + 4 * g);  // first of this lane's four consecutive logical rows
+  const int seg = SEG == 16 ? (L0 >> 4) : 0, pos0 = SEG == 16 ? (L0 & 15) : L0;
+  float val[MB][4];
+  float vmax = 0.f;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int y = y0 + mb * RPS + seg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * wk + e, tx = pos0 + e, x = x0 + tx;
+      float v = (xch[xaddr(0, mb, r)] + xch[xaddr(2, mb, r)]) + (xch[xaddr(1, mb, r)] + xch[xaddr(3, mb, r)]);
+      v = fmaf(v, descale, bias_j);
+      if (P.relu) v = fmaxf(v, 0.f);
+      val[mb][e] = v;
+      if (tx < TW && y < H && x < W) {
+        outb[((size_t)y * W + x) * Cout] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+      }
+    }
+  }
+  if (P.out_amax) {  // 64 slots: same-address atomics serialise in L2 (~10 ns each)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(P.out_amax) + ((blockIdx.x * 4 * NW + wave) & 63), __float_as_uint(vmax));
+  }
+  if (P.pool_out) {  // H, W even; y0, x0 even: a 2x2 window never leaves the tile, nor this wave's quad
+    const int Hp = H >> 1, Wp = W >> 1;
+    float* pb = P.pool_out + (size_t)b * Hp * Wp * Cout + n0 + j;
+    if (SEG == 32) {  // patch row = block: the window's rows are blocks 2p, 2p + 1 of the same lane
+#pragma unroll
+      for (int p = 0; p < MB / 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const int tx = L0 + e, x = x0 + tx, y = y0 + 2 * p;
+          const float m = fmaxf(fmaxf(val[2 * p][e], val[2 * p][e + 1]), fmaxf(val[2 * p + 1][e], val[2 * p + 1][e + 1]));
+          if (tx < TW && y + 1 < H && x + 1 < W) pb[((size_t)(y >> 1) * Wp + (x >> 1)) * Cout] = m;
+        }
+    } else {  // two patch rows per block: the window's second row is held by the other half wave
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          float m = fmaxf(val[mb][e], val[mb][e + 1]);
+          m = fmaxf(m, __shfl_xor(m, 32));
+          const int tx = (L0 & 15) + e, x = x0 + tx, y = y0 + 2 * mb;
+          if (L0 < 16 && tx < TW && y + 1 < H && x + 1 < W) pb[((size_t)(y >> 1) * Wp + (x >> 1)) * Cout] = m;
+        }
+    }
+  }
+  CH2_STAMP(14);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv1_1 (models/CNN/vgg.py:187, 3 -> 64 channels, K = 27): 0.17 GFLOP -- not matrix-pipe work.  Direct fp32
+// FMA convolution: a workgroup walks 32-pixel row segments (grid-stride), stages their 3 x 34 x 3 input window in
+// LDS, thread (pixel pair, channel quad) keeps its 27 x 4 weights in registers for the whole walk and stores
+// 16-byte channel quads (16 lanes = one pixel = 256 contiguous bytes); per-workgroup maximum -> the 64 slots
+// the first conv_h2 layer scales by.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, int B, int H, int W,
+                                                             int relu, float* __restrict__ out,
+                                                             float* __restrict__ out_amax) {
+  __shared__ float win[2][3 * 34 * 3 + 2];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, c4 = tid & 15, pp = tid >> 4;  // pixels pp and pp + 16 of the segment
+  float4 wr[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wr[k] = *reinterpret_cast<const float4*>(w + k * 64 + 4 * c4);
+  const float4 bv = *reinterpret_cast<const float4*>(bias + 4 * c4);
+  const int segs_x = (W + 31) >> 5;
+  const long nseg = (long)B * H * segs_x;
+  float vmax = 0.f;
+  int buf = 0;
+  for (long sg = blockIdx.x; sg < nseg; sg += gridDim.x, buf ^= 1) {
+    const int sx = (int)(sg % segs_x);
+    const long by = sg / segs_x;
+    const int y = (int)(by % H), b = (int)(by / H);
+    const int x0 = sx * 32;
+    const float* img = in + (size_t)b * H * W * 3;
+    for (int i = tid; i < 3 * 34 * 3; i += 256) {  // window element (row r, pixel px, channel c)
+      const int r = i / 102, rem = i - r * 102, px = rem / 3, c = rem - px * 3;
+      const int yy = y - 1 + r, xx = x0 - 1 + px;
+      win[buf][i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[((size_t)yy * W + xx) * 3 + c] : 0.f;
+    }
+    __syncthreads();  // one barrier per segment: the other buffer is being read by nobody (everyone passed this point)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int px = pp + 16 * h;
+      float4 a = bv;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {  // q = dx * 3 + c: nine consecutive floats of the window row
+          const float v = win[buf][r * 102 + px * 3 + q];
+          const float4 ww = wr[r * 9 + q];
+          a.x = fmaf(v, ww.x, a.x); a.y = fmaf(v, ww.y, a.y); a.z = fmaf(v, ww.z, a.z); a.w = fmaf(v, ww.w, a.w);
+        }
+      if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+      if (x0 + px < W) {
+        *reinterpret_cast<float4*>(out + (((size_t)b * H + y) * W + x0 + px) * 64 + 4 * c4) = a;
+        vmax = fmaxf(fmaxf(fmaxf(vmax, fabsf(a.x)), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+      }
+    }
+  }
+  if (out_amax) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    if ((tid & 63) == 0) red[tid >> 6] = vmax;
+    __syncthreads();
+    if (tid == 0)
+      atomicMax(reinterpret_cast<unsigned*>(out_amax) + (blockIdx.x & 63),
+                __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+  }
+}
+
+// w: the TF tensor [3][3][3][64] as is; out_amax: 64 slots zeroed by the caller, or nullptr
+hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu,
+                                 float* out, float* out_amax, hipStream_t st) {
+  const long nseg = (long)B * H * ((W + 31) / 32);
+  const int grid = (int)(nseg < 2048 ? nseg : 2048);
+  hipLaunchKernelGGL(conv1_1_direct_kernel, dim3(grid), dim3(256), 0, st, in, w_hwio, bias, B, H, W, relu, out, out_amax);
+  return hipGetLastError();
+}
+
+template <int MB, int NW, int SEG, int TW, int D>
+static hipError_t conv_h2_go(ConvH2Dev d, hipStream_t st) {
+  constexpr int TH = MB * (32 / SEG);
+  d.tiles_x = (d.W + TW - 1) / TW;
+  d.tiles_y = (d.H + TH - 1) / TH;
+  const int grid = d.B * d.tiles_x * d.tiles_y * (d.Cout / (32 * NW));
+  hipLaunchKernelGGL((conv_h2_kernel<MB, NW, SEG, TW, D>), dim3(grid), dim3(256 * NW), 0, st, d);
+  return hipGetLastError();
+}
+
+bool conv_h2_supported(int H, int W, int Cin, int Cout) {
+  return Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 64 == 0 && H > 0 && W > 0 && H < 32768 && W < 32768 &&
+         (size_t)H * W * (Cin > Cout ? Cin : Cout) < (size_t)1 << 31;
+}
+
+// cfg: 0 = by shape; 1..4 force <1,1,16,14>, <2,1,32,28>, <2,2,32,28>, <4,2,16,16> (tests: every shape through every tiling)
+hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const void* wimg, const float* bias,
+                          int Cout, int relu, const float* in_amax, float* out, float* pool_out, float* out_amax,
+                          hipStream_t st, int cfg) {
+  ConvH2Dev d{};
+  d.in = in; d.wimg = static_cast<const unsigned char*>(wimg); d.bias = bias; d.in_amax = in_amax;
+  d.out = out; d.pool_out = pool_out; d.out_amax = out_amax;
+  d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.relu = relu;
+#ifdef DISN_TUNING
+  d.stamps = tune::ch2_stamps;
+#endif
+  if (cfg == 0) {
+    // patch shape by image width; n-blocks per workgroup so that one image still gives >= ~200 workgroups
+    if (W <= 14) cfg = 1;
+    else if (W <= 28 || (W % 28 == 0 && W % 16 != 0)) {
+      const long wgs1 = (long)B * ((H + 1) / 2) * ((W + 27) / 28) * (Cout / 32);
+      cfg = wgs1 <= 320 ? 2 : 3;
+    } else cfg = 4;
+  }
+  switch (cfg) {
+    case 1: return conv_h2_go<1, 1, 16, 14, 9>(d, st);
+    case 2: return conv_h2_go<2, 1, 32, 28, 9>(d, st);
+    case 3: return conv_h2_go<2, 2, 32, 28, 9>(d, st);
+    default: return conv_h2_go<4, 2, 16, 16, 3>(d, st);
+  }
+}
+
+}  // namespace disn
+
+// ---- C ABI: the layer as a unit (tests, composition); disn_encode* use conv_h2_launch directly ----------
+#include "../../include/disn_amd.h"
+
+extern "C" {
+
+size_t disn_pack_conv_h2_bytes(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return 0;
+  return disn::conv_h2_image_bytes(Cin, Cout);
+}
+
+int disn_pack_conv_h2(const float* w_hwio, int Cin, int Cout, void* image, void* stream) {
+  if (!w_hwio || !image || Cin <= 0 || Cout <= 0) return DISN_E_ARG;
+  if (Cin % 64 || Cout % 64) return DISN_E_SHAPE;
+  // the float behind {s_w, 1/s_w} in the image's tail is the scratch of the max |w| pass
+  float* scratch = reinterpret_cast<float*>(static_cast<char*>(image) + (size_t)Cin * 9 * Cout * 4) + 2;
+  const hipError_t e = disn::conv_h2_pack_launch(w_hwio, Cin, Cout, image, scratch, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+size_t disn_conv3x3_h2_workspace_bytes(void) { return 512; }
+
+int disn_conv3x3_h2(const float* in, int B, int H, int W, int Cin, const void* image, const float* bias, int Cout,
+                    int relu, float* out, float* pool_out, float* out_amax, int tiling, void* ws, size_t ws_bytes,
+                    void* stream) {
+  if (!in || !image || !bias || !out || !ws || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
+  if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 4 || (pool_out && ((H | W) & 1)))
+    return DISN_E_SHAPE;
+  if (ws_bytes < 512) return DISN_E_WS;
+  hipStream_t st = (hipStream_t)stream;
+  float* amax_in = static_cast<float*>(ws);  // 64 slots in, 64 slots out
+  float* amax_out = amax_in + 64;
+  hipError_t e = disn::amax64_launch(in, (size_t)B * H * W * Cin, amax_in, st);
+  if (e != hipSuccess) return (int)e;
+  if (out_amax) {
+    e = hipMemsetAsync(amax_out, 0, 64 * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  e = disn::conv_h2_launch(in, B, H, W, Cin, image, bias, Cout, relu, amax_in, out, pool_out,
+                           out_amax ? amax_out : nullptr, st, tiling);
+  if (e == hipSuccess && out_amax) e = disn::amax_fold_launch(amax_out, out_amax, st);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+size_t disn_conv1_1_workspace_bytes(void) { return 256; }
+
+int disn_conv1_1(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu, float* out,
+                 float* out_amax, void* ws, size_t ws_bytes, void* stream) {
+  if (!in || !w_hwio || !bias || !out || !ws || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
+  if (ws_bytes < 256) return DISN_E_WS;
+  hipStream_t st = (hipStream_t)stream;
+  float* slots = static_cast<float*>(ws);
+  hipError_t e = hipSuccess;
+  if (out_amax) e = hipMemsetAsync(slots, 0, 256, st);
+  if (e == hipSuccess) e = disn::conv1_1_direct_launch(in, B, H, W, w_hwio, bias, relu, out, out_amax ? slots : nullptr, st);
+  if (e == hipSuccess && out_amax) e = disn::amax_fold_launch(slots, out_amax, st);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // extern "C"

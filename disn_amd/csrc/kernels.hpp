@@ -231,6 +231,9 @@ size_t mlp_fused_image_bytes();
 hipError_t mlp_fused_pack_launch(const float* w2, const float* w3, const float* w4_point, const float* w5,
                                  void* image, hipStream_t st);
 hipError_t amax_launch(const float* x, size_t n, float* out, hipStream_t st);  // n % 4 == 0
+// the same into 64 slots (their maximum is max |x|) / the maximum of 64 slots -> out[0]
+hipError_t amax64_launch(const float* x, size_t n, float* out64, hipStream_t st);
+hipError_t amax_fold_launch(const float* slots64, float* out, hipStream_t st);
 // one stream for n points of one image; pts_rot == nullptr: points k0.. of `grid`.  local: gather from
 // pmap + 'sdfprediction_imgfeat', out = (add_in + sum) / out_div; global: 'sdfprediction' with b4 = the
 // folded per-image bias row, out = sum
@@ -239,6 +242,22 @@ hipError_t mlp_fused_launch(bool local, const void* image, const float* w1, cons
                             const float* pts, const float* pts_rot, const GridSpec* grid, long long k0,
                             long long n, const float* trans_mat_b, const float* pmap, const float* pmap_amax,
                             const float* add_in, float* out, float out_div, hipStream_t st);
+
+// ---- conv_h2.hip: the single-image 3x3 convolution (two-term f16 split, halo in LDS, K parallel inside the workgroup) ----
+size_t conv_h2_image_bytes(int Cin, int Cout);
+// w: TF HWIO [3][3][Cin][Cout]; scratch: one device float
+hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, float* scratch, hipStream_t st);
+bool conv_h2_supported(int H, int W, int Cin, int Cout);  // Cin, Cout multiples of 64
+// in_amax: 64 floats whose maximum is max |in|; out_amax (optional, 64 floats zeroed by the caller): atomic
+// max |out| spread over the slots; pool_out
+// (optional, H and W even): the 2x2 max pool of out; tiling 0: by shape
+hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const void* wimg, const float* bias,
+                          int Cout, int relu, const float* in_amax, float* out, float* pool_out, float* out_amax,
+                          hipStream_t st, int tiling = 0);
+
+// conv1_1 (Cin = 3, Cout = 64) as a direct fp32 FMA convolution; w_hwio: the TF tensor [3][3][3][64] as is
+hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu,
+                                 float* out, float* out_amax, hipStream_t st);
 
 // ---- mlp_small.hip ---------------------------------------------------------
 // relu(p . W1 + b1) for both streams: pts [M][3] -> out_g [M][64], out_l [M][64]

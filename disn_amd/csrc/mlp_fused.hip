@@ -164,9 +164,12 @@ hipError_t mlp_fused_pack_launch(const float* w2, const float* w3, const float* 
   return hipGetLastError();
 }
 
-// max |x| over n floats -> *out (a non-negative float: integer atomicMax on the bit pattern); *out
-// must be zeroed first (amax_launch does)
-__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, size_t n4, float* __restrict__ out) {
+// max |x| over n floats -> max over out[0 .. slots) (non-negative floats: integer atomicMax on the bit pattern, one
+// per workgroup; same-address atomics serialise in L2 at ~10 ns each, hence few workgroups and optional slots).
+// out[0 .. slots) must be zeroed first (the launchers do)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, size_t n4, float* __restrict__ out,
+                                                   int slots) {
+  __shared__ float red[4];
   float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -174,13 +177,34 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax(reinterpret_cast<unsigned*>(out) + (blockIdx.x & (slots - 1)), __float_as_uint(m));
+  }
 }
 
-hipError_t amax_launch(const float* x, size_t n, float* out, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+static hipError_t amax_go(const float* x, size_t n, float* out, int slots, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(out, 0, slots * sizeof(float), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(amax_kernel, dim3(1024), dim3(256), 0, st, x, n / 4, out);
+  const size_t n4 = n / 4;
+  const int grid = (int)(n4 < 512 * 256 ? (n4 + 255) / 256 : 512);
+  hipLaunchKernelGGL(amax_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, x, n4, out, slots);
+  return hipGetLastError();
+}
+hipError_t amax_launch(const float* x, size_t n, float* out, hipStream_t st) { return amax_go(x, n, out, 1, st); }
+// the 64-slot form the conv_h2 kernels read (max over the slots = max |x|)
+hipError_t amax64_launch(const float* x, size_t n, float* out64, hipStream_t st) { return amax_go(x, n, out64, 64, st); }
+
+__global__ void amax_fold_kernel(const float* __restrict__ slots64, float* __restrict__ out) {
+  float m = slots64[threadIdx.x];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (threadIdx.x == 0) out[0] = m;
+}
+hipError_t amax_fold_launch(const float* slots64, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(64), 0, st, slots64, out);
   return hipGetLastError();
 }
 

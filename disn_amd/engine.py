@@ -22,7 +22,7 @@ from .weights import MLP_SCOPES, VGG_CONV_NAMES, WeightStore
 class DeviceWeights:
     """Uploads a WeightStore and re-packs the GEMM-shaped layers for the MFMA kernels."""
 
-    def __init__(self, store: WeightStore, device: torch.device):
+    def __init__(self, store: WeightStore, device: torch.device, conv_h2: bool = True):
         if not store.complete():
             raise ValueError("WeightStore is incomplete")
         self.device = device
@@ -40,6 +40,8 @@ class DeviceWeights:
             v.conv_w[i] = packed.data_ptr()
             if ci != 3:   # three-term bf16 image: same fp32 accuracy on the 16x faster bf16 MFMA pipes
                 v.conv_w_x3[i] = self._hold(ops.pack_kn_x3(wd)).data_ptr()
+            if conv_h2:   # single-image kernels (conv_h2.hip): two-term f16 image; conv1_1: the TF tensor as is
+                v.conv_w_h2[i] = (wd if ci == 3 else self._hold(ops.pack_conv_h2(wd))).data_ptr()
             v.conv_b[i] = dev(store[nm + "/biases"]).data_ptr()
         for i, nm in enumerate(("fc6", "fc7", "fc8")):
             w = store["vgg_16/%s/weights" % nm]
@@ -121,7 +123,8 @@ class SdfEngine:
     kernels (mlp_fused.hip: activations in registers, fp32-accurate two-term fp16 products) instead of the
     layer-by-layer GEMM chain (three-term bf16 products); same math, fp32-rounding-level difference."""
 
-    def __init__(self, store: WeightStore, device: Optional[torch.device] = None, fused: bool = True):
+    def __init__(self, store: WeightStore, device: Optional[torch.device] = None, fused: bool = True,
+                 conv_h2: bool = True):
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         if not torch.cuda.is_available():
@@ -129,7 +132,7 @@ class SdfEngine:
         self.device = torch.device(device)
         self.fused = bool(fused)
         with torch.cuda.device(self.device):
-            self.weights = DeviceWeights(store, self.device)
+            self.weights = DeviceWeights(store, self.device, conv_h2=conv_h2)
             self._ctx = ops.ctx_create()      # aux HIP stream + events for the overlapped encoder
         self._ws: Dict[str, torch.Tensor] = {}
 

@@ -102,6 +102,54 @@ def conv3x3_x3(x: torch.Tensor, w_x3: torch.Tensor, bias: torch.Tensor, cout: in
     return out
 
 
+def conv1_1(x: torch.Tensor, w_hwio: torch.Tensor, bias: torch.Tensor, relu: bool = True, want_amax: bool = False):
+    """disn_conv1_1: [B,H,W,3] x TF [3,3,3,64] -> [B,H,W,64] (direct fp32 FMA), optionally also max |out|"""
+    x, w = _chk(x, "x"), _chk(w_hwio, "w_hwio")
+    B, H, W, Cin = x.shape
+    if Cin != 3 or w.numel() != 27 * 64:
+        raise ValueError("conv1_1: expected 3 -> 64 channels")
+    out = torch.empty((B, H, W, 64), dtype=torch.float32, device=x.device)
+    amax = torch.zeros(1, dtype=torch.float32, device=x.device) if want_amax else None
+    ws = _ws(lib().disn_conv1_1_workspace_bytes(), x.device)
+    check("disn_conv1_1", lib().disn_conv1_1(x.data_ptr(), B, H, W, w.data_ptr(), bias.data_ptr(), int(relu),
+                                             out.data_ptr(), amax.data_ptr() if want_amax else None, ws.data_ptr(),
+                                             ws.numel(), _stream()))
+    return (out, amax) if want_amax else out
+
+
+def pack_conv_h2(w_hwio: torch.Tensor) -> torch.Tensor:
+    """disn_pack_conv_h2: TF HWIO [3,3,Cin,Cout] (or [9*Cin,Cout]) -> the two-term f16 weight image of conv_h2.hip"""
+    w = _chk(w_hwio, "w_hwio")
+    cout = w.shape[-1]
+    cin = w.numel() // (9 * cout)
+    nbytes = lib().disn_pack_conv_h2_bytes(cin, cout)
+    if nbytes == 0:
+        raise ValueError("pack_conv_h2: Cin and Cout must be multiples of 64, got %d, %d" % (cin, cout))
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check("disn_pack_conv_h2", lib().disn_pack_conv_h2(w.data_ptr(), cin, cout, out.data_ptr(), _stream()))
+    return out
+
+
+def conv3x3_h2(x: torch.Tensor, image: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool = True,
+               pool: bool = False, want_amax: bool = False, tiling: int = 0,
+               out: Optional[torch.Tensor] = None):
+    """disn_conv3x3_h2 -> out, or (out, pooled, amax) with the entries asked for"""
+    x = _chk(x, "x")
+    B, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    pooled = torch.empty((B, H // 2, W // 2, cout), dtype=torch.float32, device=x.device) if pool else None
+    amax = torch.zeros(1, dtype=torch.float32, device=x.device) if want_amax else None
+    ws = _ws(lib().disn_conv3x3_h2_workspace_bytes(), x.device)
+    check("disn_conv3x3_h2", lib().disn_conv3x3_h2(
+        x.data_ptr(), B, H, W, Cin, image.data_ptr(), bias.data_ptr(), cout, int(relu), out.data_ptr(),
+        pooled.data_ptr() if pool else None, amax.data_ptr() if want_amax else None, int(tiling), ws.data_ptr(),
+        ws.numel(), _stream()))
+    if not pool and not want_amax:
+        return out
+    return out, pooled, amax
+
+
 def maxpool2x2(x: torch.Tensor) -> torch.Tensor:
     x = _chk(x, "x")
     B, H, W, Cc = x.shape

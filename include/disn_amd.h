@@ -38,7 +38,7 @@ extern "C" {
 #define DISN_E_WS (-3)    /* workspace too small */
 
 /* ABI version of this header; disn_abi_version() returns the library's. */
-#define DISN_ABI_VERSION 4
+#define DISN_ABI_VERSION 5
 int disn_abi_version(void);
 
 /* ---------------------------------------------------------------------- *
@@ -61,6 +61,26 @@ int disn_pack_kn_x3(const float* w_kn, int K, int N, void* packed, void* stream)
 size_t disn_conv3x3_x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w_x3, const float* bias,
                     int Cout, int relu, float* out, void* ws, size_t ws_bytes, void* stream);
+/* The single-image convolution (conv_h2.hip; models/CNN/vgg.py:187-196): fp32-accurate products from a two-term
+ * f16 split of both operands (x = h + l after a power-of-two scale; l_a h_b + h_a l_b + h_a h_b accumulated in
+ * fp32), the 3x3 halo of a 2-D pixel patch staged once in LDS, all K parallelism inside the workgroup -- no
+ * split-K pass.  disn_pack_conv_h2: TF HWIO [3][3][Cin][Cout] -> the weight image (Cin, Cout multiples of 64;
+ * `image` holds disn_pack_conv_h2_bytes).  disn_conv3x3_h2: out = act(conv(in) + bias) [B,H,W,Cout]; optional
+ * pool_out = its 2x2 max pool [B,H/2,W/2,Cout] (H, W even), optional out_amax = max |out| (the activation scale
+ * of a following disn_conv3x3_h2 inside disn_encode*; here the input's own maximum is measured first).
+ * tiling: 0 = by shape, 1..4 = force one of the four workgroup tilings (same result up to summation order --
+ * none: the K order of a tile does not depend on the tiling).  ws: disn_conv3x3_h2_workspace_bytes(). */
+size_t disn_pack_conv_h2_bytes(int Cin, int Cout);
+int disn_pack_conv_h2(const float* w_hwio, int Cin, int Cout, void* image, void* stream);
+/* conv1_1 (3 -> 64 channels; models/CNN/vgg.py:187) as a direct fp32 FMA convolution: w_hwio is the TF tensor
+ * [3][3][3][64] as is; optional out_amax = max |out|.  ws: disn_conv1_1_workspace_bytes(). */
+size_t disn_conv1_1_workspace_bytes(void);
+int disn_conv1_1(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu, float* out,
+                 float* out_amax, void* ws, size_t ws_bytes, void* stream);
+size_t disn_conv3x3_h2_workspace_bytes(void);
+int disn_conv3x3_h2(const float* in, int B, int H, int W, int Cin, const void* image, const float* bias, int Cout,
+                    int relu, float* out, float* pool_out, float* out_amax, int tiling, void* ws, size_t ws_bytes,
+                    void* stream);
 
 /* ---------------------------------------------------------------------- *
  * Row A / E: tf.image.resize_bilinear, TF1 legacy (align_corners=False,    *
@@ -91,6 +111,10 @@ typedef struct disn_vgg_weights {
    * (every fp32 operand is the exact sum of three bf16 terms; six cross products accumulated in
    * fp32), 1.1-1.5x the speed of the f32-input MFMA. */
   const void* conv_w_x3[13];
+  /* optional (NULL = not used): disn_pack_conv_h2 of the HWIO tensor; index 0 (Cin = 3): the TF tensor [3][3][3][64]
+   * as is.  With it a layer runs the single-image kernels of conv_h2.hip (two-term f16 split; conv1_1: direct fp32
+   * FMA) -- takes precedence over conv_w_x3; all 13 entries must be set for the activation-scale chain. */
+  const void* conv_w_h2[13];
 } disn_vgg_weights_t;
 
 size_t disn_vgg16_workspace_bytes(int B);

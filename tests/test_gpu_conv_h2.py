@@ -1,0 +1,145 @@
+"""GPU parity of the single-image convolution (disn_amd/csrc/conv_h2.hip, through the C ABI) against the
+oracle's float64 3x3 SAME convolution (oracle/disn_oracle.py:conv2d; models/CNN/vgg.py:187-196): every VGG
+layer shape at B = 1, every workgroup tiling on ragged shapes, the fused 2x2 max pool, the activation maximum
+the next layer scales by, run-to-run bit reproducibility, and the device weight image against its CPU
+restatement (tests/conv_h2_emulation.py)."""
+import numpy as np
+import pytest
+import torch
+
+import conv_h2_emulation as E
+from conftest import report_close
+from oracle import disn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from disn_amd import ops as _ops
+    return _ops
+
+
+def case(B, H, W, Cin, Cout, seed, relu_input=True):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    if relu_input:
+        x = np.maximum(x, 0) * 2.0
+    w = (rng.standard_normal((3, 3, Cin, Cout)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    return x, w, b
+
+
+def test_weight_image_equals_the_layout_restatement(ops):
+    _, w, _ = case(1, 2, 2, 128, 64, 5)
+    img = host(ops.pack_conv_h2(dev(w)))
+    ref, s = E.pack(w)
+    n = ref.size * 2
+    assert np.array_equal(img[:n].view(np.float16).reshape(ref.shape), ref)
+    meta = img[n:n + 8].view(np.float32)
+    assert meta[0] == s and meta[1] == 1.0 / s
+
+
+VGG_SHAPES = [(224, 64, 64), (112, 64, 128), (112, 128, 128), (56, 128, 256), (56, 256, 256), (28, 256, 512),
+              (28, 512, 512), (14, 512, 512)]
+
+
+@pytest.mark.parametrize("hw,cin,cout", VGG_SHAPES)
+def test_vgg_layer_shapes_vs_float64(ops, hw, cin, cout):
+    x, w, b = case(1, hw, hw, cin, cout, hw + cin)
+    ref = O.conv2d(x, w, b, "SAME", True, dtype=np.float64)
+    out, pooled, amax = ops.conv3x3_h2(dev(x), ops.pack_conv_h2(dev(w)), dev(b), cout, True, pool=True,
+                                       want_amax=True)
+    got = host(out)
+    # products carry 2^-22-relative operand errors, accumulation is fp32 over K <= 4608: same bar as the
+    # three-term kernel (tests/test_gpu_kernels.py)
+    report_close("conv3x3_h2 %s" % ((hw, cin, cout),), got, ref, atol=1e-5, rtol=1e-5)
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    print("hw %d cin %d cout %d: max err %.3g, scale %.3g, relative %.3g" % (hw, cin, cout, err, scale, err / scale))
+    assert err <= 2e-6 * scale
+    assert np.array_equal(host(pooled), got.reshape(1, hw // 2, 2, hw // 2, 2, cout).max(axis=(2, 4)))
+    assert float(amax) == float(np.abs(got).max())
+
+
+@pytest.mark.parametrize("tiling", [1, 2, 3, 4])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 20, 18, 64, 128), (1, 30, 44, 128, 64), (3, 6, 8, 192, 64)])
+def test_every_tiling_on_ragged_shapes(ops, tiling, B, H, W, Cin, Cout):
+    x, w, b = case(B, H, W, Cin, Cout, 100 * tiling + H, relu_input=False)
+    ref = O.conv2d(x, w, b, "SAME", False, dtype=np.float64)
+    out, pooled, amax = ops.conv3x3_h2(dev(x), ops.pack_conv_h2(dev(w)), dev(b), Cout, False, pool=True,
+                                       want_amax=True, tiling=tiling)
+    got = host(out)
+    report_close("conv3x3_h2 tiling %d %s" % (tiling, (B, H, W, Cin, Cout)), got, ref, atol=1e-5, rtol=1e-5)
+    assert np.array_equal(host(pooled), got.reshape(B, H // 2, 2, W // 2, 2, Cout).max(axis=(2, 4)))
+    assert float(amax) == float(np.abs(got).max())
+
+
+def test_tilings_agree_bit_for_bit_and_runs_repeat(ops):
+    """the K order of an output element (chunk, tap, k16 block; (w0+w2)+(w1+w3)) does not depend on the tiling"""
+    x, w, b = case(1, 28, 28, 128, 128, 77)
+    img, xd, bd = ops.pack_conv_h2(dev(w)), dev(x), dev(b)
+    outs = [host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=t)) for t in (1, 2, 3, 4, 2)]
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)
+
+
+def test_zero_input_and_tiny_activations(ops):
+    x, w, b = case(1, 14, 14, 64, 64, 9)
+    img = ops.pack_conv_h2(dev(w))
+    out0 = host(ops.conv3x3_h2(dev(np.zeros_like(x)), img, dev(b), 64, True))
+    assert np.array_equal(out0, np.broadcast_to(np.maximum(b, 0), out0.shape))
+    xs = x * np.float32(1e-12)                        # the scale follows the tensor: relative accuracy is kept
+    ref = O.conv2d(xs, w, np.zeros_like(b), "SAME", True, dtype=np.float64)
+    got = host(ops.conv3x3_h2(dev(xs), img, dev(np.zeros_like(b)), 64, True))
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_argument_checks(ops):
+    from disn_amd import _lib
+    x, w, b = case(1, 8, 8, 64, 64, 1)
+    img = ops.pack_conv_h2(dev(w))
+    with pytest.raises(_lib.DisnError) as e:
+        ops.conv3x3_h2(dev(x[:, :7]), img, dev(b), 64, True, pool=True)       # odd height with a pool
+    assert e.value.status == -2
+    with pytest.raises(ValueError):
+        ops.pack_conv_h2(dev(np.zeros((3, 3, 32, 64), np.float32)))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 224, 224), (2, 37, 45), (1, 5, 3)])
+def test_conv1_1_direct_vs_float64(ops, B, H, W):
+    rng = np.random.default_rng(H)
+    x = rng.random((B, H, W, 3)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 64)) * np.sqrt(2.0 / 27)).astype(np.float32)
+    b = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    ref = O.conv2d(x, w, b, "SAME", True, dtype=np.float64)
+    out, amax = ops.conv1_1(dev(x), dev(w), dev(b), True, want_amax=True)
+    got = host(out)
+    report_close("conv1_1 direct %s" % ((B, H, W),), got, ref, atol=2e-6, rtol=2e-6)   # 27-term fp32 FMA chain
+    assert float(amax) == float(np.abs(got).max())
+
+
+def test_encoder_through_the_h2_kernels_equals_the_three_term_path():
+    """same weights, same image: the single-image kernels (engine default) against the implicit-GEMM path"""
+    from disn_amd.engine import SdfEngine
+    from disn_amd.weights import WeightStore
+    store = WeightStore.random_init(3, mode="he")
+    img = O.synth_inputs(5, 1, 8)["imgs"]
+    a = SdfEngine(store, conv_h2=True).encode(img)
+    b = SdfEngine(store, conv_h2=False).encode(img)
+    torch.cuda.synchronize()
+    for ta, tb, name in zip(a.taps, b.taps, ("conv1_2", "conv2_2", "conv3_3", "conv4_3", "conv5_3")):
+        sc = float(tb.abs().max())
+        d = float((ta - tb).abs().max())
+        print("%s: max |h2 - x3| %.3g of scale %.3g" % (name, d, sc))
+        assert d <= 4e-6 * sc
+    sc = float(b.embedding.abs().max())
+    assert float((a.embedding - b.embedding).abs().max()) <= 4e-6 * sc
