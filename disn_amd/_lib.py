@@ -35,7 +35,8 @@ class VggWeights(C.Structure):  # disn_vgg_weights_t
     _fields_ = [("conv_w", C.c_void_p * 13), ("conv_b", C.c_void_p * 13),
                 ("fc_w", C.c_void_p * 3), ("fc_b", C.c_void_p * 3), ("num_classes", C.c_int),
                 ("conv_w_x3", C.c_void_p * 13),   # optional three-term bf16 images (disn_pack_kn_x3)
-                ("conv_w_h2", C.c_void_p * 13)]   # optional two-term f16 images (disn_pack_conv_h2)
+                ("conv_w_h2", C.c_void_p * 13),   # optional two-term f16 images (disn_pack_conv_h2)
+                ("fc_w_t", C.c_void_p * 3)]       # optional transposed fc matrices [N][K]
 
 
 MLP_FIELDS = ("g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3", "g_w4_point", "g_w4_global", "g_b4",
@@ -46,10 +47,11 @@ MLP_FIELDS = ("g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3", "g_w4_point", "g_w
 MLP_X3_FIELDS = ("g_x2", "g_x3", "g_x4_point", "g_x5", "l_x2", "l_x3", "l_x4", "l_x5")   # optional
 MLP_FOLD_FIELDS = ("l_w4_point", "l_w4_feat", "l_x4_point", "l_x4_feat")   # optional: *_folded entry points
 MLP_FUSED_FIELDS = ("g_fused", "l_fused")   # optional: *_fused entry points (disn_mlp_fused_pack images)
+MLP_T_FIELDS = ("g_w4_global_t",)           # optional: g_w4_global transposed [512][1024]
 
 
 class MlpWeights(C.Structure):  # disn_mlp_weights_t
-    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS + MLP_X3_FIELDS + MLP_FOLD_FIELDS + MLP_FUSED_FIELDS]
+    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS + MLP_X3_FIELDS + MLP_FOLD_FIELDS + MLP_FUSED_FIELDS + MLP_T_FIELDS]
 
 
 CAM_FIELDS = tuple("%s_%s%d" % (t, k, i) for t in "srt" for i in (1, 2, 3) for k in "wb")
@@ -91,6 +93,7 @@ SIGNATURES = {
     "disn_maxpool2x2": (I, [P, I, I, I, I, P, P]),
     "disn_fc_workspace_bytes": (Z, [I, I, I]),
     "disn_fc": (I, [P, I, I, P, P, I, I, P, P, Z, P]),
+    "disn_fc_t": (I, [P, I, I, P, P, I, I, P, P]),
     "disn_dense_workspace_bytes": (Z, [I, I, I]),
     "disn_dense": (I, [P, I, I, P, I, I, I, P, P, I, I, P, P, Z, P]),
     "disn_build_featmap": (I, [C.POINTER(C.c_void_p * 5), I, P, P]),

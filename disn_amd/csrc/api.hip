@@ -413,6 +413,14 @@ int disn_fc(const float* x, int B, int K, const float* w_kn, const float* bias, 
   return 0;
 }
 
+int disn_fc_t(const float* x, int B, int K, const float* wt_nk, const float* bias, int N, int relu, float* out,
+              void* stream) {
+  if (!x || !wt_nk || !bias || !out || B <= 0 || K <= 0 || N <= 0) return DISN_E_ARG;
+  if (K % 4) return DISN_E_SHAPE;
+  DISN_TRY(gemv_rows_launch(x, B, K, wt_nk, bias, N, relu, out, (hipStream_t)stream));
+  return 0;
+}
+
 size_t disn_dense_workspace_bytes(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0 || K % 32 || N % 64) return 0;
   return gemm_plan(M, N, K).ws_bytes;
@@ -472,16 +480,15 @@ bool vgg_weights_ok(const disn_vgg_weights_t* w) {
 int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* resized,
                  float* const taps[5], float* featmap, const VggWs& s, const float** pool5,
                  hipStream_t st) {
+  // the single-image kernels (conv_h2.hip) when every layer has its image: each layer's epilogue leaves the
+  // maximum of its output in the slots the next layer scales its f16 split by (cleared by the resize launch)
+  bool h2 = x3_enabled();
+  for (int i = 0; i < 13; ++i) h2 = h2 && w->conv_w_h2[i] != nullptr;
   DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, resized, DISN_VGG_SIZE,
-                                  DISN_VGG_SIZE, 3, 0, st));
+                                  DISN_VGG_SIZE, 3, 0, st, 0, h2 ? s.amax : nullptr, h2 ? 14 * 64 : 0));
   const float* x = resized;
   bool toggle = false;
   const size_t gws_cap = (size_t)((char*)s.fc_ws - (char*)s.gemm_ws);
-  // the single-image kernels (conv_h2.hip) when every layer has its image: each layer's epilogue leaves the
-  // maximum of its output in the slots the next layer scales its f16 split by
-  bool h2 = x3_enabled();
-  for (int i = 0; i < 13; ++i) h2 = h2 && w->conv_w_h2[i] != nullptr;
-  if (h2) DISN_TRY(hipMemsetAsync(s.amax, 0, 14 * 64 * sizeof(float), st));
   for (int i = 0; i < 13; ++i) {
     const VggLayer& L = kVgg[i];
     float* out = L.tap >= 0 ? taps[L.tap] : (L.hw >= 112 ? s.bufA : (toggle ? s.bufB : s.bufA));
@@ -518,13 +525,24 @@ int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* re
 
 // row C: fc6 (7x7 VALID == dense over the NHWC-flattened pool5), fc7, fc8
 // (models/CNN/vgg.py:198-214; dropout inactive: is_training=False, model_normalization.py:76)
+int fc_layer(const float* x, int B, int K, const float* w_kn, const float* wt_nk, const float* bias, int N, int relu,
+             float* out, float* ws, hipStream_t st) {
+  if (wt_nk) DISN_TRY(gemv_rows_launch(x, B, K, wt_nk, bias, N, relu, out, st));
+  else DISN_TRY(gemv_launch(x, B, K, w_kn, bias, N, relu, out, ws, st));
+  return 0;
+}
+
 int vgg_head(const disn_vgg_weights_t* w, const float* pool5, int B, float* embedding,
              const VggWs& s, hipStream_t st) {
-  DISN_TRY(gemv_launch(pool5, B, 25088, w->fc_w[0], w->fc_b[0], 4096, 1, s.fc6, s.fc_ws, st));
-  DISN_TRY(gemv_launch(s.fc6, B, 4096, w->fc_w[1], w->fc_b[1], 4096, 1, s.fc7, s.fc_ws, st));
-  DISN_TRY(gemv_launch(s.fc7, B, 4096, w->fc_w[2], w->fc_b[2], w->num_classes, 0, embedding,
-                       s.fc_ws, st));
-  return 0;
+  int rc;
+  if ((rc = fc_layer(pool5, B, 25088, w->fc_w[0], w->fc_w_t[0], w->fc_b[0], 4096, 1, s.fc6, s.fc_ws, st))) return rc;
+  if ((rc = fc_layer(s.fc6, B, 4096, w->fc_w[1], w->fc_w_t[1], w->fc_b[1], 4096, 1, s.fc7, s.fc_ws, st))) return rc;
+  return fc_layer(s.fc7, B, 4096, w->fc_w[2], w->fc_w_t[2], w->fc_b[2], w->num_classes, 0, embedding, s.fc_ws, st);
+}
+
+// the per-image folded bias of the global fold2/conv1: gbias[b] = embedding[b] . W4_global + b4
+int gbias_layer(const disn_mlp_weights_t* w, const float* embedding, int B, float* gbias, float* ws, hipStream_t st) {
+  return fc_layer(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_w4_global_t, w->g_b4, 512, 0, gbias, ws, st);
 }
 
 struct EncQueryWs {
@@ -637,19 +655,20 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   int rc;
   DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (also orders aux behind the caller's inputs)
   DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
-  if (two) {
-    if ((rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, ctx->aux))) return rc;
-    if ((rc = mlp_g4_pre(mw, B * N, e.q.mlp, ctx->aux))) return rc;
-    DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
-  }
+  // The convolution stack is enqueued FIRST: when the host, not the GPU, is the pacer (a step is ~45 launches)
+  // the caller's stream must not sit idle while the auxiliary stream's small launches are being issued.  They
+  // are enqueued next and still run under the convolutions (the GPU is tens of microseconds behind the host).
   const float* pool5 = nullptr;
   rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5,
                     st);
   if (rc) return rc;
   if (two) {
     DISN_TRY(hipEventRecord(ctx->ev[7], st));
+    if ((rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, ctx->aux))) return rc;
+    if ((rc = mlp_g4_pre(mw, B * N, e.q.mlp, ctx->aux))) return rc;
+    DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
-    // g4_pre finished long ago: its wait sits next to the record, where `st` drains anyway
+    // g4_pre finishes long before conv5_3: its wait sits next to the ev[7] record, where `st` drains anyway
     DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));
   } else {
     if ((rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, st))) return rc;
@@ -669,8 +688,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
-  DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, mw->g_w4_global, mw->g_b4, 512, 0, e.q.gbias,
-                       e.q.gemv_ws, st));
+  { const int grc = gbias_layer(mw, embedding, B, e.q.gbias, e.q.gemv_ws, st); if (grc) return grc; }
   if (two)  // bias + ReLU of the split layer, fold2/conv2, then -- behind ev[6] -- the final sum
     return mlp_phase2_split(mw, B, N, e.q.gbias, sdf, e.q.mlp, st, ctx->ev[6]);
   return mlp_phase2(mw, B, N, e.q.gbias, sdf, nullptr, nullptr, 1.0f, e.q.mlp, st);
@@ -731,8 +749,7 @@ int disn_sdf_mlp(const disn_mlp_weights_t* w, const float* pts_rot, const float*
   const int chunk = chunk_for(N);
   const QueryWs q = query_layout(ws, B, chunk, false, false);
   if (q.total > ws_bytes) return DISN_E_WS;
-  DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
-                       q.gemv_ws, st));
+  { const int grc = gbias_layer(w, embedding, B, q.gbias, q.gemv_ws, st); if (grc) return grc; }
   for (int b = 0; b < B; ++b)
     for (int n0 = 0; n0 < N; n0 += chunk) {
       const int n = (N - n0) < chunk ? (N - n0) : chunk;
@@ -760,8 +777,7 @@ int disn_query(const disn_mlp_weights_t* w, const float* featmap, const float* e
   const int chunk = chunk_for(N);
   const QueryWs q = query_layout(ws, B, chunk, true, false);
   if (q.total > ws_bytes) return DISN_E_WS;
-  DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
-                       q.gemv_ws, st));
+  { const int grc = gbias_layer(w, embedding, B, q.gbias, q.gemv_ws, st); if (grc) return grc; }
   const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
   for (int b = 0; b < B; ++b)
     for (int n0 = 0; n0 < N; n0 += chunk) {
@@ -810,8 +826,7 @@ int disn_query_folded(const disn_mlp_weights_t* w, const float* pmap, const floa
   const QueryWs q = query_layout(ws, B, chunk, true, false);
   if (q.total > ws_bytes) return DISN_E_WS;
   DISN_TRY(hipMemsetAsync(q.mlp.zero512, 0, 512 * sizeof(float), st));
-  DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
-                       q.gemv_ws, st));
+  { const int grc = gbias_layer(w, embedding, B, q.gbias, q.gemv_ws, st); if (grc) return grc; }
   for (int b = 0; b < B; ++b)
     for (int n0 = 0; n0 < N; n0 += chunk) {
       const int n = (N - n0) < chunk ? (N - n0) : chunk;
@@ -839,8 +854,7 @@ int disn_query_grid_folded(const disn_mlp_weights_t* w, const float* pmap, const
   const QueryWs q = query_layout(ws, 1, chunk, true, true);
   if (q.total > ws_bytes) return DISN_E_WS;
   DISN_TRY(hipMemsetAsync(q.mlp.zero512, 0, 512 * sizeof(float), st));
-  DISN_TRY(gemv_launch(embedding, 1, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
-                       q.gemv_ws, st));
+  { const int grc = gbias_layer(w, embedding, 1, q.gbias, q.gemv_ws, st); if (grc) return grc; }
   for (int64_t k = k0; k < k1; k += chunk) {
     const int n = (int)((k1 - k) < chunk ? (k1 - k) : chunk);
     DISN_TRY(grid_points_launch(g, k, k + n, q.pts, st));
@@ -913,7 +927,7 @@ int disn_query_fused(const disn_mlp_weights_t* w, const float* pmap, const float
   hipStream_t st = (hipStream_t)stream;
   const FusedWs f = fused_layout(ws, B, N);
   if (f.total > ws_bytes) return DISN_E_WS;
-  DISN_TRY(gemv_launch(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, f.gbias, f.gemv_ws, st));
+  { const int grc = gbias_layer(w, embedding, B, f.gbias, f.gemv_ws, st); if (grc) return grc; }
   for (int b = 0; b < B; ++b) {
     const size_t o = (size_t)b * N;
     const int rc = fused_streams(w, f.gbias + (size_t)b * 512, pmap + (size_t)b * kMapPixels * 512, pmap_amax + b,
@@ -942,7 +956,7 @@ int disn_query_grid_fused(const disn_mlp_weights_t* w, const float* pmap, const 
   hipStream_t st = (hipStream_t)stream;
   const FusedWs f = fused_layout(ws, 1, k1 - k0);
   if (f.total > ws_bytes) return DISN_E_WS;
-  DISN_TRY(gemv_launch(embedding, 1, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, f.gbias, f.gemv_ws, st));
+  { const int grc = gbias_layer(w, embedding, 1, f.gbias, f.gemv_ws, st); if (grc) return grc; }
   // one launch per stream over the whole range: no chunking, no per-point workspace but the global sums
   return fused_streams(w, f.gbias, pmap, pmap_amax, trans_mat, nullptr, nullptr, &g, k0, k1 - k0, f.gsum, out,
                        sdf_weight, st);
@@ -977,8 +991,7 @@ int disn_query_grid(const disn_mlp_weights_t* w, const float* featmap, const flo
   const int chunk = chunk_for(k1 - k0);
   const QueryWs q = query_layout(ws, 1, chunk, true, true);
   if (q.total > ws_bytes) return DISN_E_WS;
-  DISN_TRY(gemv_launch(embedding, 1, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
-                       q.gemv_ws, st));
+  { const int grc = gbias_layer(w, embedding, 1, q.gbias, q.gemv_ws, st); if (grc) return grc; }
   for (int64_t k = k0; k < k1; k += chunk) {
     const int n = (int)((k1 - k) < chunk ? (k1 - k) : chunk);
     DISN_TRY(grid_points_launch(g, k, k + n, q.pts, st));
@@ -1020,8 +1033,7 @@ int disn_query_grid_ctx(disn_ctx_t* ctx, const disn_mlp_weights_t* w, const floa
   // events: 0 fork, 1/2 buffer ready (aux -> main), 3/4 buffer free (main -> aux)
   DISN_TRY(hipEventRecord(ctx->ev[0], st));
   DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
-  DISN_TRY(gemv_launch(embedding, 1, DISN_EMBED_DIM, w->g_w4_global, w->g_b4, 512, 0, q.gbias,
-                       q.gemv_ws, st));
+  { const int grc = gbias_layer(w, embedding, 1, q.gbias, q.gemv_ws, st); if (grc) return grc; }
   int i = 0;
   for (int64_t k = k0; k < k1; k += chunk, ++i) {
     const int n = (int)((k1 - k) < chunk ? (k1 - k) : chunk);

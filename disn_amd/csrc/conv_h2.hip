@@ -48,7 +48,6 @@ typedef _Float16 ch_h4 __attribute__((ext_vector_type(4)));
 typedef float ch_f16v __attribute__((ext_vector_type(16)));
 
 namespace ch2 {
-constexpr int kPix = 272;  // bytes per halo pixel in LDS
 // power of two s with amax * s in [2^target, 2^(target+1)); 1 for amax == 0 / non-finite / extreme
 __host__ __device__ inline float pow2_scale(float amax, int target_exp) {
   union { float f; unsigned u; } a;
@@ -69,15 +68,17 @@ __host__ __device__ constexpr int quad_row(int q, int g) {
 }  // namespace ch2
 
 // ---------------------------------------------------------------------------------------------------
-// weight image: for n-block nb (32 output channels), k-wave wk, step s = chunk * 9 + tap:
-//   two 1-KiB planes (h, l), lane (j, g) holds W[tap][64 chunk + 16 wk + 8 g + e][32 nb + j] * s_w, e = 0..7
-// at byte ((((nb * 4 + wk) * S + s) * 2 + plane) * 64 + lane) * 16.  Behind the image: {s_w, 1 / s_w}.
+// weight image: for n-block nb (32 output channels), k16 block kb (input channels 16 kb .. 16 kb + 15), tap t:
+//   two 1-KiB planes (h, l), lane (j, g) holds W[t][16 kb + 8 g + e][32 nb + j] * s_w, e = 0..7
+// at byte ((((nb * (Cin / 16) + kb) * 9 + t) * 2 + plane) * 64 + lane) * 16: the nine taps of one k16 block are one
+// contiguous 18 KiB -- what one k-wave reads per chunk, whatever the number of k-waves.  Behind the image:
+// {s_w, 1 / s_w}.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restrict__ w, int Cin, int Cout,
                                                            const float* __restrict__ amax,
                                                            unsigned char* __restrict__ image) {
-  const int S = 9 * (Cin >> 6);
-  const size_t frags = (size_t)(Cout >> 5) * 4 * S;
+  const int KB = Cin >> 4;
+  const size_t frags = (size_t)(Cout >> 5) * KB * 9;
   const float s = ch2::pow2_scale(amax[0], 13);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     float* meta = reinterpret_cast<float*>(image + (size_t)Cin * 9 * Cout * 4);
@@ -87,15 +88,14 @@ __global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restri
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < frags * 64; idx += (size_t)gridDim.x * 256) {
     const int lane = (int)(idx & 63);
     const size_t f = idx >> 6;
-    const int st = (int)(f % S);
-    const int wk = (int)((f / S) & 3);
-    const int nb = (int)(f / ((size_t)S * 4));
-    const int c = st / 9, t = st - 9 * c;
+    const int t = (int)(f % 9);
+    const int kb = (int)((f / 9) % KB);
+    const int nb = (int)(f / ((size_t)9 * KB));
     const int j = lane & 31, g = lane >> 5;
     ch_h8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int ci = 64 * c + 16 * wk + 8 * g + e;
+      const int ci = 16 * kb + 8 * g + e;
       const float v = w[((size_t)t * Cin + ci) * Cout + 32 * nb + j] * s;
       const _Float16 h = (_Float16)v;
       hi[e] = h;
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restri
 
 size_t conv_h2_image_bytes(int Cin, int Cout) { return (size_t)Cin * 9 * Cout * 4 + 256; }
 
+#ifndef CH2_UBENCH
 // w: TF HWIO [3][3][Cin][Cout]; scratch: one float (max |w|)
 hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, float* scratch, hipStream_t st) {
   hipError_t e = amax_launch(w, (size_t)9 * Cin * Cout, scratch, st);
@@ -117,6 +118,8 @@ hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, f
                      static_cast<unsigned char*>(image));
   return hipGetLastError();
 }
+
+#endif  // CH2_UBENCH
 
 // ---------------------------------------------------------------------------------------------------
 struct ConvH2Dev {
@@ -140,23 +143,33 @@ struct ConvH2Dev {
 #define CH2_STAMP(i)
 #endif
 
-template <int MB, int NW, int SEG, int TW, int D>
-__global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P) {
+// WK k-waves per n-block (4 or 8): a chunk is CK = 16 WK input channels.  Eight k-waves put two waves on every
+// SIMD of the CU: a global_load_dwordx4 blocks its wave's in-order issue for ~50 cycles (measured: a chunk with
+// loads costs 1100-1400 cycles more than the same chunk without, r02d stamps), which only ANOTHER wave's MFMAs can
+// cover.
+// ABL (tools/ubench/conv_h2_ablate.hip only; 0 in the library): 1 no weight loads in the loop, 2 no halo loads,
+// 4 no split + LDS store, 8 no A-fragment reads in the loop (wrong results: timing only)
+template <int MB, int NW, int SEG, int TW, int D, int WK, int ABL = 0>
+__global__ __launch_bounds__(64 * WK * NW, 1) void conv_h2_kernel(const ConvH2Dev P) {
+  constexpr int CK = 16 * WK;         // input channels per chunk
+  constexpr int KPIX = CK * 4 + 16;   // bytes per halo pixel: h plane, l plane, pad -- an odd multiple of 16
+  constexpr int UPP = CK / 4;         // float4 units per pixel
   constexpr int RPS = 32 / SEG;       // patch rows per 32-row block
   constexpr int TH = MB * RPS;        // patch rows
   constexpr int RP = TW + 2;          // halo row pitch in pixels
   constexpr int HP = (TH + 2) * RP;   // halo pixels
-  constexpr int BUF = HP * ch2::kPix;
-  constexpr int NT = 256 * NW;
-  constexpr int LP = (HP * 16 + NT - 1) / NT;  // float4 units per thread and chunk
-  constexpr int XCH = NW * 4 * MB * 4096;      // exchange area of the final K reduction
+  constexpr int BUF = HP * KPIX;
+  constexpr int NT = 64 * WK * NW;
+  constexpr int LP = (HP * UPP + NT - 1) / NT;  // float4 units per thread and chunk
+  constexpr int XCH = NW * WK * MB * 4096;      // exchange area of the final K reduction
   // reads of the rows beyond TW (never stored) run up to 34 - RP pixels past a buffer
-  constexpr int LDS_BYTES = (2 * BUF + 8 * ch2::kPix) > XCH ? (2 * BUF + 8 * ch2::kPix) : XCH;
+  constexpr int LDS_BYTES = (2 * BUF + 8 * KPIX) > XCH ? (2 * BUF + 8 * KPIX) : XCH;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wk = wave & 3, wn = wave >> 2;
+  const int wk = wave % WK, wn = wave / WK;
   const int j = lane & 31, g = lane >> 5;
   CH2_STAMP(0);
   CH2_STAMP(1);
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
   const int y0 = tyi * TH, x0 = txi * TW;
   const int n0 = (nt * NW + wn) * 32;
   const int H = P.H, W = P.W, Cin = P.Cin, Cout = P.Cout;
-  const int NC = Cin >> 6;
+  const int NC = Cin / CK;
   const float* inb = P.in + (size_t)b * H * W * Cin;
 
   // ---- halo loader: unit u = (pixel, float4 of the chunk's 64 channels); 16 lanes = one pixel ----------------
@@ -188,18 +201,18 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
 #pragma unroll
   for (int k = 0; k < LP; ++k) {
     const int u = tid + k * NT;
-    const int hp = u >> 4, c4 = u & 15;
+    const int hp = u / UPP, c4 = u % UPP;
     const int hy = hp / RP, hx = hp - hy * RP;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-    const bool in_halo = u < HP * 16;
+    const bool in_halo = u < HP * UPP;
     const bool ok = in_halo && y >= 0 && y < H && x >= 0 && x < W;
     goff[k] = ok ? (y * W + x) * Cin + 4 * c4 : 4 * c4;
     gmask[k] = ok ? 0xffffffffu : 0u;
-    woff[k] = in_halo ? hp * ch2::kPix + 8 * c4 : -1;
+    woff[k] = in_halo ? hp * KPIX + 8 * c4 : -1;
   }
   auto load_chunk = [&](int c, float4 (&ra)[LP]) {
 #pragma unroll
-    for (int k = 0; k < LP; ++k) ra[k] = *reinterpret_cast<const float4*>(inb + goff[k] + 64 * c);
+    for (int k = 0; k < LP; ++k) ra[k] = *reinterpret_cast<const float4*>(inb + goff[k] + CK * c);
   };
   float sa = 1.0f;
   auto store_unit = [&](int buf, const float4 (&ra)[LP], int k) {
@@ -214,23 +227,18 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
       ll[e] = (_Float16)(v - (float)h);
     }
     *reinterpret_cast<ch_h4*>(&lds[buf * BUF + woff[k]]) = hh;
-    *reinterpret_cast<ch_h4*>(&lds[buf * BUF + woff[k] + 128]) = ll;
+    *reinterpret_cast<ch_h4*>(&lds[buf * BUF + woff[k] + CK * 2]) = ll;
   };
 
   // the first halo is requested before anything else (loads return in order: nothing may queue in front of it)
   float4 ra0[LP];
   load_chunk(0, ra0);
 
-  // ---- scales: the producer's maximum (64 slots, see the epilogue) and the weight image's ------------------------
+  // ---- scales: the producer's maximum (64 slots, see the epilogue) and the weight image's; requested here, used
+  // after the weight queue below is in flight (loads return in order: waiting for these must not wait for those) ----
   const float* meta = reinterpret_cast<const float*>(P.wimg + (size_t)Cin * 9 * Cout * 4);
-  float descale;
-  {
-    float m = P.in_amax[lane];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    sa = ch2::pow2_scale(m, 14);
-    descale = (1.0f / sa) * meta[1];
-  }
+  float amax_lane = P.in_amax[lane];
+  const float inv_sw = meta[1];
 
   // ---- A rows of this lane: logical row sigma(i) of block mb -> centre pixel in the halo -----------------------
   int arow[MB];
@@ -239,15 +247,16 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
     const int seg = SEG == 16 ? (Lr >> 4) : 0, pos = SEG == 16 ? (Lr & 15) : Lr;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
-      arow[mb] = ((mb * RPS + seg + 1) * RP + pos + 1) * ch2::kPix + (16 * wk + 8 * g) * 2;
+      arow[mb] = ((mb * RPS + seg + 1) * RP + pos + 1) * KPIX + (16 * wk + 8 * g) * 2;
   }
 
   // ---- this wave's weight stream -----------------------------------------------------------------------------
-  // queue of D fragment pairs (D divides 9): step s = 9 chunk + tap sits in slot tap % D; step s + D is
-  // requested into the slot step s just freed
+  // k16 block WK c + wk in chunk c: nine contiguous pairs per chunk, WK * 18 KiB from one chunk to the next.
+  // Queue of D pairs (D divides 9): tap t of a chunk sits in slot t % D; the pair D taps ahead is requested into
+  // the slot a tap just freed.
   static_assert(9 % D == 0, "queue depth");
-  const int S = 9 * NC;
-  const unsigned char* wp = P.wimg + ((size_t)((n0 >> 5) * 4 + wk) * S) * 2048 + lane * 16;
+  const unsigned char* wp = P.wimg + ((size_t)((n0 >> 5) * (Cin >> 4) + wk) * 9) * 2048 + lane * 16;
+  constexpr size_t kChunkStride = (size_t)WK * 9 * 2048;
   ch_h8 qh[D], ql[D];
 #pragma unroll
   for (int t = 0; t < D; ++t) {
@@ -261,6 +270,11 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
 
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) amax_lane = fmaxf(amax_lane, __shfl_xor(amax_lane, off));
+  sa = ch2::pow2_scale(amax_lane, 14);
+  const float descale = (1.0f / sa) * inv_sw;
+
   CH2_STAMP(2);
 #pragma unroll
   for (int k = 0; k < LP; ++k) store_unit(0, ra0, k);
@@ -272,30 +286,39 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
   // the ~7 VALU slots between two 8-pass MFMAs are free), and each tap requests the fragment pair D steps
   // ahead into the queue slot it just freed.  The A fragments of tap t + 1 are read while the MFMAs of tap t run.
   auto read_a = [&](const unsigned char* A, int t, ch_h8 (&ah)[MB], ch_h8 (&al)[MB]) {
-    const int shift = ((t / 3 - 1) * RP + (t % 3 - 1)) * ch2::kPix;
+    const int shift = ((t / 3 - 1) * RP + (t % 3 - 1)) * KPIX;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       ah[mb] = *reinterpret_cast<const ch_h8*>(A + arow[mb] + shift);
-      al[mb] = *reinterpret_cast<const ch_h8*>(A + arow[mb] + shift + 128);
+      al[mb] = *reinterpret_cast<const ch_h8*>(A + arow[mb] + shift + CK * 2);
     }
   };
   constexpr int T0 = 5;
   auto chunk = [&](int c, auto more_c) {
     constexpr bool MORE = decltype(more_c)::value;
     float4 ra[LP];
-    if (MORE) load_chunk(c + 1, ra);
+    if (MORE && !(ABL & 2)) load_chunk(c + 1, ra);
+    if (ABL & 2) {
+#pragma unroll
+      for (int k = 0; k < LP; ++k) ra[k] = make_float4(1.f, 2.f, 3.f, 4.f);
+    }
     const unsigned char* A = &lds[(c & 1) * BUF];
-    const unsigned char* wnext = wp + ((size_t)c * 9 + D) * 2048;
+    const unsigned char* wcur = wp + (size_t)c * kChunkStride;
     ch_h8 ah[2][MB], al[2][MB];
     read_a(A, 0, ah[0], al[0]);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const ch_h8 bh = qh[t % D], bl = ql[t % D];
-      if (MORE || t + D < 9) {
-        qh[t % D] = *reinterpret_cast<const ch_h8*>(wnext + (size_t)t * 2048);
-        ql[t % D] = *reinterpret_cast<const ch_h8*>(wnext + (size_t)t * 2048 + 1024);
+      if ((MORE || t + D < 9) && !(ABL & 1)) {  // the pair D taps ahead: this chunk's or the next one's
+        const unsigned char* wa = wcur + ((t + D) / 9) * kChunkStride + (size_t)((t + D) % 9) * 2048;
+        qh[t % D] = *reinterpret_cast<const ch_h8*>(wa);
+        ql[t % D] = *reinterpret_cast<const ch_h8*>(wa + 1024);
       }
-      if (t < 8) read_a(A, t + 1, ah[(t + 1) & 1], al[(t + 1) & 1]);
+      if (t < 8 && !(ABL & 8)) read_a(A, t + 1, ah[(t + 1) & 1], al[(t + 1) & 1]);
+      if (t < 8 && (ABL & 8)) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) { ah[(t + 1) & 1][mb] = ah[0][mb]; al[(t + 1) & 1][mb] = al[0][mb]; }
+      }
       __builtin_amdgcn_sched_barrier(0);  // the loads above are ISSUED here, not sunk next to their uses
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
@@ -303,7 +326,7 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
         acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t & 1][mb], bl, acc[mb], 0, 0, 0);
         acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t & 1][mb], bh, acc[mb], 0, 0, 0);
       }
-      if (MORE && t >= T0) {  // units k with T0 + (9 - T0) k / LP == t: not before the loads had time to return
+      if (MORE && t >= T0 && !(ABL & 4)) {  // units k with T0 + (9 - T0) k / LP == t: not before the loads had time to return
 #pragma unroll
         for (int k = 0; k < LP; ++k)
           if (T0 + ((9 - T0) * k) / LP == t) store_unit((c + 1) & 1, ra, k);
@@ -326,10 +349,12 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
   chunk(NC - 1, std::false_type{});
   CH2_STAMP(12);
 
-  // ---- sum of the four k-waves through LDS, (w0 + w2) + (w1 + w3); wave wk finishes register quad q = wk of every
-  // block: a quarter of the tile's rows each, so the stores, the pool and the maximum are spread over all waves ----
+  // ---- sum of the k-waves through LDS in a fixed order -- (w0 + w2) + (w1 + w3), with eight waves
+  // ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7)).  Every wave finishes a share of the tile: register quad
+  // q = wk & 3 of every block (with eight waves: rows 2 hh, 2 hh + 1 of the quad, hh = wk >> 2), so the stores,
+  // the pool and the maximum are spread over all waves ----
   float* xch = reinterpret_cast<float*>(lds);
-  auto xaddr = [&](int slot, int mb, int r) { return (((wn * 4 + slot) * MB + mb) * 16 + r) * 64 + lane; };
+  auto xaddr = [&](int slot, int mb, int r) { return (((wn * WK + slot) * MB + mb) * 16 + r) * 64 + lane; };
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -337,19 +362,26 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
   __syncthreads();
   CH2_STAMP(13);
 
+  constexpr int NE = WK == 8 ? 2 : 4;  // rows of the quad this wave finishes
+  const int q4 = wk & 3, e0 = WK == 8 ? 2 * (wk >> 2) : 0;
   const float bias_j = P.bias[n0 + j];
   float* outb = P.out + (size_t)b * H * W * Cout + n0 + j;
-  const int L0 = ch2::sigma(8 * wk + 4 * g);  // first of this lane's four consecutive logical rows
+  const int L0 = ch2::sigma(8 * q4 + 4 * g);  // first of the quad's four consecutive logical rows
   const int seg = SEG == 16 ? (L0 >> 4) : 0, pos0 = SEG == 16 ? (L0 & 15) : L0;
-  float val[MB][4];
+  float val[MB][NE];
   float vmax = 0.f;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int y = y0 + mb * RPS + seg;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int r = 4 * wk + e, tx = pos0 + e, x = x0 + tx;
-      float v = (xch[xaddr(0, mb, r)] + xch[xaddr(2, mb, r)]) + (xch[xaddr(1, mb, r)] + xch[xaddr(3, mb, r)]);
+    for (int e = 0; e < NE; ++e) {
+      const int r = 4 * q4 + e0 + e, tx = pos0 + e0 + e, x = x0 + tx;
+      float v;
+      if (WK == 8)
+        v = ((xch[xaddr(0, mb, r)] + xch[xaddr(4, mb, r)]) + (xch[xaddr(2, mb, r)] + xch[xaddr(6, mb, r)])) +
+            ((xch[xaddr(1, mb, r)] + xch[xaddr(5, mb, r)]) + (xch[xaddr(3, mb, r)] + xch[xaddr(7, mb, r)]));
+      else
+        v = (xch[xaddr(0, mb, r)] + xch[xaddr(2, mb, r)]) + (xch[xaddr(1, mb, r)] + xch[xaddr(3, mb, r)]);
       v = fmaf(v, descale, bias_j);
       if (P.relu) v = fmaxf(v, 0.f);
       val[mb][e] = v;
@@ -362,7 +394,7 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
   if (P.out_amax) {  // 64 slots: same-address atomics serialise in L2 (~10 ns each)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(P.out_amax) + ((blockIdx.x * 4 * NW + wave) & 63), __float_as_uint(vmax));
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(P.out_amax) + ((blockIdx.x * WK * NW + wave) & 63), __float_as_uint(vmax));
   }
   if (P.pool_out) {  // H, W even; y0, x0 even: a 2x2 window never leaves the tile, nor this wave's quad
     const int Hp = H >> 1, Wp = W >> 1;
@@ -371,8 +403,8 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
 #pragma unroll
       for (int p = 0; p < MB / 2; ++p)
 #pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          const int tx = L0 + e, x = x0 + tx, y = y0 + 2 * p;
+        for (int e = 0; e < NE; e += 2) {
+          const int tx = L0 + e0 + e, x = x0 + tx, y = y0 + 2 * p;
           const float m = fmaxf(fmaxf(val[2 * p][e], val[2 * p][e + 1]), fmaxf(val[2 * p + 1][e], val[2 * p + 1][e + 1]));
           if (tx < TW && y + 1 < H && x + 1 < W) pb[((size_t)(y >> 1) * Wp + (x >> 1)) * Cout] = m;
         }
@@ -380,10 +412,10 @@ __global__ __launch_bounds__(256 * NW, 1) void conv_h2_kernel(const ConvH2Dev P)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int e = 0; e < 4; e += 2) {
+        for (int e = 0; e < NE; e += 2) {
           float m = fmaxf(val[mb][e], val[mb][e + 1]);
           m = fmaxf(m, __shfl_xor(m, 32));
-          const int tx = (L0 & 15) + e, x = x0 + tx, y = y0 + 2 * mb;
+          const int tx = (L0 & 15) + e0 + e, x = x0 + tx, y = y0 + 2 * mb;
           if (L0 < 16 && tx < TW && y + 1 < H && x + 1 < W) pb[((size_t)(y >> 1) * Wp + (x >> 1)) * Cout] = m;
         }
     }
@@ -403,11 +435,15 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
                                                              int relu, float* __restrict__ out,
                                                              float* __restrict__ out_amax) {
   __shared__ float win[2][3 * 34 * 3 + 2];
+  __shared__ __attribute__((aligned(16))) float wl[27 * 64];
   __shared__ float red[4];
   const int tid = threadIdx.x, c4 = tid & 15, pp = tid >> 4;  // pixels pp and pp + 16 of the segment
+  for (int i = tid; i < 27 * 16; i += 256)  // the 6.9 KB of weights once per workgroup, then per thread from LDS
+    reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(w)[i];
+  __syncthreads();
   float4 wr[27];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) wr[k] = *reinterpret_cast<const float4*>(w + k * 64 + 4 * c4);
+  for (int k = 0; k < 27; ++k) wr[k] = *reinterpret_cast<const float4*>(&wl[k * 64 + 4 * c4]);
   const float4 bv = *reinterpret_cast<const float4*>(bias + 4 * c4);
   const int segs_x = (W + 31) >> 5;
   const long nseg = (long)B * H * segs_x;
@@ -459,18 +495,18 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
 hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu,
                                  float* out, float* out_amax, hipStream_t st) {
   const long nseg = (long)B * H * ((W + 31) / 32);
-  const int grid = (int)(nseg < 2048 ? nseg : 2048);
+  const int grid = (int)(nseg < 512 ? nseg : 512);  // two workgroups per CU, ~3 segments each at 224 x 224
   hipLaunchKernelGGL(conv1_1_direct_kernel, dim3(grid), dim3(256), 0, st, in, w_hwio, bias, B, H, W, relu, out, out_amax);
   return hipGetLastError();
 }
 
-template <int MB, int NW, int SEG, int TW, int D>
+template <int MB, int NW, int SEG, int TW, int D, int WK>
 static hipError_t conv_h2_go(ConvH2Dev d, hipStream_t st) {
   constexpr int TH = MB * (32 / SEG);
   d.tiles_x = (d.W + TW - 1) / TW;
   d.tiles_y = (d.H + TH - 1) / TH;
   const int grid = d.B * d.tiles_x * d.tiles_y * (d.Cout / (32 * NW));
-  hipLaunchKernelGGL((conv_h2_kernel<MB, NW, SEG, TW, D>), dim3(grid), dim3(256 * NW), 0, st, d);
+  hipLaunchKernelGGL((conv_h2_kernel<MB, NW, SEG, TW, D, WK>), dim3(grid), dim3(64 * WK * NW), 0, st, d);
   return hipGetLastError();
 }
 
@@ -498,16 +534,19 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
       cfg = wgs1 <= 320 ? 2 : 3;
     } else cfg = 4;
   }
+  // one n-block per workgroup: eight k-waves (two waves per SIMD) when the channel count allows 128-channel chunks
+  const bool wk8 = Cin % 128 == 0;
   switch (cfg) {
-    case 1: return conv_h2_go<1, 1, 16, 14, 9>(d, st);
-    case 2: return conv_h2_go<2, 1, 32, 28, 9>(d, st);
-    case 3: return conv_h2_go<2, 2, 32, 28, 9>(d, st);
-    default: return conv_h2_go<4, 2, 16, 16, 3>(d, st);
+    case 1: return wk8 ? conv_h2_go<1, 1, 16, 14, 9, 8>(d, st) : conv_h2_go<1, 1, 16, 14, 9, 4>(d, st);
+    case 2: return wk8 ? conv_h2_go<2, 1, 32, 28, 9, 8>(d, st) : conv_h2_go<2, 1, 32, 28, 9, 4>(d, st);
+    case 3: return conv_h2_go<2, 2, 32, 28, 9, 4>(d, st);
+    default: return conv_h2_go<4, 2, 16, 16, 3, 4>(d, st);
   }
 }
 
 }  // namespace disn
 
+#ifndef CH2_UBENCH
 // ---- C ABI: the layer as a unit (tests, composition); disn_encode* use conv_h2_launch directly ----------
 #include "../../include/disn_amd.h"
 
@@ -567,3 +606,4 @@ int disn_conv1_1(const float* in, int B, int H, int W, const float* w_hwio, cons
 }
 
 }  // extern "C"
+#endif  // CH2_UBENCH

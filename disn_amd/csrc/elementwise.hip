@@ -25,7 +25,12 @@ template <int VEC>
 __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, int B, int Hin,
                                                      int Win, int C, float* __restrict__ out,
                                                      int Hout, int Wout, int out_cstride,
-                                                     int out_coff, float sy, float sx) {
+                                                     int out_coff, float sy, float sx,
+                                                     float* __restrict__ zero, int nzero) {
+  // side job of the encoder's first launch: clear the activation-maximum slots of the convolution stack
+  // (api.hip vgg_features) -- saves a memset launch and the stream bubble around it
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0.f;
   const int cv = C / VEC;
   const size_t total = (size_t)B * Hout * Wout * cv;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -78,7 +83,7 @@ static inline int grid_for(size_t total, int cap = 8192) {
 
 hipError_t resize_bilinear_launch(const float* in, int B, int Hin, int Win, int C, float* out,
                                   int Hout, int Wout, int out_cstride, int out_coff,
-                                  hipStream_t st, int max_blocks) {
+                                  hipStream_t st, int max_blocks, float* zero, int nzero) {
   const int cap = max_blocks > 0 ? max_blocks : 8192;
   const float sy = (float)Hin / (float)Hout;  // CalculateResizeScale, float32 division
   const float sx = (float)Win / (float)Wout;
@@ -86,11 +91,11 @@ hipError_t resize_bilinear_launch(const float* in, int B, int Hin, int Win, int 
   if (vec) {
     const size_t total = (size_t)B * Hout * Wout * (C / 4);
     hipLaunchKernelGGL((resize_kernel<4>), dim3(grid_for(total, cap)), dim3(256), 0, st, in, B, Hin, Win,
-                       C, out, Hout, Wout, out_cstride, out_coff, sy, sx);
+                       C, out, Hout, Wout, out_cstride, out_coff, sy, sx, zero, nzero);
   } else {
     const size_t total = (size_t)B * Hout * Wout * C;
     hipLaunchKernelGGL((resize_kernel<1>), dim3(grid_for(total, cap)), dim3(256), 0, st, in, B, Hin, Win,
-                       C, out, Hout, Wout, out_cstride, out_coff, sy, sx);
+                       C, out, Hout, Wout, out_cstride, out_coff, sy, sx, zero, nzero);
   }
   return hipGetLastError();
 }

@@ -52,6 +52,89 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
   }
 }
 
+// The same layer from the TRANSPOSED weight matrix wt [N][K] (one contiguous K-long row per output): a wave owns R
+// consecutive outputs and streams their rows (non-temporal, 64 lanes x 16 B = 1 KiB per instruction, U row pieces
+// in flight per row) against x; no K split, so no partial slabs and no reduce launch -- one launch per layer
+// instead of two, and at fc7 / fc8 sizes (67 / 17 MB, launch-latency bound) each of them is shorter.  x (16-100 KB)
+// is re-read by every wave from L1 / L2.  Fixed summation order: per lane over k = 4 lane + 256 i, then the
+// xor-shuffle tree.
+template <int NB, int R, int U>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ x, int K,
+                                                        const float* __restrict__ wt, int N,
+                                                        const float* __restrict__ bias, int relu,
+                                                        float* __restrict__ out, int b0) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const int n0 = wave * R;
+  if (n0 >= N) return;
+  float acc[R][NB];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+  const float* wr = wt + (size_t)n0 * K + lane * 4;
+  const float* xr = x + (size_t)b0 * K + lane * 4;
+  for (int k = 0; k < K; k += 256 * U) {
+    float4 wv[R][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool ok = k + 256 * u + lane * 4 < K && n0 + r < N;
+        wv[r][u] = ok ? nt_load4(wr + (size_t)r * K + k + 256 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = k + 256 * u + lane * 4 < K;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float4 xv = ok ? *reinterpret_cast<const float4*>(xr + (size_t)b * K + k + 256 * u)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          acc[r][b] += (wv[r][u].x * xv.x + wv[r][u].y * xv.y) + (wv[r][u].z * xv.z + wv[r][u].w * xv.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float v = acc[r][b];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0 && n0 + r < N) {
+        v += bias[n0 + r];
+        if (relu) v = fmaxf(v, 0.f);
+        out[(size_t)(b0 + b) * N + n0 + r] = v;
+      }
+    }
+}
+
+// wt_nk: [N][K] (the TF [K][N] matrix transposed); K % 4 == 0
+hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, const float* bias, int N, int relu,
+                            float* out, hipStream_t st) {
+  // two rows per wave when there are enough outputs to fill the chip that way (halves the x re-reads)
+  const bool two = N >= 4096;
+  const int waves = two ? (N + 1) / 2 : N;
+  const dim3 grid((waves + 3) / 4);
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    const int nb = (B - b0) < 4 ? (B - b0) : 4;
+    switch (nb) {
+#define DISN_GR_CASE(NB)                                                                                          \
+  case NB:                                                                                                        \
+    if (two) hipLaunchKernelGGL((gemv_rows_kernel<NB, 2, 4>), grid, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, b0); \
+    else hipLaunchKernelGGL((gemv_rows_kernel<NB, 1, 8>), grid, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, b0);    \
+    break;
+      DISN_GR_CASE(1) DISN_GR_CASE(2) DISN_GR_CASE(3) DISN_GR_CASE(4)
+#undef DISN_GR_CASE
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 int gemv_splits(int K, int N) {
   const int colblocks = N / 256;
   int s = (2048 + colblocks - 1) / colblocks;

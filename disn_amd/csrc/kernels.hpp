@@ -101,14 +101,17 @@ size_t gemv_ws_bytes(int B, int K, int N);
 // out[b][n] = act(sum_k x[b][k] W[k][n] + bias[n]); N % 256 == 0
 hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const float* bias, int N,
                        int relu, float* out, float* ws, hipStream_t st);
+// the same from the transposed matrix wt_nk [N][K]: one launch, no split-K partials (K % 4 == 0)
+hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, const float* bias, int N, int relu,
+                            float* out, hipStream_t st);
 
 
 // ---- elementwise.hip (compiled with -ffp-contract=off) --------------------
 // max_blocks > 0 caps the grid (grid-stride): a background launch that should trickle under
-// MFMA-bound work instead of flooding the CUs
+// MFMA-bound work instead of flooding the CUs; zero / nzero: floats the launch also clears (side job)
 hipError_t resize_bilinear_launch(const float* in, int B, int Hin, int Win, int C, float* out,
                                   int Hout, int Wout, int out_cstride, int out_coff,
-                                  hipStream_t st, int max_blocks = 0);
+                                  hipStream_t st, int max_blocks = 0, float* zero = nullptr, int nzero = 0);
 hipError_t maxpool2x2_launch(const float* in, int B, int H, int W, int C, float* out,
                              hipStream_t st);
 hipError_t project_launch(const float* pts, const float* trans_mat, int B, int N, float* xy,

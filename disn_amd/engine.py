@@ -45,7 +45,9 @@ class DeviceWeights:
             v.conv_b[i] = dev(store[nm + "/biases"]).data_ptr()
         for i, nm in enumerate(("fc6", "fc7", "fc8")):
             w = store["vgg_16/%s/weights" % nm]
-            v.fc_w[i] = dev(w.reshape(-1, w.shape[3])).data_ptr()   # [K][N], K=(h,w,c) = NHWC flatten
+            wkn = w.reshape(-1, w.shape[3])
+            v.fc_w[i] = dev(wkn).data_ptr()   # [K][N], K=(h,w,c) = NHWC flatten
+            v.fc_w_t[i] = dev(wkn.T).data_ptr()   # [N][K]: one launch per layer, no split-K partials (gemv_rows_kernel)
             v.fc_b[i] = dev(store["vgg_16/%s/biases" % nm]).data_ptr()
         v.num_classes = store.num_classes
         self.vgg = v
@@ -81,6 +83,7 @@ class DeviceWeights:
         w4g = W(g, "fold2/conv1")                          # [512+1024, 512]: rows 0-511 point, rest global
         m.g_w4_point = pk(w4g[:512], "g_x4_point")
         m.g_w4_global = dev(w4g[512:]).data_ptr()          # folded into a per-image bias by the library
+        m.g_w4_global_t = dev(w4g[512:].T).data_ptr()      # [512][1024]: that fold as one launch
         w4l = W(l, "fold2/conv1")                          # [512+1472, 512]
         m.l_w4 = pk(w4l, "l_x4")
         m.l_w4_point = pk(w4l[:512], "l_x4_point")         # the two halves on their own: the folded

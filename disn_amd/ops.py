@@ -169,6 +169,17 @@ def fc(x: torch.Tensor, w_kn: torch.Tensor, bias: torch.Tensor, relu: bool) -> t
     return out
 
 
+def fc_t(x: torch.Tensor, wt_nk: torch.Tensor, bias: torch.Tensor, relu: bool) -> torch.Tensor:
+    """disn_fc_t: act(x @ wt_nk.T + bias) from the transposed matrix [N][K], one launch"""
+    x, wt = _chk(x, "x"), _chk(wt_nk, "wt_nk")
+    B, K = x.shape
+    N = wt.shape[0]
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    check("disn_fc_t", lib().disn_fc_t(x.data_ptr(), B, K, wt.data_ptr(), bias.data_ptr(), N, int(relu),
+                                       out.data_ptr(), _stream()))
+    return out
+
+
 def dense(a1: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, n_out: int, relu: bool = True,
           a2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act([a1 | a2] @ W + b): the tf_util.conv2d [1,1] primitive on [M,K] rows."""

@@ -115,6 +115,9 @@ typedef struct disn_vgg_weights {
    * as is.  With it a layer runs the single-image kernels of conv_h2.hip (two-term f16 split; conv1_1: direct fp32
    * FMA) -- takes precedence over conv_w_x3; all 13 entries must be set for the activation-scale chain. */
   const void* conv_w_h2[13];
+  /* optional (NULL = not used): fc6, fc7, fc8 TRANSPOSED, [N][K] row-major (one contiguous K-long row per output).
+   * With it a layer is one launch (a wave per output row pair, no split-K partials, no reduce pass). */
+  const float* fc_w_t[3];
 } disn_vgg_weights_t;
 
 size_t disn_vgg16_workspace_bytes(int B);
@@ -146,6 +149,10 @@ int disn_maxpool2x2(const float* in, int B, int H, int W, int C, float* out, voi
 size_t disn_fc_workspace_bytes(int B, int K, int N);
 int disn_fc(const float* x, int B, int K, const float* w_kn, const float* bias, int N, int relu,
             float* out, void* ws, size_t ws_bytes, void* stream);
+/* the same layer from the transposed matrix wt_nk [N][K] (K % 4 == 0): one launch, no workspace -- what
+ * disn_vgg16_forward / disn_encode* run for a layer whose fc_w_t entry is set */
+int disn_fc_t(const float* x, int B, int K, const float* wt_nk, const float* bias, int N, int relu, float* out,
+              void* stream);
 
 /* Row G3: tf_util.conv2d with a [1,1] kernel (utils/tf_util.py:119-184) == per-row
  * out[m][n] = act(sum_k A[m][k] W[k][n] + bias[n]) where A = [a1 (k1 cols) | a2 (k2 cols)]
@@ -212,6 +219,8 @@ typedef struct disn_mlp_weights {
   const void *l_x4_point, *l_x4_feat;
   /* optional, for the *_fused entry points: disn_mlp_fused_pack images of the two streams */
   const void *g_fused, *l_fused;
+  /* optional: g_w4_global transposed, [512][1024] row-major -- the per-image bias fold as one launch (see fc_w_t) */
+  const float* g_w4_global_t;
 } disn_mlp_weights_t;
 
 /* scratch for one launch over B images x N points (N per image) */

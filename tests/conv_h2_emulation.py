@@ -9,8 +9,12 @@ float64 and accumulated in float64 (the MFMA accumulates in fp32: its rounding i
 """
 import numpy as np
 
-KPIX = 272
 TILINGS = {1: (1, 1, 16, 14), 2: (2, 1, 32, 28), 3: (2, 2, 32, 28), 4: (4, 2, 16, 16)}   # MB, NW, SEG, TW
+
+
+def k_waves(tiling, cin):
+    """k-waves per n-block: eight (128-channel chunks) for the one-n-block tilings when Cin allows, else four"""
+    return 8 if tiling in (1, 2) and cin % 128 == 0 else 4
 
 
 def pow2_scale(amax, target):
@@ -42,15 +46,14 @@ def pack(w_hwio):
     _, _, cin, cout = w_hwio.shape
     w = w_hwio.reshape(9 * cin, cout).astype(np.float32)
     s = pow2_scale(np.abs(w).max(), 13)
-    S = 9 * (cin // 64)
-    frags = (cout // 32) * 4 * S
+    KB = cin // 16
+    frags = (cout // 32) * KB * 9
     img = np.zeros((frags, 2, 64, 8), np.float16)
     for f in range(frags):
-        st, wk, nb = f % S, (f // S) & 3, f // (S * 4)
-        c, t = divmod(st, 9)
+        t, kb, nb = f % 9, (f // 9) % KB, f // (9 * KB)
         for lane in range(64):
             j, g = lane & 31, lane >> 5
-            ci = 64 * c + 16 * wk + 8 * g + np.arange(8)
+            ci = 16 * kb + 8 * g + np.arange(8)
             v = w[t * cin + ci, 32 * nb + j] * s
             img[f, 0, lane], img[f, 1, lane] = split(v.astype(np.float32))
     return img, s
@@ -63,7 +66,9 @@ def conv_tile(x, img, s_w, bias, tiling, tile, relu=True, exact_operands=False):
     RPS = 32 // SEG
     TH, RP = MB * RPS, TW + 2
     HP = (TH + 2) * RP
-    NC, S = Cin // 64, 9 * (Cin // 64)
+    WK = k_waves(tiling, Cin)
+    CK, KB = 16 * WK, Cin // 16
+    NC = Cin // CK
     tyi, txi, nt = tile
     y0, x0 = tyi * TH, txi * TW
     sa = pow2_scale(np.abs(x).max(), 14)
@@ -71,24 +76,24 @@ def conv_tile(x, img, s_w, bias, tiling, tile, relu=True, exact_operands=False):
     out, pooled, vmax = {}, {}, 0.0
     for wn in range(NW):
         n0 = (nt * NW + wn) * 32
-        acc = np.zeros((4, MB, 16, 64), np.float64)          # [wk][mb][r][lane]
+        acc = np.zeros((WK, MB, 16, 64), np.float64)         # [wk][mb][r][lane]
         for c in range(NC):
             # halo in "LDS": pixel hp -> (h[64], l[64]); beyond the halo (rows never stored) zeros
-            lds_h = np.zeros((HP + 40, 64), np.float64)
-            lds_l = np.zeros((HP + 40, 64), np.float64)
+            lds_h = np.zeros((HP + 40, CK), np.float64)
+            lds_l = np.zeros((HP + 40, CK), np.float64)
             for hp in range(HP):
                 hy, hx = divmod(hp, RP)
                 yy, xx = y0 - 1 + hy, x0 - 1 + hx
                 if 0 <= yy < H and 0 <= xx < W:
-                    v = (x[yy, xx, 64 * c:64 * c + 64] * sa).astype(np.float32)
+                    v = (x[yy, xx, CK * c:CK * c + CK] * sa).astype(np.float32)
                     if exact_operands:
                         lds_h[hp] = v
                     else:
                         h, l = split(v)
                         lds_h[hp], lds_l[hp] = h, l
-            for wk in range(4):
+            for wk in range(WK):
                 for t in range(9):
-                    f = ((n0 >> 5) * 4 + wk) * S + c * 9 + t
+                    f = ((n0 >> 5) * KB + c * WK + wk) * 9 + t
                     bh, bl = img[f, 0].astype(np.float64), img[f, 1].astype(np.float64)   # [lane][8]
                     # B[k][j] of the 16 x 32 block: lane (j, g) holds k = 8g + e
                     Bh = np.zeros((16, 32)); Bl = np.zeros((16, 32))
@@ -112,7 +117,10 @@ def conv_tile(x, img, s_w, bias, tiling, tile, relu=True, exact_operands=False):
                             j, g = lane & 31, lane >> 5
                             for r in range(16):
                                 acc[wk, mb, r, lane] += Dm[(r & 3) + 8 * (r >> 2) + 4 * g, j]
-        tot = (acc[0] + acc[2]) + (acc[1] + acc[3])
+        if WK == 8:
+            tot = ((acc[0] + acc[4]) + (acc[2] + acc[6])) + ((acc[1] + acc[5]) + (acc[3] + acc[7]))
+        else:
+            tot = (acc[0] + acc[2]) + (acc[1] + acc[3])
         val = np.zeros((MB, 16, 64))
         for lane in range(64):
             j, g = lane & 31, lane >> 5
@@ -183,19 +191,20 @@ def conv(x, w_hwio, bias, tiling, relu=True, exact_operands=False):
     return out, pooled, vmax
 
 
-def lds_read_conflicts(tiling):
+def lds_read_conflicts(tiling, wk_count=4):
     """extra LDS cycles of one A-fragment ds_read_b128 (MI355X_MICROARCH.md, LDS: four 16-lane groups per
     instruction, a 16-byte access covers four of the 64 banks): 0 = conflict-free, for every tap and block"""
     MB, NW, SEG, TW = TILINGS[tiling]
     RPS, RP = 32 // SEG, TW + 2
+    KPIX = 64 * wk_count + 16
     groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
               [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
     groups = groups + [[l + 32 for l in grp] for grp in groups]
     worst = 0
-    for wk in range(4):
+    for wk in range(wk_count):
         for mb in range(MB):
             for t in range(9):
-                for plane in (0, 128):
+                for plane in (0, 32 * wk_count):
                     for grp in groups:
                         slots = {}
                         for lane in grp:

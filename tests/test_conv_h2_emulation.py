@@ -43,9 +43,11 @@ def test_every_tiling_reproduces_the_convolution(tiling, H, W):
     assert abs(vmax - scale) <= 3e-7 * scale
 
 
-def test_two_chunks_and_k_wave_order():
-    x, w, b = case(2, 14, 128, 64, seed=7)
-    out, _, _ = E.conv(x, w, b, 1)
+@pytest.mark.parametrize("tiling,cin", [(1, 128), (1, 256), (3, 128), (2, 128)])
+def test_several_chunks_and_both_k_wave_counts(tiling, cin):
+    """Cin = 128: one 128-channel chunk of eight k-waves (tilings 1, 2) or two 64-channel chunks of four"""
+    x, w, b = case(2, 14 if tiling == 1 else 28, cin, 64, seed=7)
+    out, _, _ = E.conv(x, w, b, tiling)
     ref = ref_conv(x, w, b)
     assert np.abs(out - ref).max() <= 3e-7 * np.abs(ref).max()
 
@@ -58,9 +60,9 @@ def test_exact_operands_give_the_exact_convolution():
     assert np.abs(out - ref).max() <= 2e-7 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("tiling", [1, 2, 3, 4])
-def test_a_fragment_reads_are_bank_conflict_free(tiling):
-    assert E.lds_read_conflicts(tiling) == 0
+@pytest.mark.parametrize("tiling,wk", [(1, 4), (2, 4), (3, 4), (4, 4), (1, 8), (2, 8)])
+def test_a_fragment_reads_are_bank_conflict_free(tiling, wk):
+    assert E.lds_read_conflicts(tiling, wk) == 0
 
 
 def test_pow2_scale_and_sigma():

@@ -210,6 +210,23 @@ def test_fc_vs_oracle(ops, B, K, N, relu):
     report_close("fc %s" % ((B, K, N),), got, ref, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,K,N,relu", [(1, 25088, 4096, True), (3, 4096, 1024, False), (8, 1024, 512, False),
+                                        (5, 4096, 4096, True), (2, 100, 7, False)])
+def test_fc_transposed_vs_oracle(ops, B, K, N, relu):
+    """the one-launch form (disn_fc_t: a wave per output row pair, weights [N][K]) of the same layer"""
+    rng = np.random.default_rng(K + N + 1)
+    x = np.maximum(rng.standard_normal((B, K)), 0).astype(np.float32)
+    w = (rng.standard_normal((K, N)) * np.sqrt(2.0 / K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = x.astype(np.float64) @ w.astype(np.float64) + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    wt = dev(np.ascontiguousarray(w.T))
+    got = host(ops.fc_t(dev(x), wt, dev(b), relu))
+    report_close("fc_t %s" % ((B, K, N),), got, ref, atol=1e-5, rtol=1e-5)
+    assert np.array_equal(got, host(ops.fc_t(dev(x), wt, dev(b), relu)))       # fixed summation order
+
+
 # ---------------------------------------------------------------- row G ------------------------
 @pytest.mark.parametrize("M,k1,k2,N", [(2048, 64, 0, 256), (1000, 256, 0, 512), (777, 512, 1472, 512),
                                        (4096, 512, 0, 256), (70000, 512, 1472, 512)])

@@ -266,15 +266,18 @@ def test_encode_query_equals_encode_plus_query(B, N):
     report_close("encode_query vs oracle", sdf_a.cpu().numpy(), ref["pred_sdf"][..., 0], PRED_ATOL)
 
 
-def test_vgg_stack_equals_standalone_layer_chain():
-    """The conv stack inside disn_encode (split-K reduce that also emits the 2x2 max pool for conv2_2,
-    conv3_3, conv4_3, conv5_3; a separate pool after conv1_2) == the same layers one by one through
-    disn_conv3x3_x3 + disn_maxpool2x2, bit for bit at every tap."""
+@pytest.mark.parametrize("conv_h2", [True, False])
+def test_vgg_stack_equals_standalone_layer_chain(conv_h2):
+    """The conv stack inside disn_encode == the same layers one by one through the unit entry points, bit for
+    bit at every tap.  conv_h2 (engine default): disn_conv1_1 + disn_conv3x3_h2 with its fused pool (inside the
+    encoder each layer's scale comes from the producer's atomic maximum, standalone from a pass over the
+    input: the same number).  Otherwise: disn_conv3x3_x3 (split-K reduce that also emits the 2x2 max pool for
+    conv2_2 .. conv5_3) + disn_maxpool2x2."""
     from disn_amd import ops
     from disn_amd.engine import SdfEngine
     from disn_amd.weights import WeightStore, VGG_CONV_NAMES
     store = WeightStore.random_init(3, mode="he")
-    eng = SdfEngine(store)
+    eng = SdfEngine(store, conv_h2=conv_h2)
     rng = np.random.default_rng(5)
     for B in (1, 2):
         imgs = rng.random((B, 137, 137, 3), dtype=np.float32)
@@ -287,14 +290,21 @@ def test_vgg_stack_equals_standalone_layer_chain():
             kh, kw, ci, co = w.shape
             wd = torch.from_numpy(np.ascontiguousarray(w.reshape(kh * kw * ci, co))).cuda()
             bias = torch.from_numpy(store[nm + "/biases"]).cuda()
-            if ci == 3:
+            pooled = None
+            if conv_h2:
+                if ci == 3:
+                    x = ops.conv1_1(x, wd, bias, True)
+                else:
+                    x, pooled, _ = ops.conv3x3_h2(x, ops.pack_conv_h2(wd), bias, co, True, pool=i in pool_after,
+                                                  want_amax=True)
+            elif ci == 3:
                 x = ops.conv3x3(x, ops.pack_kn(wd), bias, co, True)
             else:
                 x = ops.conv3x3_x3(x, ops.pack_kn_x3(wd), bias, co, True)
             if i in pool_after:
                 assert torch.equal(x, enc.taps[tap]), "tap %d (%s) differs, B=%d" % (tap, nm, B)
                 tap += 1
-                x = ops.maxpool2x2(x)
+                x = pooled if pooled is not None else ops.maxpool2x2(x)
         assert tap == 5
 
 
