@@ -86,6 +86,7 @@ SIGNATURES = {
     "disn_resize_bilinear": (I, [P, I, I, I, I, P, I, I, I, I, P]),
     "disn_vgg16_workspace_bytes": (Z, [I]),
     "disn_vgg16_forward": (I, [C.POINTER(VggWeights), P, I, P, C.POINTER(C.c_void_p * 5), P, P, Z, P]),
+    "disn_vgg16_conv_stack": (I, [C.POINTER(VggWeights), P, I, P, C.POINTER(C.c_void_p * 5), P, P, Z, P]),
     "disn_conv3x3_workspace_bytes": (Z, [I, I, I, I, I]),
     "disn_conv3x3": (I, [P, I, I, I, I, P, P, I, I, P, P, Z, P]),
     "disn_conv3x3_planned_workspace_bytes": (Z, [I, I, I, I, I, I, I, I]),

@@ -196,15 +196,23 @@ int dense_layer(const float* a1, int lda1, int k1, const float* a2, int lda2, in
 //   phase 1 -- needs the feature map: local fold2/conv1 on [point512 | feat1472], fold2/conv2 (:180-184)
 //   phase 2 -- needs the embedding: global fold2/conv1 with the per-image folded bias, fold2/conv2,
 //              both fold2/conv5 and the sum  (:78-88, :186; models/model_normalization.py:204)
+// fold1/conv2, conv3 of one stream (after pt_embed); `gws`: the GEMM scratch this stream may use
+int mlp_fold1_local(const disn_mlp_weights_t* w, int n, const MlpWs& s, float* gws, hipStream_t st) {
+  int rc;
+  if ((rc = dense_layer(s.e1l, 64, 64, nullptr, 0, 64, n, w->l_w2, w->l_b2, 256, s.h256, gws, s.gemm_ws_bytes, st, w->l_x2))) return rc;
+  return dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->l_w3, w->l_b3, 512, s.h512a, gws, s.gemm_ws_bytes, st, w->l_x3);
+}
+int mlp_fold1_global(const disn_mlp_weights_t* w, int n, const MlpWs& s, float* gws, hipStream_t st) {
+  int rc;
+  if ((rc = dense_layer(s.e1g, 64, 64, nullptr, 0, 64, n, w->g_w2, w->g_b2, 256, s.g256, gws, s.gemm_ws_bytes, st, w->g_x2))) return rc;
+  return dense_layer(s.g256, 256, 256, nullptr, 0, 256, n, w->g_w3, w->g_b3, 512, s.g512, gws, s.gemm_ws_bytes, st, w->g_x3);
+}
 int mlp_phase0(const disn_mlp_weights_t* w, const float* pts_rot, int n, const MlpWs& s,
                hipStream_t st) {
   int rc;
   DISN_TRY(pt_embed_launch(pts_rot, n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g, s.e1l, st));
-  if ((rc = dense_layer(s.e1l, 64, 64, nullptr, 0, 64, n, w->l_w2, w->l_b2, 256, s.h256, s.gemm_ws, s.gemm_ws_bytes, st, w->l_x2))) return rc;
-  if ((rc = dense_layer(s.h256, 256, 256, nullptr, 0, 256, n, w->l_w3, w->l_b3, 512, s.h512a, s.gemm_ws, s.gemm_ws_bytes, st, w->l_x3))) return rc;
-  if ((rc = dense_layer(s.e1g, 64, 64, nullptr, 0, 64, n, w->g_w2, w->g_b2, 256, s.g256, s.gemm_ws, s.gemm_ws_bytes, st, w->g_x2))) return rc;
-  if ((rc = dense_layer(s.g256, 256, 256, nullptr, 0, 256, n, w->g_w3, w->g_b3, 512, s.g512, s.gemm_ws, s.gemm_ws_bytes, st, w->g_x3))) return rc;
-  return 0;
+  if ((rc = mlp_fold1_local(w, n, s, s.gemm_ws, st))) return rc;
+  return mlp_fold1_global(w, n, s, s.gemm_ws, st);
 }
 
 int mlp_phase1(const disn_mlp_weights_t* w, int n, const float* feat, const MlpWs& s,
@@ -236,10 +244,10 @@ int mlp_phase2(const disn_mlp_weights_t* w, int B, int N, const float* gbias, fl
 // global fold2/conv1 in two halves.  g4_pre: the 512-deep product on the point features, no bias, no
 // ReLU -- needs only phase 0.  phase2_split: + the per-image folded bias, ReLU (the same fp32 add the
 // fused epilogue does), fold2/conv2 on s.gemm_ws2, then -- behind `joined` -- both conv5 and the sum.
-int mlp_g4_pre(const disn_mlp_weights_t* w, int n, const MlpWs& s, hipStream_t st) {
-  DISN_TRY(hipMemsetAsync(s.zero512, 0, 512 * sizeof(float), st));  // on this stream: no cross-stream order
+int mlp_g4_pre(const disn_mlp_weights_t* w, int n, const MlpWs& s, float* gws, hipStream_t st, bool zeroed = false) {
+  if (!zeroed) DISN_TRY(hipMemsetAsync(s.zero512, 0, 512 * sizeof(float), st));  // on this stream: no cross-stream order
   return dense_layer(s.g512, 512, 512, nullptr, 0, 512, n, w->g_w4_point, s.zero512, 512, s.g4pre,
-                     s.gemm_ws, s.gemm_ws_bytes, st, w->g_x4_point, 0);
+                     gws, s.gemm_ws_bytes, st, w->g_x4_point, 0);
 }
 
 int mlp_phase2_split(const disn_mlp_weights_t* w, int B, int N, const float* gbias, float* sdf,
@@ -477,22 +485,26 @@ bool vgg_weights_ok(const disn_vgg_weights_t* w) {
 }
 
 // rows A, B (+E when featmap != nullptr): resize, conv stack, pools, all on `st`.  Returns pool5.
+// layers [i0, i1) of the stack; i0 == 0 starts with the resize; *xio carries the current activation between calls
 int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* resized,
-                 float* const taps[5], float* featmap, const VggWs& s, const float** pool5,
-                 hipStream_t st) {
+                 float* const taps[5], float* featmap, const VggWs& s, const float** xio,
+                 hipStream_t st, int i0 = 0, int i1 = 13) {
   // the single-image kernels (conv_h2.hip) when every layer has its image: each layer's epilogue leaves the
   // maximum of its output in the slots the next layer scales its f16 split by (cleared by the resize launch)
   bool h2 = x3_enabled();
   for (int i = 0; i < 13; ++i) h2 = h2 && w->conv_w_h2[i] != nullptr;
-  DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, resized, DISN_VGG_SIZE,
-                                  DISN_VGG_SIZE, 3, 0, st, 0, h2 ? s.amax : nullptr, h2 ? 14 * 64 : 0));
-  const float* x = resized;
-  bool toggle = false;
+  if (i0 == 0)
+    DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, resized, DISN_VGG_SIZE,
+                                    DISN_VGG_SIZE, 3, 0, st, 0, h2 ? s.amax : nullptr, h2 ? 14 * 64 : 0));
+  const float* x = i0 == 0 ? resized : *xio;
+  bool toggle = false;  // (a pool precedes every layer that uses the bufA / bufB toggle first: restarts agree)
   const size_t gws_cap = (size_t)((char*)s.fc_ws - (char*)s.gemm_ws);
-  for (int i = 0; i < 13; ++i) {
+  for (int i = 0; i < i1; ++i) {
     const VggLayer& L = kVgg[i];
     float* out = L.tap >= 0 ? taps[L.tap] : (L.hw >= 112 ? s.bufA : (toggle ? s.bufB : s.bufA));
     if (L.tap < 0 && L.hw < 112) toggle = !toggle;
+    if (kPoolAfter[i]) toggle = false;
+    if (i < i0) continue;  // replay of the buffer choice only
     // a layer the pool follows: when its split-K reduce runs anyway, that pass also emits the pool
     bool pooled = false;
     int rc = 0;
@@ -516,10 +528,9 @@ int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* re
     if (kPoolAfter[i]) {
       if (!pooled) DISN_TRY(maxpool2x2_launch(x, B, L.hw, L.hw, L.cout, s.bufP, st));
       x = s.bufP;
-      toggle = false;
     }
   }
-  *pool5 = x;
+  *xio = x;
   return 0;
 }
 
@@ -535,7 +546,9 @@ int fc_layer(const float* x, int B, int K, const float* w_kn, const float* wt_nk
 int vgg_head(const disn_vgg_weights_t* w, const float* pool5, int B, float* embedding,
              const VggWs& s, hipStream_t st) {
   int rc;
-  if ((rc = fc_layer(pool5, B, 25088, w->fc_w[0], w->fc_w_t[0], w->fc_b[0], 4096, 1, s.fc6, s.fc_ws, st))) return rc;
+  // fc6 (411 MB) stays on the split-K stream kernel: 6.2 TB/s there against 2.8 for the row form (r02i); the
+  // 67 / 17 / 2 MB layers are launch-latency bound and take the one-launch row form
+  if ((rc = fc_layer(pool5, B, 25088, w->fc_w[0], nullptr, w->fc_b[0], 4096, 1, s.fc6, s.fc_ws, st))) return rc;
   if ((rc = fc_layer(s.fc6, B, 4096, w->fc_w[1], w->fc_w_t[1], w->fc_b[1], 4096, 1, s.fc7, s.fc_ws, st))) return rc;
   return fc_layer(s.fc7, B, 4096, w->fc_w[2], w->fc_w_t[2], w->fc_b[2], w->num_classes, 0, embedding, s.fc_ws, st);
 }
@@ -605,6 +618,21 @@ int disn_vgg16_forward(const disn_vgg_weights_t* w, const float* img, int B, flo
   return vgg_head(w, pool5, B, embedding, s, st);
 }
 
+int disn_vgg16_conv_stack(const disn_vgg_weights_t* w, const float* img, int B, float* resized224,
+                          float* const taps[5], float* pool5, void* ws, size_t ws_bytes, void* stream) {
+  if (!vgg_weights_ok(w) || !img || !taps || !ws || B <= 0) return DISN_E_ARG;
+  for (int i = 0; i < 5; ++i)
+    if (!taps[i]) return DISN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const VggWs s = vgg_layout(ws, B, w->num_classes > 0 ? w->num_classes : DISN_EMBED_DIM);
+  if (s.total > ws_bytes) return DISN_E_WS;
+  const float* p5 = nullptr;
+  const int rc = vgg_features(w, img, B, resized224 ? resized224 : s.resized, taps, nullptr, s, &p5, st);
+  if (rc) return rc;
+  if (pool5) DISN_TRY(hipMemcpyAsync(pool5, p5, (size_t)B * 7 * 7 * 512 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
 size_t disn_encode_workspace_bytes(int B) { return disn_vgg16_workspace_bytes(B); }
 
 int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, int B,
@@ -653,24 +681,33 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   const bool two = two_streams();
   hipStream_t ms = two ? ctx->aux : st;
   int rc;
-  DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (also orders aux behind the caller's inputs)
-  DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
-  // The convolution stack is enqueued FIRST: when the host, not the GPU, is the pacer (a step is ~45 launches)
-  // the caller's stream must not sit idle while the auxiliary stream's small launches are being issued.  They
-  // are enqueued next and still run under the convolutions (the GPU is tens of microseconds behind the host).
+  // Schedule (r02i / r02j traces).  The convolution kernels from conv2 on are ONE round of 112..224 workgroups that
+  // each fill a CU: a point-MLP GEMM running beside them takes CUs away and doubles a layer (18 -> 34 us), so
+  // nothing runs beside conv2_1 .. conv5_3.  `st`: resize, the convolutions, the HBM-bound fc head, the short
+  // global tail.  ctx->aux: from the fork, the point embedding, the GLOBAL stream's fold1 and the point half of its
+  // fold2/conv1 -- ~45 us of small launches beside resize / conv1_1 / conv1_2 (VALU work and a two-round kernel,
+  // measured unaffected) -- then, behind conv5_3, the LOCAL stream's fold1, the gather and fold2 under the fc head.
   const float* pool5 = nullptr;
-  rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5,
-                    st);
-  if (rc) return rc;
   if (two) {
-    DISN_TRY(hipEventRecord(ctx->ev[7], st));
-    if ((rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, ctx->aux))) return rc;
-    if ((rc = mlp_g4_pre(mw, B * N, e.q.mlp, ctx->aux))) return rc;
+    DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (orders aux behind the caller's inputs)
+    DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
+    // host order: the caller's stream gets resize, conv1_1, conv1_2 first (it must never wait for the host), then
+    // the auxiliary stream its launches, then the rest of the stack
+    rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 0, 2);
+    if (rc) return rc;
+    DISN_TRY(pt_embed_launch(pts_rot, B * N, mw->g_w1, mw->g_b1, mw->l_w1, mw->l_b1, e.q.mlp.e1g, e.q.mlp.e1l, ctx->aux));
+    if ((rc = mlp_fold1_global(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws2, ctx->aux))) return rc;
+    if ((rc = mlp_g4_pre(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws2, ctx->aux))) return rc;
     DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
+    rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 2, 13);
+    if (rc) return rc;
+    DISN_TRY(hipEventRecord(ctx->ev[7], st));
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
-    // g4_pre finishes long before conv5_3: its wait sits next to the ev[7] record, where `st` drains anyway
-    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));
+    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));  // next to the ev[7] record, where `st` drains anyway
+    if ((rc = mlp_fold1_local(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws, ctx->aux))) return rc;
   } else {
+    rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st);
+    if (rc) return rc;
     if ((rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, st))) return rc;
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
@@ -1080,6 +1117,7 @@ namespace disn {
 namespace tune {
 int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0;
 int gemm_force[3] = {0, 0, 0};
+int gemv_wgs = 0;
 long long* ch2_stamps = nullptr;
 }
 }  // namespace disn
@@ -1091,9 +1129,10 @@ extern "C" int disn_tuning_set_ptr(int key, void* p) {
 // tuning builds only (build.py --tuning -> libdisn_amd_tuning.so): 0 x3, 1 overlap, 2 bf_splits, 3 skip_pack,
 // 4 fused_safe
 extern "C" int disn_tuning_set(int key, int value) {
-  int* k[5] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
-               &disn::tune::fused_safe};
-  if (key < 0 || key > 4) return DISN_E_ARG;
+  int* k[9] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
+               &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
+               &disn::tune::gemm_force[2], &disn::tune::gemv_wgs};
+  if (key < 0 || key > 8) return DISN_E_ARG;
   *k[key] = value;
   return 0;
 }

@@ -7,6 +7,7 @@
 // interleaved rows, K is split across blockIdx.y; partials are combined by
 // splitk_reduce_kernel (deterministic, no atomics).  x[b][k] is wave-uniform -> scalar loads.
 #include "kernels.hpp"
+#include "tuning.hpp"
 
 namespace disn {
 
@@ -137,7 +138,8 @@ hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, co
 
 int gemv_splits(int K, int N) {
   const int colblocks = N / 256;
-  int s = (2048 + colblocks - 1) / colblocks;
+  const int wgs = tune::gemv_wgs > 0 ? tune::gemv_wgs : 2048;
+  int s = (wgs + colblocks - 1) / colblocks;
   const int smax = K / 32 > 0 ? K / 32 : 1;
   if (s > smax) s = smax;
   if (s < 1) s = 1;

@@ -219,6 +219,25 @@ def vgg16_forward(w: VggWeights, img: torch.Tensor, ws: Optional[torch.Tensor] =
     return resized, taps, emb
 
 
+class ConvStackRun:
+    """disn_vgg16_conv_stack with every buffer allocated once (bench.py times repeated calls of .run())"""
+
+    def __init__(self, w: VggWeights, img: torch.Tensor, want_pool5: bool = True):
+        self.w, self.img = w, _chk(img, "img")
+        B, dev = img.shape[0], img.device
+        self.B = B
+        self.resized = torch.empty((B, 224, 224, 3), dtype=torch.float32, device=dev)
+        self.taps = [torch.empty((B, hw, hw, ch), dtype=torch.float32, device=dev) for hw, ch in TAP_SHAPES]
+        self.pool5 = torch.empty((B, 7, 7, 512), dtype=torch.float32, device=dev) if want_pool5 else None
+        self.ws = _ws(lib().disn_vgg16_workspace_bytes(B), dev)
+        self.tp = (C.c_void_p * 5)(*[t.data_ptr() for t in self.taps])
+
+    def run(self) -> None:
+        check("disn_vgg16_conv_stack", lib().disn_vgg16_conv_stack(
+            C.byref(self.w), self.img.data_ptr(), self.B, self.resized.data_ptr(), C.byref(self.tp),
+            self.pool5.data_ptr() if self.pool5 is not None else None, self.ws.data_ptr(), self.ws.numel(), _stream()))
+
+
 def ctx_create() -> int:
     """Concurrency context (aux HIP stream + events) on the current device."""
     h = C.c_void_p()

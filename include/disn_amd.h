@@ -129,6 +129,11 @@ size_t disn_vgg16_workspace_bytes(int B);
 int disn_vgg16_forward(const disn_vgg_weights_t* w, const float* img, int B, float* resized224,
                        float* const taps[5], float* embedding, void* ws, size_t ws_bytes,
                        void* stream);
+/* Rows A + B only: the resize and the 13 convolutions (+ pools) of that forward, no fc head -- the launches
+ * bench.py's `roofline` times.  pool5 [B,7,7,512] optional (NULL: not copied out).  Workspace as
+ * disn_vgg16_forward. */
+int disn_vgg16_conv_stack(const disn_vgg_weights_t* w, const float* img, int B, float* resized224,
+                          float* const taps[5], float* pool5, void* ws, size_t ws_bytes, void* stream);
 
 /* Single layers of the above (unit-test / composition surface).
  * disn_conv3x3: SAME 3x3 stride-1 conv + bias + optional ReLU, NHWC, Cin in {3} or a
