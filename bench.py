@@ -21,9 +21,10 @@ slices (RCCL over xGMI), marching cubes of image b on rank b % N.  N = 1: one im
 N > 1: eight images (config 4).  value = grid points evaluated per second, whole job.
 
 Besides the contract line's fields the JSON carries
-  roofline      -- the dominant kernel family (implicit-GEMM 3x3 conv, fp32 MFMA): algorithmic
-                   FLOP of the 13 conv launches of one step / their summed duration measured with
-                   events on the launch stream, against the 157.3 TFLOP/s fp32-MFMA peak;
+  roofline      -- the dominant kernel family (the 13 convolutions of one step: conv_h2.hip, two-term f16
+                   split on the f16 MFMA pipes): their algorithmic FLOP / the duration of the launch chain
+                   measured with events on the launch stream, against the 157.3 TFLOP/s fp32-MFMA peak;
+  single_stream -- one step at a time (the main line keeps --in-flight independent steps on the GPU);
   roofline_gather -- the gathers that are actually on the timed paths: project_gather_taps_kernel (the
                    step), gather_fold_kernel (layer-by-layer dense grid), and gather_kernel from
                    materialised maps incl. a 3-image case that exceeds the 256 MB Infinity Cache;
@@ -265,6 +266,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / grid / cpu legs")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="--workload query: independent steps in flight on this GPU (disn_amd.engine.StepPipeline: one "
+                         "HIP stream + host thread per step context); 1 = one step at a time")
     ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--workload", choices=("query", "grid", "train"), default="query",
                     help="query: BASELINE.json metric (default); grid: configs 3/4 (dense grid + gather + marching "
@@ -332,31 +336,35 @@ def main():
             dist.destroy_process_group()
         return
 
+    from disn_amd.engine import StepPipeline
     store = WeightStore.random_init(0, mode="xavier")          # "random-init weights" (create_sdf.py:184-192)
-    eng = SdfEngine(store, dev)
+    S = max(1, args.in_flight)
+    pipe = StepPipeline(store, dev, in_flight=S)
+    eng = pipe.engines[0]
     rng = np.random.default_rng(1000 + rank)
     img = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32)).to(dev)
     pts = torch.from_numpy((rng.random((1, N_POINTS, 3), dtype=np.float32) * 2 - 1).astype(np.float32)).to(dev)
     tm = torch.tensor([DEMO_TM], dtype=torch.float32, device=dev)
 
-    def step():
-        # rows A..H, every step, through the single overlapped entry (disn_encode_query)
-        return eng.encode_query(img, pts, tm)[1]
+    def run_steps(k):
+        # rows A..H, every step, through the single overlapped entry (disn_encode_query); S steps in flight:
+        # step j runs on engine context j % S (own HIP stream, own host thread); nothing shared between steps
+        return pipe.run([(img, pts, tm)] * k)
 
-    for _ in range(args.warmup):
-        out = step()
+    run_steps(max(args.warmup, S))
     torch.cuda.synchronize()
     if launched:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    outs = run_steps(args.steps)
     torch.cuda.synchronize()
     if launched:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    out = outs[-1]
+    assert all(torch.equal(o, outs[0]) for o in outs[1:]), "steps on different contexts disagree"
     if launched:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -371,6 +379,11 @@ def main():
         "config": {"workload": "BASELINE config 2: VGG-16 encode + 2048 random query points, img_feat_twostream, "
                                "fp32, random-init (xavier) weights, nothing cached between steps",
                    "images_per_step_per_gpu": 1, "points_per_step_per_gpu": N_POINTS,
+                   "steps_in_flight": S,
+                   "steps_in_flight_note": "independent steps (own image, own workspaces, own HIP stream and host "
+                                           "thread) overlap on the GPU and fill the gaps between each other's ~35 "
+                                           "dependent launches; every step does all of its work; --in-flight 1 = "
+                                           "one step at a time (see single_stream)",
                    "parallelism": "replicas x%d (no data-path collective)%s" % (
                        world, "; ranks SHARE GPUs (plumbing run)" if shared_gpu else "")},
     }
@@ -378,30 +391,19 @@ def main():
     if rank == 0:
         print("[bench] main line: %.4g points/s, %.4f ms/step" % (value, line["ms_per_step"]), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_extras:   # roofline / cpu legs: N=1 only (bench contract)
-        # ---- roofline of the dominant kernel family: the 13 implicit-GEMM conv launches ----------
-        # Each layer is timed through the kernel the step runs for it at B = 1: the three-term bf16
-        # split ("x3": fp32-accurate, bf16 MFMA pipes) wherever api.hip selects it, else the
-        # f32-input MFMA kernel (conv1_1, K = 27).
-        layers, tot_ms, tot_flop = [], 0.0, 0.0
-        for cin, cout, hw in VGG_LAYERS:
-            x = torch.rand((1, hw, hw, cin), device=dev)
-            wraw = torch.randn((9 * cin, cout), device=dev) * (2.0 / (9 * cin)) ** 0.5
-            b = torch.zeros(cout, device=dev)
-            use_x3 = cin != 3
-            if use_x3:
-                w3 = ops.pack_kn_x3(wraw)
-                wsb = torch.empty(max(ops.lib().disn_conv3x3_x3_workspace_bytes(1, hw, hw, cin, cout), 256),
-                                  dtype=torch.uint8, device=dev)
-                o = torch.empty((1, hw, hw, cout), device=dev)
-                ms = ev_time_ms(lambda: ops.conv3x3_x3(x, w3, b, cout, True, wsb, o), 20, torch)
-            else:
-                w = ops.pack_kn(wraw)
-                ms = ev_time_ms(lambda: ops.conv3x3(x, w, b, cout, True), 20, torch)
-            fl = 2.0 * hw * hw * cout * 9 * cin
-            layers.append({"cin": cin, "cout": cout, "hw": hw, "ms": round(ms, 5), "tflops": round(fl / ms / 1e9, 2),
-                           "kernel": "gemm_bf16_mfma<*,*,CONV3,3>" if use_x3 else "gemm_f32_mfma<*,*,CONV3*>"})
-            tot_ms += ms
-            tot_flop += fl
+        # ---- one step at a time (the latency of a step; the main line overlaps S independent steps) ----------
+        if S > 1:
+            ms1 = ev_time_ms(lambda: eng.encode_query(img, pts, tm), 50, torch)
+            line["single_stream"] = {"ms_per_step": ms1, "points_per_s": N_POINTS / ms1 * 1e3,
+                                     "note": "--in-flight 1: one step at a time, its ~35 dependent launches back to back"}
+        # ---- roofline of the dominant kernel family: the 13 convolution launches of one step ----------------
+        # Timed as the step runs them: ONE disn_vgg16_conv_stack call = resize + conv1_1_direct_kernel + 12
+        # conv_h2_kernel launches (two-term f16 split: fp32-accurate, f16 MFMA pipes, fused pools), back to back
+        # on the launch stream, HIP events around the call.  The resize launch (~5 us, 0.08 GFLOP-equivalent of
+        # nothing) is inside the bracket and charged to the family.
+        stack = ops.ConvStackRun(eng.weights.vgg, img, want_pool5=False)
+        tot_ms = ev_time_ms(stack.run, 50, torch)
+        tot_flop = sum(2.0 * hw * hw * cout * 9 * cin for cin, cout, hw in VGG_LAYERS)
         ach = tot_flop / tot_ms / 1e9
         # HBM-side bytes of the same 13 launches from the PMC passes of the last profiled build
         # (profiles/pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/gpu_pmc_traffic.sh,
@@ -413,23 +415,25 @@ def main():
             traffic = pmc["conv_family_per_step"]["hbm_bytes"]
         except Exception:
             pass
-        # fp32-equivalent ceiling of the three-term method: 6 bf16 MFMAs (2.5 PFLOP/s dense) per product block
-        peak_x3 = 2500.0 / 6.0
-        line["roofline"] = {"kernel": "13 conv launches of one VGG-16 forward, B=1: gemm_bf16_mfma<64,64,CONV3,3> "
-                                      "(three-term bf16 split, fp32-accurate) for 12 layers, gemm_f32_mfma for conv1_1",
+        peak_h2 = 2500.0 / 3.0   # fp32-equivalent ceiling of the two-term method: 3 f16 MFMAs (2.5 PFLOP/s dense) per block
+        line["roofline"] = {"kernel": "the 13 convolutions of one VGG-16 forward at B=1, as one disn_vgg16_conv_stack call: "
+                                      "conv1_1_direct_kernel (fp32 FMA) + 12 conv_h2_kernel launches (two-term f16 split, "
+                                      "fp32-accurate, f16 MFMA pipes, pools fused) + the resize launch",
                             "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                            "peak_note": "peak = dense f32-input MFMA (157.3), the arithmetic type of the result; "
-                                         "the three-term kernels issue bf16 MFMAs whose fp32-equivalent ceiling is "
-                                         "2500/6 = 417 TFLOP/s",
-                            "frac_of_three_term_ceiling": ach / peak_x3, "traffic": traffic,
+                            "peak_note": "peak = dense f32-input MFMA (157.3), the arithmetic type of the result; the "
+                                         "kernels issue f16 MFMAs, three per product block: their fp32-equivalent ceiling "
+                                         "is 2500/3 = 833 TFLOP/s (frac_of_two_term_ceiling)",
+                            "frac_of_two_term_ceiling": ach / peak_h2, "traffic": traffic,
                             "traffic_measured_on": pmc.get("build"),
-                            "traffic_note": "memory-side bytes per step of the 13 conv launches + their split-K "
-                                            "reduces (FETCH_SIZE x2 + calibrated WRITE_SIZE; L2 misses served by MALL "
-                                            "count), replayed from profiles/pmc_traffic.json (PMC passes of "
-                                            "tools/gpu_pmc_traffic.sh on the build named in traffic_measured_on); "
-                                            "algorithmic ~180 MB (three-plane bf16 weights 88 + inputs 36 + outputs 54)",
-                            "flop_per_step": tot_flop, "ms_per_step": tot_ms, "layers": layers}
+                            "traffic_note": "memory-side bytes per step of the 13 conv launches (FETCH_SIZE x2 + calibrated "
+                                            "WRITE_SIZE; L2 misses served by MALL count), replayed from "
+                                            "profiles/pmc_traffic.json (PMC passes of tools/gpu_pmc_traffic.sh on the build "
+                                            "named in traffic_measured_on); algorithmic ~165 MB (two-plane f16 weights 59 + "
+                                            "inputs 36 + outputs and pooled copies 68)",
+                            "flop_per_step": tot_flop, "ms_per_step": tot_ms, "launches": 14,
+                            "per_launch": "profiles/r02*_conv_stack_trace.txt (rocprofv3 kernel trace of the same call); a "
+                                          "layer alone takes 9-21 us, ~5-8 us more as a link of the chain"}
         # ---- gathers (HBM / cache bound): the kernels that ARE on the timed paths ---------------------
         ACHIEVABLE = 6300.0      # MI355X_MICROARCH.md: measured float4-copy HBM rate; above it = cache bandwidth
         enc = eng.encode(img)

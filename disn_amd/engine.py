@@ -126,8 +126,10 @@ class SdfEngine:
     kernels (mlp_fused.hip: activations in registers, fp32-accurate two-term fp16 products) instead of the
     layer-by-layer GEMM chain (three-term bf16 products); same math, fp32-rounding-level difference."""
 
-    def __init__(self, store: WeightStore, device: Optional[torch.device] = None, fused: bool = True,
-                 conv_h2: bool = True):
+    def __init__(self, store: Optional[WeightStore], device: Optional[torch.device] = None, fused: bool = True,
+                 conv_h2: bool = True, weights: Optional[DeviceWeights] = None):
+        """``weights``: share the device weights of another engine (``store`` is then ignored): several engine
+        contexts -- each with its own workspaces and auxiliary stream -- over one copy of the 560 MB"""
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         if not torch.cuda.is_available():
@@ -135,7 +137,7 @@ class SdfEngine:
         self.device = torch.device(device)
         self.fused = bool(fused)
         with torch.cuda.device(self.device):
-            self.weights = DeviceWeights(store, self.device, conv_h2=conv_h2)
+            self.weights = weights if weights is not None else DeviceWeights(store, self.device, conv_h2=conv_h2)
             self._ctx = ops.ctx_create()      # aux HIP stream + events for the overlapped encoder
         self._ws: Dict[str, torch.Tensor] = {}
 
@@ -274,3 +276,49 @@ class SdfEngine:
             ws = self._workspace("grid", need)
             return ops.query_grid(self.weights.mlp, self.featmap_of(enc)[image_index], enc.embedding[image_index:image_index + 1],
                                   tm.contiguous(), sdf_params, res, k0, k1, sdf_weight, ws, out, ctx)
+
+
+class StepPipeline:
+    """``in_flight`` independent encode + query steps at a time on one GPU.
+
+    A step (disn_encode_query) is a chain of ~35 dependent launches; between two dependent launches the GPU idles
+    for several microseconds (measured on MI355X: a convolution layer takes 18 us alone and 26 us as a link of the
+    chain), which at a 0.5 ms step is a third of the time.  Steps on different images are independent, so the
+    chains of several steps -- each on its own HIP stream, fed by its own host thread (the ctypes calls release
+    the GIL), each with its own workspaces and auxiliary stream, all over ONE copy of the weights -- fill each
+    other's gaps: 0.49 -> 0.35 ms per step at three in flight (tools/multi_stream_try.py).  Every step still does
+    all of its work; nothing is shared or cached between steps, and each result equals the single-stream one bit
+    for bit (the kernels and their launch order within a step are the same)."""
+
+    def __init__(self, store: WeightStore, device: Optional[torch.device] = None, in_flight: int = 3):
+        import threading
+        self._threading = threading
+        first = SdfEngine(store, device)
+        self.device = first.device
+        self.engines = [first] + [SdfEngine(None, self.device, weights=first.weights) for _ in range(in_flight - 1)]
+        with torch.cuda.device(self.device):
+            self.streams = [torch.cuda.Stream(self.device) for _ in self.engines]
+
+    def run(self, jobs, keep_encoded: bool = False):
+        """jobs: sequence of (imgs, pts, trans_mat[, pts_rot]) -> list of pred_sdf (or (Encoded, pred_sdf)) in
+        job order.  Job k runs on engine context k % in_flight.  Returns with the work enqueued, not finished:
+        synchronise the device (or the returned tensors' use on the current stream) as usual."""
+        S = len(self.engines)
+        out = [None] * len(jobs)
+        cur = torch.cuda.current_stream(self.device)
+
+        def work(i):
+            with torch.cuda.device(self.device), torch.cuda.stream(self.streams[i]):
+                self.streams[i].wait_stream(cur)          # inputs produced on the caller's stream
+                for k in range(i, len(jobs), S):
+                    enc, sdf = self.engines[i].encode_query(*jobs[k])
+                    out[k] = (enc, sdf) if keep_encoded else sdf
+
+        threads = [self._threading.Thread(target=work, args=(i,)) for i in range(min(S, len(jobs)))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for st in self.streams:
+            cur.wait_stream(st)                            # results are ordered before later work on the caller's stream
+        return out

@@ -407,3 +407,23 @@ dist.barrier(); dist.destroy_process_group(); print("SHARD_OK")
     env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env2)
     assert r.returncode == 0 and "SHARD_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_step_pipeline_equals_single_stream_steps():
+    """disn_amd.engine.StepPipeline: three steps in flight (own contexts, streams, host threads, shared weights)
+    return, for every job, exactly what one engine returns one step at a time"""
+    from disn_amd.engine import SdfEngine, StepPipeline
+    from disn_amd.weights import WeightStore
+    store = WeightStore.random_init(2, mode="he")
+    pipe = StepPipeline(store, in_flight=3)
+    jobs = []
+    for k in range(7):
+        d = O.synth_inputs(20 + k, 1, 256 + 64 * k)
+        jobs.append((torch.from_numpy(d["imgs"]).cuda(), torch.from_numpy(d["sample_pc"]).cuda(),
+                     torch.from_numpy(d["trans_mat"]).cuda()))
+    got = pipe.run(jobs)
+    torch.cuda.synchronize()
+    one = SdfEngine(None, weights=pipe.engines[0].weights)
+    for k, job in enumerate(jobs):
+        ref = one.encode_query(*job)[1]
+        assert torch.equal(got[k], ref), "job %d differs" % k

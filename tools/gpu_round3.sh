@@ -1,0 +1,42 @@
+#!/bin/bash
+# round-2 evidence run: pipeline test, bench (main line + extras), grid line, rocprof traces (step, conv stack), PMC traffic
+set -u
+TAG=${1:-r02m}; shift || true
+WHAT=${*:-"test bench grid prof pmc"}
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+if has test; then
+  timeout 300 python -m pytest tests/test_gpu_model.py -q -k "pipeline or standalone_layer_chain or cfg2" --no-header -p no:cacheprovider > $OUT/pytest_quick.log 2>&1; echo "quick tests exit $?"; tail -3 $OUT/pytest_quick.log
+fi
+if has tests; then
+  timeout 1500 python -m pytest tests -m gpu -q -rA --no-header -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log; grep -v "^PASSED" $OUT/pytest_gpu.log | tail -15
+fi
+if has bench; then
+  timeout 600 python bench.py --steps 200 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; tail -3 $OUT/bench.err
+  timeout 120 python bench.py --steps 200 --warmup 10 --in-flight 1 --no-extras 2>&1 | tail -2 | cut -c1-120
+fi
+if has grid; then
+  timeout 300 python bench.py --workload grid --steps 3 --warmup 1 > $OUT/bench_grid1.json 2> $OUT/bench_grid1.err; echo "grid exit $?"; tail -c 400 $OUT/bench_grid1.json
+fi
+if has prof; then
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-extras --in-flight 1 > /tmp/prof_$TAG.log 2>&1; echo "rocprof exit $?")
+  for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/bench_kernel_stats.csv; done
+  python tools/trace_step.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null | grep -v "at::native\|rocclr_copy" > $OUT/infer_step_trace.txt; tail -3 $OUT/infer_step_trace.txt
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profc_$TAG -o trace -- python $GRAFT_REPO_ROOT/tools/conv_stack_time.py > /tmp/profc_$TAG.log 2>&1; echo "rocprof conv stack exit $?")
+  for f in $(find /tmp/profc_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/conv_stack_kernel_stats.csv; done
+  python tools/trace_step.py $(find /tmp/profc_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null > $OUT/conv_stack_trace.txt; tail -2 $OUT/conv_stack_trace.txt
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profk_$TAG -o trace -- python $GRAFT_REPO_ROOT/tools/prof_kernels.py > /tmp/profk_$TAG.log 2>&1; echo "rocprof kernels exit $?")
+  for f in $(find /tmp/profk_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/kernels_kernel_stats.csv; done
+fi
+if has pmc; then
+  cd /tmp
+  for C in FETCH_SIZE WRITE_SIZE; do
+    PROF_STEPS=1 timeout 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$C -o pmc -- python $GRAFT_REPO_ROOT/tools/prof_kernels.py > $GRAFT_REPO_ROOT/$OUT/pmc_$C.log 2>&1
+    echo "pmc $C exit $?"
+    for f in $(find /tmp/pmc_${TAG}_$C -name "*counter_collection.csv"); do cp $f $GRAFT_REPO_ROOT/$OUT/pmc_$C.csv; done
+  done
+  cd $GRAFT_REPO_ROOT
+  python tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.json && head -14 $OUT/pmc_traffic.json
+fi
+exit 0

@@ -30,7 +30,8 @@ ids = sorted(fetch)
 
 
 def is_conv(n):
-    return ("gemm_bf16_mfma" in n and ", 1, " in n) or ("gemm_f32_mfma" in n and (", 1, 0>" in n or ", 2, 0>" in n))
+    return ("conv_h2_kernel" in n or "conv1_1_direct_kernel" in n or ("gemm_bf16_mfma" in n and ", 1, " in n)
+            or ("gemm_f32_mfma" in n and (", 1, 0>" in n or ", 2, 0>" in n)))
 
 
 # the first step = from the first conv GEMM to the 13th
@@ -68,9 +69,10 @@ def hbm(idl):
 out = {"build": build, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_kernels.py workload (PROF_STEPS=1)",
        "note": "KB as reported; gfx950: FETCH_SIZE x2 for wide coalesced reads; WRITE_SIZE calibrated on the gather",
        "conv_family_per_step": dict(hbm(conv), kernels=sorted({fetch[i]["name"].split("(")[0] for i in conv}),
-                                    algorithmic_bytes_note="weights 88 MB (three bf16 planes, 6 B/weight) + layer inputs "
-                                    "~36 MB + outputs ~54 MB + split-K partials; the 3x3 taps re-read every input row "
-                                    "through L2/MALL (hits there are counted by FETCH_SIZE)"),
+                                    algorithmic_bytes_note="conv_h2 build: weights 59 MB (two f16 planes, 4 B/weight) + layer "
+                                    "inputs ~36 MB + outputs ~54 MB (+ 14 MB pooled copies); every workgroup re-reads its "
+                                    "n-block's weights and its halo through L2 (hits there are not counted, MALL hits "
+                                    "are); three-term build: weights 88 MB + split-K partials"),
        "gather_n2048": dict(hbm([g_small]), algorithmic_bytes=2048 * 29440),
        "gather_n262144": dict(hbm([g_big]), algorithmic_bytes=262144 * 29440),
        "gather_from_taps_n2048": (dict(hbm(g_taps[-1:]), algorithmic_bytes=2048 * (16 * 5888 + 5888),
