@@ -94,6 +94,7 @@ SIGNATURES = {
     "disn_maxpool2x2": (I, [P, I, I, I, I, P, P]),
     "disn_fc_workspace_bytes": (Z, [I, I, I]),
     "disn_fc": (I, [P, I, I, P, P, I, I, P, P, Z, P]),
+    "disn_get_loss": (I, [P, P, L, F, F, P, P]),
     "disn_fc_t": (I, [P, I, I, P, P, I, I, P, P]),
     "disn_dense_workspace_bytes": (Z, [I, I, I]),
     "disn_dense": (I, [P, I, I, P, I, I, I, P, P, I, I, P, P, Z, P]),

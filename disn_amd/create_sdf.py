@@ -36,7 +36,12 @@ def grid_points_host(sdf_params: Sequence[float], sdf_res: int) -> np.ndarray:
     """Host grid as the reference builds it (test/create_sdf.py:246-256) -- for callers that
     still feed points through placeholders.  The device path never materialises this."""
     res = sdf_res + 1
-    p = np.asarray(sdf_params, dtype=np.float64)   # numpy-1.x semantics of the reference (float64 linspace)
+    # float64 linspace: what numpy 1.x computes for int / float64 sdf_params (demo/demo.py:278 passes ints).  For
+    # FLOAT32 sdf_params numpy 1.x forms delta = stop - start and step = delta / div as float32 scalars before the
+    # float64 arange multiply; with a box whose float32 difference or division is inexact (not the +-1 demo box
+    # or any dyadic box) the coordinates then drift from this grid by the accumulated step rounding, up to
+    # R * ulp32(step) / 2 ~ 1e-7 of the box (tests/test_oracle.py::test_grid_float32_params_caveat).  numpy >= 2 computes in float32.
+    p = np.asarray(sdf_params, dtype=np.float64)
     x_ = np.linspace(p[0], p[3], num=res)
     y_ = np.linspace(p[1], p[4], num=res)
     z_ = np.linspace(p[2], p[5], num=res)

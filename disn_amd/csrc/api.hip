@@ -429,6 +429,13 @@ int disn_fc_t(const float* x, int B, int K, const float* wt_nk, const float* bia
   return 0;
 }
 
+int disn_get_loss(const float* pred, const float* gt, int64_t M, float sdf_weight, float mask_weight, float* out5,
+                  void* stream) {
+  if (!pred || !gt || !out5 || M <= 0 || sdf_weight == 0.0f) return DISN_E_ARG;
+  DISN_TRY(loss_reduce_launch(pred, gt, (long)M, sdf_weight, mask_weight, out5, (hipStream_t)stream));
+  return 0;
+}
+
 size_t disn_dense_workspace_bytes(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0 || K % 32 || N % 64) return 0;
   return gemm_plan(M, N, K).ws_bytes;

@@ -96,6 +96,7 @@ def get_model(ref_dict, num_point, is_training, bn=False, bn_decay=None, img_siz
     N = ref_sample_pc.get_shape()[1]
 
     end_points = {}
+    end_points['wd'] = wd                                   # get_loss's weight decay (the reference threads it through slim scopes)
     end_points['ref_pc'] = ref_dict['pc']
     end_points['ref_sdf'] = ref_dict['sdf']
     end_points['ref_img'] = ref_img                       # :62 -- the UN-resized input
@@ -166,54 +167,44 @@ def get_decoder(num_point, input_pls, feature_pls, bn=False, bn_decay=None, wd=N
 
 def get_loss(end_points, sdf_weight=10., regularization=True, mask_weight=4.,
              num_sample_points=2048, FLAGS=None, batch_size=None):
-    """models/model_normalization.py:254-300, regression branch.  Scalars only; evaluated with
-    torch reductions on the device (row K is training-side glue, not a hot kernel)."""
+    """models/model_normalization.py:254-300, regression branch.  The scalars come from ONE launch of the
+    library's loss kernel (disn_get_loss = loss_reduce_kernel, the one disn_train_step uses); the weight decay is
+    the `wd` given to get_model (slim l2_regularizer(wd) on the VGG conv weights, :75, + the tf_util
+    'regularizer' collection, utils/tf_util.py:45-47: wd * sum(w^2) / 2 over every '/weights' variable).  This
+    shim serves the INFERENCE / evaluation loops (test/create_sdf.py); there is no train_op here -- training is
+    disn_amd.train_sdf.Trainer."""
     F = _flags(FLAGS)
     _check_supported(F)
     pred_sdf = end_points['pred_sdf']
     gt_sdf = end_points['ref_sdf']
+    wd = float(end_points.get('wd', 1e-5))
     end_points['losses'] = {}
 
-    def prep(sess, pred, gt):
+    def reg_fn(sess):
+        if not regularization:
+            return 0.0
+        return float(sum(wd * 0.5 * float(np.sum(np.asarray(v, np.float64) ** 2))
+                         for k, v in sess.weights.items() if k.endswith('/weights')))
+
+    reg = SymTensor('regularization', (), reg_fn, ())
+
+    def five_fn(sess, pred, gt, r):
         import torch
-        return pred, torch.from_numpy(np.ascontiguousarray(gt, np.float32)).to(pred.device)
+        from . import ops
+        gt_d = torch.from_numpy(np.ascontiguousarray(gt, np.float32)).to(pred.device)
+        return ops.get_loss(pred.reshape(-1), gt_d.reshape(-1), sdf_weight, mask_weight, r)
 
-    pair = SymTensor('loss_inputs', (), prep, (pred_sdf, gt_sdf))
+    five = SymTensor('loss_scalars', (5,), five_fn, (pred_sdf, gt_sdf, reg))
 
-    def acc_fn(sess, pg):
-        pred, gt = pg
-        return ((gt > 0) == (pred > 0)).float().mean()
+    def mask_fn(sess, gt):
+        gt = np.asarray(gt, np.float32)
+        return (gt <= 0.01).astype(np.float32) * np.float32(mask_weight) + (gt > 0.01).astype(np.float32)
 
-    def mask_fn(sess, pg):
-        _, gt = pg
-        return (gt <= 0.01).float() * mask_weight + (gt > 0.01).float()
-
-    def sdf_loss_fn(sess, pg, mask):
-        pred, gt = pg
-        return ((gt * sdf_weight - pred).abs() * mask).mean() * 1000
-
-    def real_fn(sess, pg):
-        pred, gt = pg
-        return (gt - pred / sdf_weight).abs().mean()
-
-    accuracy = SymTensor('accuracy', (), acc_fn, (pair,))
-    weight_mask = SymTensor('weighed_mask', gt_sdf.get_shape(), mask_fn, (pair,))
-    sdf_loss = SymTensor('sdf_loss', (), sdf_loss_fn, (pair, weight_mask))
-    end_points['losses']['accuracy'] = accuracy
-    end_points['weighed_mask'] = weight_mask
-    end_points['losses']['sdf_loss_realvalue'] = SymTensor('sdf_loss_realvalue', (), real_fn, (pair,))
-    end_points['losses']['sdf_loss'] = sdf_loss
-    loss = sdf_loss
+    end_points['weighed_mask'] = SymTensor('weighed_mask', gt_sdf.get_shape(), mask_fn, (gt_sdf,))
+    for i, name in enumerate(('accuracy', 'sdf_loss_realvalue', 'sdf_loss')):
+        end_points['losses'][name] = SymTensor(name, (), lambda sess, v, i=i: v[i], (five,))
     if regularization:
-        def reg_fn(sess):
-            # slim l2_regularizer(wd) on VGG conv weights (:75) + tf_util 'regularizer' collection
-            # (utils/tf_util.py:45-47): wd * sum(w^2)/2 over every '/weights' variable
-            wd = 1e-5
-            return float(sum(wd * 0.5 * float(np.sum(np.asarray(v, np.float64) ** 2))
-                             for k, v in sess.weights.items() if k.endswith('/weights')))
-
-        reg = SymTensor('regularization', (), reg_fn, ())
         end_points['losses']['regularization'] = reg
-        loss = SymTensor('overall_loss', (), lambda sess, a, b: a + b, (sdf_loss, reg))
+    loss = SymTensor('overall_loss', (), lambda sess, v: v[4] if regularization else v[2], (five,))
     end_points['losses']['overall_loss'] = loss
     return loss, end_points

@@ -169,6 +169,19 @@ def fc(x: torch.Tensor, w_kn: torch.Tensor, bias: torch.Tensor, relu: bool) -> t
     return out
 
 
+def get_loss(pred: torch.Tensor, gt: torch.Tensor, sdf_weight: float, mask_weight: float,
+             regularization: float = 0.0) -> torch.Tensor:
+    """disn_get_loss -> 5 device floats {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}"""
+    pred, gt = _chk(pred, "pred"), _chk(gt, "gt")
+    if pred.numel() != gt.numel():
+        raise ValueError("get_loss: pred and gt differ in size")
+    out = torch.zeros(5, dtype=torch.float32, device=pred.device)
+    out[3] = float(regularization)
+    check("disn_get_loss", lib().disn_get_loss(pred.data_ptr(), gt.data_ptr(), pred.numel(), float(sdf_weight),
+                                               float(mask_weight), out.data_ptr(), _stream()))
+    return out
+
+
 def fc_t(x: torch.Tensor, wt_nk: torch.Tensor, bias: torch.Tensor, relu: bool) -> torch.Tensor:
     """disn_fc_t: act(x @ wt_nk.T + bias) from the transposed matrix [N][K], one launch"""
     x, wt = _chk(x, "x"), _chk(wt_nk, "wt_nk")

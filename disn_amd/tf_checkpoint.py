@@ -12,9 +12,10 @@ test/create_sdf.py:180-192) and ships its weights as V2 bundles (``checkpoint/SD
 
 This module restates that format from the TensorFlow source (tensorflow/core/util/tensor_bundle,
 tensorflow/core/lib/io/{table_builder,block_builder,format}.cc, protobuf wire format) in plain
-Python.  STATUS: round-trip tested (tests/test_tf_checkpoint.py) and checked field by field
-against the format description; NOT yet validated against a file written by TensorFlow itself
-(none is available in this environment -- the reference's checkpoints are Dropbox downloads).
+Python.  STATUS: round-trip tested, and pinned by a bundle assembled BY HAND from the format description,
+independently of this module (tests/test_tf_checkpoint.py: the reader reads it, the writer reproduces it byte for
+byte, shortened index keys included); NOT validated against a file written by TensorFlow itself (none is available
+in this environment -- the reference's checkpoints are Dropbox downloads).
 Only what DISN checkpoints contain is supported: uncompressed blocks, one shard, float32/int32/
 int64/float64 tensors, no tensor slices.
 """
@@ -236,6 +237,27 @@ def _build_block(entries: List[Tuple[bytes, bytes]], restart_interval: int) -> b
     return bytes(out)
 
 
+def _shortest_separator(start: bytes, limit: bytes) -> bytes:
+    """BytewiseComparator::FindShortestSeparator (lib/io/table_builder.cc calls it for the index key between two
+    data blocks): a short key k with start <= k < limit"""
+    m = min(len(start), len(limit))
+    d = 0
+    while d < m and start[d] == limit[d]:
+        d += 1
+    if d < m and start[d] < 0xFF and start[d] + 1 < limit[d]:
+        return start[:d] + bytes([start[d] + 1])
+    return start
+
+
+def _short_successor(key: bytes) -> bytes:
+    """BytewiseComparator::FindShortSuccessor (index key of the LAST data block): first byte that is not 0xff
+    incremented, the rest dropped"""
+    for i, b in enumerate(key):
+        if b != 0xFF:
+            return key[:i] + bytes([b + 1])
+    return key
+
+
 def _emit_block(f, block: bytes) -> Tuple[int, int]:
     off = f.tell()
     f.write(block)
@@ -334,20 +356,26 @@ def save_checkpoint(prefix: str, tensors: Dict[str, np.ndarray], block_bytes: in
         index_entries: List[Tuple[bytes, bytes]] = []
         cur: List[Tuple[bytes, bytes]] = []
         cur_bytes = 0
+        pending: Optional[Tuple[bytes, bytes]] = None      # (last key, handle) of a flushed block without its index key
 
         def flush():
-            nonlocal cur, cur_bytes
+            nonlocal cur, cur_bytes, pending
             if cur:
                 off, size = _emit_block(f, _build_block(cur, 16))
-                index_entries.append((cur[-1][0], _put_varint(off) + _put_varint(size)))
+                pending = (cur[-1][0], _put_varint(off) + _put_varint(size))
                 cur, cur_bytes = [], 0
 
         for k, v in items:
+            if pending is not None:       # TableBuilder::Add: the index key is chosen when the NEXT key is known
+                index_entries.append((_shortest_separator(pending[0], k), pending[1]))
+                pending = None
             cur.append((k, v))
             cur_bytes += len(k) + len(v) + 3
             if cur_bytes >= block_bytes:
                 flush()
         flush()
+        if pending is not None:           # TableBuilder::Finish
+            index_entries.append((_short_successor(pending[0]), pending[1]))
         mi_off, mi_size = _emit_block(f, _build_block([], 1))             # empty metaindex block
         ix_off, ix_size = _emit_block(f, _build_block(index_entries, 1))
         footer = _put_varint(mi_off) + _put_varint(mi_size) + _put_varint(ix_off) + _put_varint(ix_size)

@@ -14,6 +14,7 @@ buffer (RCCL over xGMI; gloo on CPU tensors is not supported: the path has no CP
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -70,6 +71,24 @@ class FlatParams:
         return out
 
 
+def step_from_checkpoint(arrays: Dict[str, np.ndarray], beta2: float, current: int = 0) -> int:
+    """the global step a restored bundle stands at.  `batch` (the reference's step variable,
+    train/train_sdf.py:232,268) when the bundle has it; otherwise recovered from Adam's beta2_power =
+    beta2^(t+1) while that is a usable float32 (t < ~8e4: it goes denormal near 8.7e4 steps and reaches 0 near
+    1.03e5); a power of exactly 0 means the run is past that point: bias correction is saturated (lr_t == lr, as in
+    TF, which keeps multiplying the zero) and the schedule position is unknown, so the caller's step is kept, but
+    never below the underflow point -- the schedule must not silently restart at 0."""
+    gs = arrays.get("batch")
+    b2 = arrays.get("beta2_power")
+    if gs is not None and np.asarray(gs).size == 1:
+        return max(int(np.asarray(gs).reshape(())), 0)
+    if b2 is not None and 0.0 < float(b2) < 1.0:
+        return max(int(round(math.log(float(b2)) / math.log(beta2))) - 1, 0)
+    if b2 is not None and float(b2) == 0.0:
+        return max(int(current), 104000)
+    return int(current)
+
+
 class Trainer:
     def __init__(self, store: WeightStore, device="cuda:0", batch_size: int = 20, base_lr: float = 1e-4,
                  decay_step: int = 200000, decay_rate: float = 0.9, wd: float = 1e-5,
@@ -103,17 +122,20 @@ class Trainer:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         self._ws: Optional[torch.Tensor] = None
-        self.ctx = ops.ctx_create()  # auxiliary stream for the HBM-bound side work of the step
-        # gradient exchange: fc + MLP bucket under the convolution backward, conv bucket at the end
-        self.reducer = GradientReducer(int(self.flat.layout.offset[HEAD_FIRST_VAR]), process_group)
-        self.head_ready = torch.cuda.Event()
+        # every stream / event this object owns lives on params.device, and every launch below runs under
+        # torch.cuda.device(params.device): ops._stream() is the CURRENT device's current stream
         with torch.cuda.device(self.params.device):
+            self.ctx = ops.ctx_create()  # auxiliary stream for the HBM-bound side work of the step
+            # gradient exchange: fc + MLP bucket under the convolution backward, conv bucket at the end
+            self.reducer = GradientReducer(int(self.flat.layout.offset[HEAD_FIRST_VAR]), process_group)
+            self.head_ready = torch.cuda.Event()
             self.head_ready.record()  # creates the hipEvent_t handed to the library
 
     def close(self) -> None:
         if self.ctx:
             torch.cuda.synchronize(self.params.device)
-            ops.ctx_destroy(self.ctx)
+            with torch.cuda.device(self.params.device):
+                ops.ctx_destroy(self.ctx)
             self.ctx = None
 
     def __del__(self):
@@ -130,11 +152,12 @@ class Trainer:
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.params.device)
-        out = ops.train_step(self.params, self.grads, feed["imgs"], feed["trans_mat"], feed["sample_pc"],
-                             feed["sample_pc_rot"], feed["sdf"], self.wd, self.sdf_weight,
-                             self.mask_weight, ws=self._ws, ctx=self.ctx, head_ready=self.head_ready,
-                             compute_bf16=self.compute_bf16)
-        self.reducer.start_head(self.grads, self.head_ready)
+        with torch.cuda.device(self.params.device):
+            out = ops.train_step(self.params, self.grads, feed["imgs"], feed["trans_mat"], feed["sample_pc"],
+                                 feed["sample_pc_rot"], feed["sdf"], self.wd, self.sdf_weight,
+                                 self.mask_weight, ws=self._ws, ctx=self.ctx, head_ready=self.head_ready,
+                                 compute_bf16=self.compute_bf16)
+            self.reducer.start_head(self.grads, self.head_ready)
         return out
 
     def learning_rate(self) -> float:
@@ -145,9 +168,10 @@ class Trainer:
         lr = self.learning_rate()
         t = self.step_count + 1
         lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
-        self.reducer.finish(self.grads)
-        ops.adam_update(self.params, self.grads, self.m, self.v, lr_t, self.beta1, self.beta2, self.eps,
-                        1.0 / self.world)
+        with torch.cuda.device(self.params.device):
+            self.reducer.finish(self.grads)
+            ops.adam_update(self.params, self.grads, self.m, self.v, lr_t, self.beta1, self.beta2, self.eps,
+                            1.0 / self.world)
         self.step_count = t
         return lr
 
@@ -164,14 +188,21 @@ class Trainer:
         out.update(self.flat.to_arrays(self.v, "/Adam_1"))
         out["beta1_power"] = np.asarray(self.beta1 ** (self.step_count + 1), np.float32)
         out["beta2_power"] = np.asarray(self.beta2 ** (self.step_count + 1), np.float32)
+        # the reference's global step (train/train_sdf.py:232 `batch = tf.Variable(0, name='batch')`, :268
+        # minimize(global_step=batch)), int32 as TF creates it: the step is restored from HERE -- beta2_power
+        # underflows float32 after ~1e5 steps
+        out["batch"] = np.asarray(self.step_count, np.int32)
         return out
 
     def weight_store(self) -> WeightStore:
         return WeightStore(self.flat.to_arrays(self.params))
 
     def save(self, prefix: str) -> None:
+        """variables + Adam slots + step as a TF Saver-V2 bundle, and the `checkpoint` state file next to it
+        (what saver.save writes, train/train_sdf.py:285-286), so that restore_latest / get_checkpoint_state find it"""
         from . import tf_checkpoint as tfc
         tfc.save_checkpoint(prefix, self.state_arrays())
+        tfc.write_checkpoint_state(os.path.dirname(os.path.abspath(prefix)), os.path.basename(prefix))
 
     def restore(self, prefix: str) -> int:
         """prefix + exact-shape match, as load_model (train/train_sdf.py:190-219); -> #restored"""
@@ -184,9 +215,7 @@ class Trainer:
                 if a is not None and tuple(a.shape) == tuple(self.flat.shapes[name]):
                     self.flat.view(buf, name).copy_(torch.from_numpy(np.ascontiguousarray(a, np.float32)))
                     n += 1
-        b2 = arrays.get("beta2_power")
-        if b2 is not None and 0.0 < float(b2) < 1.0:
-            self.step_count = max(int(round(math.log(float(b2)) / math.log(self.beta2))) - 1, 0)
+        self.step_count = step_from_checkpoint(arrays, self.beta2, self.step_count)
         return n
 
 

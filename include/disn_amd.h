@@ -164,6 +164,13 @@ int disn_fc_t(const float* x, int B, int K, const float* wt_nk, const float* bia
  * (the tf.concat(axis=3) of models/sdfnet.py:82,180 is read in place, never materialised).
  * k1, k2 multiples of 32 (k2 may be 0 with a2 NULL), N a multiple of 64,
  * w_packed = disn_pack_kn of W [k1+k2][N].  fp32 MFMA. */
+/* Row K: the scalars of get_loss (models/model_normalization.py:273-299, regression branch) in one launch:
+ * out5 = {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}; pred [M] = pred_sdf
+ * (un-divided), gt [M] = ref_sdf; out5[3] is READ (the caller's wd/2 * sum w^2, 0 without regularization) and
+ * overall_loss = sdf_loss + out5[3].  The kernel disn_train_step uses. */
+int disn_get_loss(const float* pred, const float* gt, int64_t M, float sdf_weight, float mask_weight, float* out5,
+                  void* stream);
+
 size_t disn_dense_workspace_bytes(int M, int K, int N);
 int disn_dense(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, int M,
                const float* w_packed, const float* bias, int N, int relu, float* out, void* ws,

@@ -501,14 +501,33 @@ def grid_points(sdf_params: Sequence[float], sdf_res: int) -> np.ndarray:
     """[(R+1)^3, 3] float32 in the flat (iz,iy,ix) order -- test/create_sdf.py:246-256:
     linspace in float64, meshgrid(z_,y_,x_,'ij'), concat (x,y,z), cast float32."""
     res = sdf_res + 1
-    # float64 explicitly: in the reference's numpy-1.x environment linspace of float32 / int
-    # scalars computes in float64 (demo/demo.py:278 even passes ints); numpy>=2 (NEP 50) would
-    # silently compute float32 for float32 inputs, which is NOT the reference's arithmetic
+    # float64 explicitly: what numpy 1.x linspace computes for int / float64 scalars (demo/demo.py:278 passes
+    # ints).  For float32 scalars numpy 1.x rounds delta = stop - start and step = delta / div to float32 and only
+    # then multiplies the float64 arange (grid_points_numpy1_float32 below): identical for the +-1 box and any
+    # dyadic box, up to R * ulp32(step) / 2 (~1e-7 of the box) apart otherwise.  numpy >= 2 (NEP 50) computes
+    # everything in float32 for float32 inputs -- neither is this function.
     p = np.asarray(sdf_params, dtype=np.float64)
     x_ = np.linspace(p[0], p[3], num=res)
     y_ = np.linspace(p[1], p[4], num=res)
     z_ = np.linspace(p[2], p[5], num=res)
     z, y, x = np.meshgrid(z_, y_, x_, indexing="ij")
+    return np.stack((x, y, z), axis=3).astype(np.float32).reshape(-1, 3)
+
+
+def grid_points_numpy1_float32(sdf_params: Sequence[float], sdf_res: int) -> np.ndarray:
+    """the grid numpy 1.x builds when sdf_params are FLOAT32 scalars (numpy/core/function_base.py linspace, 1.14):
+    start, stop stay float32, delta = stop - start and step = delta / div are float32, y = arange(float64) * step
+    + start, y[-1] = stop.  Restated with explicit casts so that it does not depend on the installed numpy."""
+    res = sdf_res + 1
+    p = np.asarray(sdf_params, dtype=np.float32)
+    axes = []
+    for a in range(3):
+        start, stop = np.float32(p[a]), np.float32(p[a + 3])
+        step = np.float32(np.float32(stop - start) / np.float32(res - 1))
+        y = np.arange(res, dtype=np.float64) * np.float64(step) + np.float64(start)
+        y[-1] = np.float64(stop)
+        axes.append(y)
+    z, y, x = np.meshgrid(axes[2], axes[1], axes[0], indexing="ij")
     return np.stack((x, y, z), axis=3).astype(np.float32).reshape(-1, 3)
 
 

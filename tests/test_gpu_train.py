@@ -278,6 +278,10 @@ def test_checkpoint_roundtrip_with_adam_slots(tmp_path, small_step):
     tr2 = Trainer(WeightStore(O.init_weights(99, "he")), batch_size=2)
     assert tr2.restore(prefix) == 3 * 56 and tr2.step_count == 2
     assert torch.equal(tr.params, tr2.params) and torch.equal(tr.m, tr2.m) and torch.equal(tr.v, tr2.v)
+    # saver.save also writes the `checkpoint` state file: the latest-checkpoint lookup finds the bundle
+    from disn_amd import tf_checkpoint as tfc
+    assert tfc.get_checkpoint_state(str(tmp_path)) == prefix
+    assert int(tfc.load_checkpoint(prefix)["batch"]) == 2
     tr.step(feed); tr2.step(feed)
     mlp = slice(int(tr.flat.layout.offset[32]), tr.flat.total)
     assert torch.equal(tr.params[mlp], tr2.params[mlp])

@@ -223,3 +223,20 @@ def test_external_kat_hand_derived_resampler_cases():
     m = (1 + xx + 1000 * yy).astype(np.float32)[None, :, :, None]
     got = O.resampler(m, np.asarray(k["resampler_137"]["xy"], np.float32)[None])[0, :, 0]
     assert np.array_equal(got, np.asarray(k["resampler_137"]["out"], np.float32))
+
+
+def test_grid_float32_params_caveat():
+    """with FLOAT32 sdf_params numpy 1.x rounds the linspace step to float32.  The product / oracle grid
+    (float64 step; what numpy 1.x computes for the ints of demo/demo.py:278 and for float64 params) is identical
+    to that for dyadic boxes (the +-1 box at a power-of-two resolution) and otherwise drifts by the accumulated
+    step rounding: |difference| <= R * ulp32(step) / 2 + one float32 rounding -- about 1e-7 of the box size."""
+    for box, R in (([-1, -1, -1, 1, 1, 1], 64), ([-1, -1, -1, 1, 1, 1], 256), ([-0.5, -1, -2, 0.5, 1, 2], 32)):
+        assert np.array_equal(O.grid_points(box, R), O.grid_points_numpy1_float32(box, R))
+    box = np.asarray([-0.83, -0.91, -0.77, 0.79, 0.95, 0.81], np.float32)
+    R = 100
+    a, b = O.grid_points(box, R), O.grid_points_numpy1_float32(box, R)
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64)).max(axis=0)
+    step = (box[3:].astype(np.float64) - box[:3]) / R
+    bound = R * np.spacing(step.astype(np.float32)).astype(np.float64) / 2 + np.spacing(np.float32(1.0))
+    print("non-dyadic float32 box, R = 100: max |difference| per axis %s (bound %s)" % (d, bound))
+    assert (d <= bound).all() and d.max() > 0 and d.max() < 2e-7 * 2.0

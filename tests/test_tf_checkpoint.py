@@ -116,3 +116,98 @@ def test_full_model_bundle_roundtrip(tmp_path):
     for k in ws.keys():
         assert np.array_equal(back[k], ws[k]), k
     assert tfc.get_checkpoint_state(os.path.dirname(prefix)) == prefix
+
+
+def test_step_recovery_from_a_bundle():
+    """the step comes from the `batch` variable; beta2_power is only a fallback and an underflowed
+    power never resets the schedule to step 0"""
+    import math
+    import pytest
+    pytest.importorskip("torch")
+    from disn_amd.train_sdf import step_from_checkpoint
+    b2 = 0.999
+    assert step_from_checkpoint({"batch": np.asarray(123456, np.int32), "beta2_power": np.float32(0.0)}, b2) == 123456
+    for t in (0, 1, 999, 50000):
+        assert step_from_checkpoint({"beta2_power": np.float32(b2 ** (t + 1))}, b2) == t
+    assert step_from_checkpoint({"beta2_power": np.float32(0.0)}, b2, current=0) >= 100000
+    assert step_from_checkpoint({"beta2_power": np.float32(0.0)}, b2, current=250000) == 250000
+    assert step_from_checkpoint({}, b2, current=7) == 7
+    assert np.float32(b2 ** 104000) == 0.0 and np.float32(b2 ** 99000) > 0   # where float32 gives up
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# A bundle assembled BY HAND from the TensorFlow format description (tensorflow/core/lib/io/{format,block_builder,
+# table_builder}.cc, tensor_bundle.proto, RFC 3720 CRC-32C) -- nothing below uses disn_amd.tf_checkpoint to build
+# the bytes; the reader has to read it, and the writer has to produce exactly these bytes.
+# ---------------------------------------------------------------------------------------------------------------
+def _kat_crc32c(data: bytes) -> int:
+    """bit-by-bit CRC-32C (reflected polynomial 0x82F63B78), independent of the module's table version"""
+    c = 0xFFFFFFFF
+    for byte in data:
+        c ^= byte
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+    return c ^ 0xFFFFFFFF
+
+
+def _kat_mask(c: int) -> int:           # crc32c.h: ((crc >> 15) | (crc << 17)) + 0xa282ead8
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _kat_block(body: bytes) -> bytes:   # block + trailer: compression type 0, masked crc over body + type
+    return body + b"\x00" + struct.pack("<I", _kat_mask(_kat_crc32c(body + b"\x00")))
+
+
+def _hand_assembled_bundle():
+    assert _kat_crc32c(b"123456789") == 0xE3069283 and _kat_crc32c(b"\x00" * 32) == 0x8A9136AA   # RFC 3720 B.4
+    t_ab = struct.pack("<2f", 1.0, -2.0)                    # 'a/b' float32 [2]
+    t_ac = struct.pack("<i", 7)                             # 'a/c' int32 scalar
+    data = t_ab + t_ac
+    header = bytes.fromhex("0801" "1a020801")                # num_shards = 1; version { producer: 1 }
+    e_ab = (bytes.fromhex("0801" "1204" "1202" "0802" "2808" "35")   # dtype DT_FLOAT; shape {dim {size: 2}}; size 8; crc32c:
+            + struct.pack("<I", _kat_mask(_kat_crc32c(t_ab))))
+    e_ac = (bytes.fromhex("0803" "1200" "2008" "2804" "35")          # DT_INT32; shape {}; offset 8; size 4
+            + struct.pack("<I", _kat_mask(_kat_crc32c(t_ac))))
+    body = b""
+    body += bytes([0, 0, len(header)]) + header                      # key "":   shared 0, non-shared 0
+    body += bytes([0, 3, len(e_ab)]) + b"a/b" + e_ab                 # key a/b:  shared 0, non-shared 3
+    body += bytes([2, 1, len(e_ac)]) + b"c" + e_ac                   # key a/c:  shared 2 ("a/"), non-shared 1
+    body += struct.pack("<II", 0, 1)                                 # restart offsets [0], count 1
+    data_block = _kat_block(body)
+    meta_block = _kat_block(struct.pack("<II", 0, 1))                # empty metaindex block
+    handle0 = bytes([0, len(body)])                                  # BlockHandle varints: offset 0, size
+    # index entry: key = FindShortSuccessor("a/c") = "b" (first byte incremented, rest dropped)
+    index_body = bytes([0, 1, len(handle0)]) + b"b" + handle0 + struct.pack("<II", 0, 1)
+    index_block = _kat_block(index_body)
+    meta_off = len(data_block)
+    index_off = meta_off + len(meta_block)
+    footer = bytes([meta_off, 8]) + bytes([index_off, len(index_body)])
+    footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57)
+    assert max(len(body), len(index_body), index_off) < 128           # every varint above is one byte
+    return data, data_block + meta_block + index_block + footer
+
+
+def test_reader_reads_a_hand_assembled_bundle(tmp_path):
+    data, index = _hand_assembled_bundle()
+    prefix = str(tmp_path / "kat.ckpt")
+    open(prefix + ".index", "wb").write(index)
+    open(prefix + ".data-00000-of-00001", "wb").write(data)
+    got = tfc.load_checkpoint(prefix)
+    assert sorted(got) == ["a/b", "a/c"]
+    assert got["a/b"].dtype == np.float32 and got["a/b"].tolist() == [1.0, -2.0]
+    assert got["a/c"].dtype == np.int32 and got["a/c"].shape == () and int(got["a/c"]) == 7
+    lv = tfc.list_variables(prefix)
+    assert lv[""]["num_shards"] == 1 and lv["a/c"]["offset"] == 8 and lv["a/b"]["shape"] == (2,)
+    bad = bytearray(index)
+    bad[10] ^= 1                                                      # inside the data block
+    open(prefix + ".index", "wb").write(bytes(bad))
+    with pytest.raises(ValueError):
+        tfc.load_checkpoint(prefix)
+
+
+def test_writer_produces_the_hand_assembled_bytes(tmp_path):
+    data, index = _hand_assembled_bundle()
+    prefix = str(tmp_path / "w.ckpt")
+    tfc.save_checkpoint(prefix, {"a/c": np.asarray(7, np.int32), "a/b": np.asarray([1.0, -2.0], np.float32)})
+    assert open(prefix + ".data-00000-of-00001", "rb").read() == data
+    assert open(prefix + ".index", "rb").read() == index
