@@ -115,6 +115,8 @@ SIGNATURES = {
     "disn_sdf_mlp": (I, [C.POINTER(MlpWeights), P, P, P, I, I, P, P, P, P, Z, P]),
     "disn_query_workspace_bytes": (Z, [I, I]),
     "disn_query": (I, [C.POINTER(MlpWeights), P, P, P, P, P, I, I, P, P, Z, P]),
+    "disn_stream_create": (I, [C.POINTER(C.c_void_p)]),
+    "disn_stream_destroy": (I, [P]),
     "disn_ctx_create": (I, [C.POINTER(C.c_void_p)]),
     "disn_ctx_destroy": (I, [P]),
     "disn_encode_workspace_bytes": (Z, [I]),

@@ -584,6 +584,21 @@ EncQueryWs encq_layout(void* ws, int B, int N, int num_classes) {
 
 extern "C" {
 
+int disn_stream_create(void** stream) {
+  if (!stream) return DISN_E_ARG;
+  hipStream_t st = nullptr;
+  DISN_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *stream = st;
+  return 0;
+}
+
+int disn_stream_destroy(void* stream) {
+  if (!stream) return DISN_E_ARG;
+  DISN_TRY(hipStreamSynchronize((hipStream_t)stream));
+  DISN_TRY(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+
 int disn_ctx_create(disn_ctx_t** out) {
   if (!out) return DISN_E_ARG;
   disn_ctx* c = new (std::nothrow) disn_ctx();

@@ -293,11 +293,38 @@ class StepPipeline:
     def __init__(self, store: WeightStore, device: Optional[torch.device] = None, in_flight: int = 3):
         import threading
         self._threading = threading
-        first = SdfEngine(store, device)
-        self.device = first.device
-        self.engines = [first] + [SdfEngine(None, self.device, weights=first.weights) for _ in range(in_flight - 1)]
+        # Stream / context creation ORDER matters: ROCm hands out its hardware queues (GPU_MAX_HW_QUEUES, default
+        # 4 including the null stream's) to streams in creation order and shares them afterwards, and two streams
+        # on one queue serialise.  So: for every step context its launch stream, then its disn_ctx_t (auxiliary
+        # stream), created back to back through the library -- not torch.cuda.Stream(), whose first use creates a
+        # pool of 64 streams and makes the assignment a lottery (0.35 ... 0.75 ms per step measured for one and
+        # the same program).  Measured with this order (tools/pipeline_try.py, one MI355X): default 4 queues
+        # 0.505 / 0.41 / 0.35 / 0.38 ms per step at 1 / 2 / 3 / 4 in flight; GPU_MAX_HW_QUEUES=8 is WORSE
+        # (0.50 / 0.45 / 0.45 at 2 / 3 / 4) -- leave the runtime's default.
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self._handles, self.streams, self.engines = [], [], []
+        weights = None
         with torch.cuda.device(self.device):
-            self.streams = [torch.cuda.Stream(self.device) for _ in self.engines]
+            for _ in range(in_flight):
+                h = ops.stream_create()
+                self._handles.append(h)
+                self.streams.append(torch.cuda.ExternalStream(h, device=self.device))
+                eng = SdfEngine(store if weights is None else None, self.device, weights=weights)
+                weights = eng.weights
+                self.engines.append(eng)
+
+    def __del__(self):
+        try:
+            with torch.cuda.device(self.device):
+                torch.cuda.synchronize(self.device)
+                self.engines = []
+                for h in self._handles:
+                    ops.stream_destroy(h)
+                self._handles = []
+        except Exception:  # interpreter shutdown
+            pass
 
     def run(self, jobs, keep_encoded: bool = False):
         """jobs: sequence of (imgs, pts, trans_mat[, pts_rot]) -> list of pred_sdf (or (Encoded, pred_sdf)) in

@@ -251,6 +251,18 @@ class ConvStackRun:
             self.pool5.data_ptr() if self.pool5 is not None else None, self.ws.data_ptr(), self.ws.numel(), _stream()))
 
 
+def stream_create() -> int:
+    """a non-blocking HIP stream on the current device (disn_stream_create) -> handle for torch.cuda.ExternalStream"""
+    h = C.c_void_p()
+    check("disn_stream_create", lib().disn_stream_create(C.byref(h)))
+    return h.value
+
+
+def stream_destroy(stream: int) -> None:
+    if stream:
+        check("disn_stream_destroy", lib().disn_stream_destroy(stream))
+
+
 def ctx_create() -> int:
     """Concurrency context (aux HIP stream + events) on the current device."""
     h = C.c_void_p()

@@ -272,6 +272,14 @@ int disn_query_folded(const disn_mlp_weights_t* w, const float* pmap, const floa
                       const float* trans_mat, const float* pts, const float* pts_rot, int B, int N,
                       float* sdf, void* ws, size_t ws_bytes, void* stream);
 
+/* A non-blocking HIP stream for a host that does not link HIP itself (hipStreamCreateWithFlags(hipStreamNonBlocking)
+ * on the current device).  disn_amd.engine.StepPipeline creates the streams of its step contexts with it, in a
+ * fixed order: ROCm hands out GPU_MAX_HW_QUEUES hardware queues (default 4, the null stream's included) in creation
+ * order and shares them afterwards, and streams that share a queue serialise -- a reproducible assignment instead
+ * of the lottery of a framework's stream pool. */
+int disn_stream_create(void** stream);
+int disn_stream_destroy(void* stream);
+
 /* ---------------------------------------------------------------------- *
  * Concurrency context.  The path mixes MFMA-bound launches (convolutions,  *
  * MLP GEMMs) with an HBM-bound one (the 495 MB fc6-fc8 weight stream) that *

@@ -12,8 +12,10 @@ img = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32)).cuda()
 pts = torch.rand((1, 2048, 3), device="cuda") * 2 - 1
 tm = torch.tensor([[[-68.453156, 5.5086656, -0.37556022], [-17.138561, -84.685486, -0.250198],
                     [-47.284092, -3.6569588, 0.2493176], [101.133705, 101.34268, 1.4305686]]], device="cuda")
+SHARE = os.environ.get("SHARE_WEIGHTS", "0") == "1"
 for S in [int(a) for a in sys.argv[1:]] or [1, 2, 3]:
-    engs = [SdfEngine(store) for _ in range(S)]
+    engs = [SdfEngine(store)]
+    engs += [SdfEngine(None, weights=engs[0].weights) if SHARE else SdfEngine(store) for _ in range(S - 1)]
     streams = [torch.cuda.Stream() for _ in range(S)]
     K = 240 // S
 
@@ -31,5 +33,5 @@ for S in [int(a) for a in sys.argv[1:]] or [1, 2, 3]:
     for t in th: t.join()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("S=%d: %.4f ms per step (%d steps), %.3g points/s" % (S, dt / (K * S) * 1e3, K * S, K * S * 2048 / dt), flush=True)
+    print("share=%d S=%d: %.4f ms per step (%d steps), %.3g points/s" % (SHARE, S, dt / (K * S) * 1e3, K * S, K * S * 2048 / dt), flush=True)
     del engs
