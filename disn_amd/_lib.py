@@ -14,7 +14,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # DISN_AMD_LIB: tools/ only -- points the binding at a tuning build (csrc/build.py --tuning), never set by the product
 LIB_PATH = os.environ.get("DISN_AMD_LIB") or os.path.join(HERE, "csrc", "libdisn_amd.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -48,10 +48,11 @@ MLP_X3_FIELDS = ("g_x2", "g_x3", "g_x4_point", "g_x5", "l_x2", "l_x3", "l_x4", "
 MLP_FOLD_FIELDS = ("l_w4_point", "l_w4_feat", "l_x4_point", "l_x4_feat")   # optional: *_folded entry points
 MLP_FUSED_FIELDS = ("g_fused", "l_fused")   # optional: *_fused entry points (disn_mlp_fused_pack images)
 MLP_T_FIELDS = ("g_w4_global_t",)           # optional: g_w4_global transposed [512][1024]
+MLP_D_FIELDS = ("g_d2", "g_d3", "g_d4_point", "g_d5", "l_d2", "l_d3", "l_d4", "l_d5")   # optional: dense_h2 images
 
 
 class MlpWeights(C.Structure):  # disn_mlp_weights_t
-    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS + MLP_X3_FIELDS + MLP_FOLD_FIELDS + MLP_FUSED_FIELDS + MLP_T_FIELDS]
+    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS + MLP_X3_FIELDS + MLP_FOLD_FIELDS + MLP_FUSED_FIELDS + MLP_T_FIELDS + MLP_D_FIELDS]
 
 
 CAM_FIELDS = tuple("%s_%s%d" % (t, k, i) for t in "srt" for i in (1, 2, 3) for k in "wb")
@@ -94,6 +95,10 @@ SIGNATURES = {
     "disn_maxpool2x2": (I, [P, I, I, I, I, P, P]),
     "disn_fc_workspace_bytes": (Z, [I, I, I]),
     "disn_fc": (I, [P, I, I, P, P, I, I, P, P, Z, P]),
+    "disn_pack_dense_h2_bytes": (Z, [I, I]),
+    "disn_pack_dense_h2": (I, [P, I, I, P, P]),
+    "disn_dense_h2_workspace_bytes": (Z, []),
+    "disn_dense_h2": (I, [P, I, I, P, I, I, P, I, P, P, I, I, P, P, P, Z, P]),
     "disn_get_loss": (I, [P, P, L, F, F, P, P]),
     "disn_fc_t": (I, [P, I, I, P, P, I, I, P, P]),
     "disn_dense_workspace_bytes": (Z, [I, I, I]),

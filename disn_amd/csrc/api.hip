@@ -109,6 +109,8 @@ int conv3x3_impl(const float* in, int B, int H, int W, int Cin, const float* w_p
 // ---- point MLP ----------------------------------------------------------------
 const int kChunk = 65536;  // points per MLP pass inside disn_query / disn_sdf_mlp
 
+const int kH2Imgs = 16;  // images per call the dense_h2 path keeps maximum slots for
+
 struct MlpWs {
   // local stream: e1l -> h256 -> h512a -> (with feat) h512b -> l5
   // global stream: e1g -> g256 -> g512 -> (with the folded bias) h512b -> g5
@@ -116,6 +118,12 @@ struct MlpWs {
   // split global fold2/conv1 (disn_encode_query): g512 . W4_point before the embedding exists, the
   // folded bias + ReLU once it does; the tail then runs beside phase 1, on its own GEMM scratch
   float *g4pre, *zero512, *gemm_ws2;
+  // dense_h2 path (small point sets): 16 x 64 activation-maximum slots, directly in front of zero512 so that the
+  // chain's first launch clears both in one go.  Slot groups: 0 e1g, 1 e1l, 2 g256, 3 h256, 4 g512, 5 h512a,
+  // 6 g4pre, 7 feat, 8 h512b (local fold2/conv1 out).  One set per image (the maxima are per image so that a
+  // batch gives every image exactly what it would get alone); sets 1 .. kH2Imgs - 1 follow zero512.
+  float* amax;
+  float* amax_more;
   size_t gemm_ws_bytes, total;
 };
 
@@ -153,7 +161,9 @@ MlpWs mlp_layout(Bump& b, int n, bool split_g4 = false) {
   w.gemm_ws_bytes = mlp_gemm_ws(n);
   w.gemm_ws = b.take(w.gemm_ws_bytes);
   w.g4pre = split_g4 ? b.take((size_t)n * 512 * f) : nullptr;
+  w.amax = b.take(16 * 64 * f);
   w.zero512 = b.take(512 * f);
+  w.amax_more = b.take((size_t)(kH2Imgs - 1) * 16 * 64 * f);
   w.gemm_ws2 = split_g4 ? b.take(w.gemm_ws_bytes) : nullptr;
   w.total = b.off;
   return w;
@@ -171,6 +181,74 @@ bool mlp_weights_ok(const disn_mlp_weights_t* w) {
 // wherever the caller supplied the 3-plane weight image
 bool x3_enabled() { return tune::x3 != 0; }
 
+// The point-MLP layers of a SMALL point set (a few thousand rows: launch- and latency-bound in the GEMM kernels)
+// through dense_h2.hip when the weights carry its images: one short launch per layer, the two streams' same-shaped
+// layers paired in one launch, the per-image bias + ReLU of the split global fold2/conv1 applied by the consumer.
+bool mlp_h2(const disn_mlp_weights_t* w, long n) {
+  return x3_enabled() && n < 8192 && w->g_d2 && w->g_d3 && w->g_d4_point && w->g_d5 && w->l_d2 && w->l_d3 &&
+         w->l_d4 && w->l_d5;
+}
+
+DenseH2Prob h2_prob(const float* a, int K, const void* img, const float* bias, int N, int relu, const float* in_amax,
+                    float* out, float* out_amax, int n) {
+  DenseH2Prob p{};
+  p.a = a; p.lda = K; p.k1 = K; p.wimg = static_cast<const unsigned char*>(img); p.bias = bias;
+  p.in_amax = in_amax; p.out = out; p.ldc = N; p.out_amax = out_amax; p.M = n; p.N = N; p.K = K; p.relu = relu;
+  return p;
+}
+
+// Slot set of image b; rows of image b start at row o in every per-point buffer.  All h2 phases work on ONE image
+// (n rows): the activation maxima -- hence the scales, hence every bit of the result -- do not depend on what else
+// is in the batch or on which entry point runs the layers.
+float* h2_slots(const MlpWs& s, int b) { return b == 0 ? s.amax : s.amax_more + (size_t)(b - 1) * 1024; }
+
+// fold1 of BOTH streams: embedding (+ its maxima, + clearing the later layers' slots and, for image 0, the zero
+// bias row behind them), then conv2 and conv3 of the two streams as two paired launches
+int mlp_fold1_h2(const disn_mlp_weights_t* w, const float* pts_rot, int n, const MlpWs& s, int b, size_t o,
+                 hipStream_t st) {
+  float* A = h2_slots(s, b);
+  DISN_TRY(pt_embed_launch(pts_rot, n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g + o * 64, s.e1l + o * 64, st, A, A + 128,
+                           14 * 64 + (b == 0 ? 512 : 0)));
+  DenseH2Prob p2[2] = {h2_prob(s.e1g + o * 64, 64, w->g_d2, w->g_b2, 256, 1, A + 0, s.g256 + o * 256, A + 128, n),
+                       h2_prob(s.e1l + o * 64, 64, w->l_d2, w->l_b2, 256, 1, A + 64, s.h256 + o * 256, A + 192, n)};
+  DISN_TRY(dense_h2_launch(p2, 2, st));
+  DenseH2Prob p3[2] = {h2_prob(s.g256 + o * 256, 256, w->g_d3, w->g_b3, 512, 1, A + 128, s.g512 + o * 512, A + 256, n),
+                       h2_prob(s.h256 + o * 256, 256, w->l_d3, w->l_b3, 512, 1, A + 192, s.h512a + o * 512, A + 320, n)};
+  DISN_TRY(dense_h2_launch(p3, 2, st));
+  return 0;
+}
+
+// the point half of the global fold2/conv1: g512 . W4_point, no bias, no ReLU -> `pre` (+ its maximum)
+int mlp_g4_pre_h2(const disn_mlp_weights_t* w, int n, const MlpWs& s, int b, size_t o, float* pre, hipStream_t st) {
+  float* A = h2_slots(s, b);
+  const DenseH2Prob p = h2_prob(s.g512 + o * 512, 512, w->g_d4_point, s.zero512, 512, 0, A + 256, pre, A + 384, n);
+  DISN_TRY(dense_h2_launch(&p, 1, st));
+  return 0;
+}
+
+// local fold2/conv1 on [h512a | feat] read in place, fold2/conv2
+int mlp_phase1_h2(const disn_mlp_weights_t* w, int n, const float* feat, const MlpWs& s, int b, size_t o,
+                  hipStream_t st) {
+  float* A = h2_slots(s, b);
+  DISN_TRY(amax64_accumulate_launch(feat, (size_t)n * DISN_FEAT_DIM, A + 448, st));
+  DenseH2Prob p4 = h2_prob(s.h512a + o * 512, 512 + DISN_FEAT_DIM, w->l_d4, w->l_b4, 512, 1, A + 320, s.h512b + o * 512,
+                           A + 512, n);
+  p4.lda = 512; p4.k1 = 512; p4.a2 = feat; p4.lda2 = DISN_FEAT_DIM; p4.in_amax2 = A + 448;
+  DISN_TRY(dense_h2_launch(&p4, 1, st));
+  const DenseH2Prob p5 = h2_prob(s.h512b + o * 512, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5 + o * 256, nullptr, n);
+  DISN_TRY(dense_h2_launch(&p5, 1, st));
+  return 0;
+}
+
+// global fold2/conv2 on relu(pre + this image's bias row): the deferred bias + ReLU
+int mlp_g5_h2(const disn_mlp_weights_t* w, int n, const float* pre, const float* gbias_b, const MlpWs& s, int b, size_t o,
+              hipStream_t st) {
+  DenseH2Prob p = h2_prob(pre, 512, w->g_d5, w->g_b5, 256, 1, h2_slots(s, b) + 384, s.g5 + o * 256, nullptr, n);
+  p.in_bias = gbias_b;
+  DISN_TRY(dense_h2_launch(&p, 1, st));
+  return 0;
+}
+
 int dense_layer(const float* a1, int lda1, int k1, const float* a2, int lda2, int K, int n,
                 const float* bp, const float* bias, int N, float* out, float* ws, size_t ws_bytes,
                 hipStream_t st, const void* x3 = nullptr, int relu = 1) {
@@ -184,6 +262,10 @@ int dense_layer(const float* a1, int lda1, int k1, const float* a2, int lda2, in
   // the three-term kernel wins from ~8k rows on, and on the 1984-deep layer always (42 vs 54 us)
   if (x3 && x3_enabled() && (n >= 8192 || K >= 1024)) {
     DISN_TRY(gemm_bf16_launch(p, GEMM_DENSE, x3, ws, ws ? ws_bytes : 0, st, 3));
+    return 0;
+  }
+  if (x3 && x3_enabled() && tune::small_x3 && K >= 256) {  // experiment: no split-K, one launch
+    DISN_TRY(gemm_bf16_launch(p, GEMM_DENSE, x3, nullptr, 0, st, 3));
     return 0;
   }
   const GemmPlan pl = gemm_plan(n, N, K, ws ? ws_bytes : 0);
@@ -289,6 +371,14 @@ int mlp_chunk(const disn_mlp_weights_t* w, const float* pts_rot, int n, const fl
               const float* feat, float* sdf, float* sdf_g, float* sdf_l, float out_div,
               const MlpWs& s, hipStream_t st) {
   int rc;
+  if (mlp_h2(w, n)) {  // the same launches as disn_encode_query, on one stream (bit-identical results)
+    if ((rc = mlp_fold1_h2(w, pts_rot, n, s, 0, 0, st))) return rc;
+    if ((rc = mlp_phase1_h2(w, n, feat, s, 0, 0, st))) return rc;
+    if ((rc = mlp_g4_pre_h2(w, n, s, 0, 0, s.h512a, st))) return rc;   // h512a is free once the local fold2/conv1 ran
+    if ((rc = mlp_g5_h2(w, n, s.h512a, gbias, s, 0, 0, st))) return rc;
+    DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, sdf_g, sdf_l, out_div, st));
+    return 0;
+  }
   if ((rc = mlp_phase0(w, pts_rot, n, s, st))) return rc;
   if ((rc = mlp_phase1(w, n, feat, s, st))) return rc;
   return mlp_phase2(w, 1, n, gbias, sdf, sdf_g, sdf_l, out_div, s, st);
@@ -710,6 +800,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   // fold2/conv1 -- ~45 us of small launches beside resize / conv1_1 / conv1_2 (VALU work and a two-round kernel,
   // measured unaffected) -- then, behind conv5_3, the LOCAL stream's fold1, the gather and fold2 under the fc head.
   const float* pool5 = nullptr;
+  const bool h2 = two && B <= kH2Imgs && mlp_h2(mw, N);   // small point sets: the dense_h2 layers, image by image
   if (two) {
     DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (orders aux behind the caller's inputs)
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
@@ -717,16 +808,24 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     // the auxiliary stream its launches, then the rest of the stack
     rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 0, 2);
     if (rc) return rc;
-    DISN_TRY(pt_embed_launch(pts_rot, B * N, mw->g_w1, mw->g_b1, mw->l_w1, mw->l_b1, e.q.mlp.e1g, e.q.mlp.e1l, ctx->aux));
-    if ((rc = mlp_fold1_global(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws2, ctx->aux))) return rc;
-    if ((rc = mlp_g4_pre(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws2, ctx->aux))) return rc;
+    if (h2) {  // per image: fold1 of both streams (paired launches) and the point half of the global fold2/conv1
+      for (int b = 0; b < B; ++b) {
+        const size_t o = (size_t)b * N;
+        if ((rc = mlp_fold1_h2(mw, pts_rot + o * 3, N, e.q.mlp, b, o, ctx->aux))) return rc;
+        if ((rc = mlp_g4_pre_h2(mw, N, e.q.mlp, b, o, e.q.mlp.g4pre + o * 512, ctx->aux))) return rc;
+      }
+    } else {
+      DISN_TRY(pt_embed_launch(pts_rot, B * N, mw->g_w1, mw->g_b1, mw->l_w1, mw->l_b1, e.q.mlp.e1g, e.q.mlp.e1l, ctx->aux));
+      if ((rc = mlp_fold1_global(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws2, ctx->aux))) return rc;
+      if ((rc = mlp_g4_pre(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws2, ctx->aux))) return rc;
+    }
     DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
     rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 2, 13);
     if (rc) return rc;
     DISN_TRY(hipEventRecord(ctx->ev[7], st));
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
     DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));  // next to the ev[7] record, where `st` drains anyway
-    if ((rc = mlp_fold1_local(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws, ctx->aux))) return rc;
+    if (!h2 && (rc = mlp_fold1_local(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws, ctx->aux))) return rc;
   } else {
     rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st);
     if (rc) return rc;
@@ -742,12 +841,27 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   } else {  // no map: up-sample the taps at the touched pixels (bit-identical), all images in one launch
     DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, ms));
   }
-  if ((rc = mlp_phase1(mw, B * N, e.q.feat, e.q.mlp, ms))) return rc;
+  if (h2) {
+    for (int b = 0; b < B; ++b) {
+      const size_t o = (size_t)b * N;
+      if ((rc = mlp_phase1_h2(mw, N, e.q.feat + o * DISN_FEAT_DIM, e.q.mlp, b, o, ms))) return rc;
+    }
+  } else if ((rc = mlp_phase1(mw, B * N, e.q.feat, e.q.mlp, ms))) return rc;
   if (two) {
     DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
   { const int grc = gbias_layer(mw, embedding, B, e.q.gbias, e.q.gemv_ws, st); if (grc) return grc; }
+  if (h2) {  // global fold2/conv2 on relu(pre + bias) per image, then -- behind ev[6] -- both fold2/conv5 and the sum
+    for (int b = 0; b < B; ++b) {
+      const size_t o = (size_t)b * N;
+      if ((rc = mlp_g5_h2(mw, N, e.q.mlp.g4pre + o * 512, e.q.gbias + (size_t)b * 512, e.q.mlp, b, o, st))) return rc;
+    }
+    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
+    DISN_TRY(final_dot_launch(e.q.mlp.g5, e.q.mlp.l5, (int64_t)B * N, mw->g_w6, mw->g_b6, mw->l_w6, mw->l_b6, sdf, nullptr,
+                              nullptr, 1.0f, st));
+    return 0;
+  }
   if (two)  // bias + ReLU of the split layer, fold2/conv2, then -- behind ev[6] -- the final sum
     return mlp_phase2_split(mw, B, N, e.q.gbias, sdf, e.q.mlp, st, ctx->ev[6]);
   return mlp_phase2(mw, B, N, e.q.gbias, sdf, nullptr, nullptr, 1.0f, e.q.mlp, st);
@@ -1140,6 +1254,7 @@ namespace tune {
 int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0;
 int gemm_force[3] = {0, 0, 0};
 int gemv_wgs = 0;
+int small_x3 = 0;
 long long* ch2_stamps = nullptr;
 }
 }  // namespace disn
@@ -1151,10 +1266,10 @@ extern "C" int disn_tuning_set_ptr(int key, void* p) {
 // tuning builds only (build.py --tuning -> libdisn_amd_tuning.so): 0 x3, 1 overlap, 2 bf_splits, 3 skip_pack,
 // 4 fused_safe
 extern "C" int disn_tuning_set(int key, int value) {
-  int* k[9] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
-               &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
-               &disn::tune::gemm_force[2], &disn::tune::gemv_wgs};
-  if (key < 0 || key > 8) return DISN_E_ARG;
+  int* k[10] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
+                &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
+                &disn::tune::gemm_force[2], &disn::tune::gemv_wgs, &disn::tune::small_x3};
+  if (key < 0 || key > 9) return DISN_E_ARG;
   *k[key] = value;
   return 0;
 }

@@ -33,13 +33,14 @@ SOURCES = {
     "mlp_small.hip": [],
     "mlp_fused.hip": [],
     "conv_h2.hip": [],
+    "dense_h2.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],
     "marching_cubes.hip": ["-ffp-contract=off"],
     "api.hip": [],
     "host_util.cpp": ["-msse4.2"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-HEADERS = ["kernels.hpp", "tuning.hpp", "mc_tables.h", os.path.join(ROOT, "include", "disn_amd.h")]
+HEADERS = ["kernels.hpp", "tuning.hpp", "h2_common.hpp", "mc_tables.h", os.path.join(ROOT, "include", "disn_amd.h")]
 
 
 def _digest(paths, extra=""):

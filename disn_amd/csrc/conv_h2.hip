@@ -38,34 +38,12 @@
 // lane (j, g) and register quad q the four consecutive logical rows L0(q, g) .. L0 + 3 of column j.
 #include "kernels.hpp"
 #include "tuning.hpp"
+#include "h2_common.hpp"
 
 #include <type_traits>
 
 namespace disn {
 
-typedef _Float16 ch_h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 ch_h4 __attribute__((ext_vector_type(4)));
-typedef float ch_f16v __attribute__((ext_vector_type(16)));
-
-namespace ch2 {
-// power of two s with amax * s in [2^target, 2^(target+1)); 1 for amax == 0 / non-finite / extreme
-__host__ __device__ inline float pow2_scale(float amax, int target_exp) {
-  union { float f; unsigned u; } a;
-  a.f = amax;
-  const int e = (int)((a.u >> 23) & 0xffu) - 127;
-  if (!(amax > 0.f) || e > 100 || e < -100) return 1.0f;
-  a.u = (unsigned)(127 + target_exp - e) << 23;
-  return a.f;
-}
-// logical row of hardware row i (0..31) of a 32-row block
-__host__ __device__ constexpr int sigma(int i) {
-  return i < 4 ? i : (i < 12 ? i + 12 : (i < 16 ? i - 8 : (i < 20 ? i + 8 : (i < 28 ? i - 12 : i))));
-}
-// first logical row of the four held by accumulator quad q (registers 4q..4q+3) of lane half g
-__host__ __device__ constexpr int quad_row(int q, int g) {
-  return sigma(8 * q + 4 * g);
-}
-}  // namespace ch2
 
 // ---------------------------------------------------------------------------------------------------
 // weight image: for n-block nb (32 output channels), k16 block kb (input channels 16 kb .. 16 kb + 15), tap t:
@@ -74,23 +52,23 @@ __host__ __device__ constexpr int quad_row(int q, int g) {
 // contiguous 18 KiB -- what one k-wave reads per chunk, whatever the number of k-waves.  Behind the image:
 // {s_w, 1 / s_w}.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restrict__ w, int Cin, int Cout,
+__global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int taps,
                                                            const float* __restrict__ amax,
                                                            unsigned char* __restrict__ image) {
   const int KB = Cin >> 4;
-  const size_t frags = (size_t)(Cout >> 5) * KB * 9;
+  const size_t frags = (size_t)(Cout >> 5) * KB * taps;
   const float s = ch2::pow2_scale(amax[0], 13);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float* meta = reinterpret_cast<float*>(image + (size_t)Cin * 9 * Cout * 4);
+    float* meta = reinterpret_cast<float*>(image + (size_t)Cin * taps * Cout * 4);
     meta[0] = s;
     meta[1] = 1.0f / s;
   }
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < frags * 64; idx += (size_t)gridDim.x * 256) {
     const int lane = (int)(idx & 63);
     const size_t f = idx >> 6;
-    const int t = (int)(f % 9);
-    const int kb = (int)((f / 9) % KB);
-    const int nb = (int)(f / ((size_t)9 * KB));
+    const int t = (int)(f % taps);
+    const int kb = (int)((f / taps) % KB);
+    const int nb = (int)(f / ((size_t)taps * KB));
     const int j = lane & 31, g = lane >> 5;
     ch_h8 hi, lo;
 #pragma unroll
@@ -111,10 +89,11 @@ size_t conv_h2_image_bytes(int Cin, int Cout) { return (size_t)Cin * 9 * Cout * 
 
 #ifndef CH2_UBENCH
 // w: TF HWIO [3][3][Cin][Cout]; scratch: one float (max |w|)
-hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, float* scratch, hipStream_t st) {
-  hipError_t e = amax_launch(w, (size_t)9 * Cin * Cout, scratch, st);
+hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, float* scratch, hipStream_t st,
+                               int taps) {
+  hipError_t e = amax_launch(w, (size_t)taps * Cin * Cout, scratch, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(conv_h2_pack_kernel, dim3(1024), dim3(256), 0, st, w, Cin, Cout, scratch,
+  hipLaunchKernelGGL(conv_h2_pack_kernel, dim3(1024), dim3(256), 0, st, w, Cin, Cout, taps, scratch,
                      static_cast<unsigned char*>(image));
   return hipGetLastError();
 }

@@ -236,6 +236,8 @@ hipError_t mlp_fused_pack_launch(const float* w2, const float* w3, const float* 
 hipError_t amax_launch(const float* x, size_t n, float* out, hipStream_t st);  // n % 4 == 0
 // the same into 64 slots (their maximum is max |x|) / the maximum of 64 slots -> out[0]
 hipError_t amax64_launch(const float* x, size_t n, float* out64, hipStream_t st);
+// the same without clearing the slots first (the caller's chain cleared them): one launch
+hipError_t amax64_accumulate_launch(const float* x, size_t n, float* out64, hipStream_t st);
 hipError_t amax_fold_launch(const float* slots64, float* out, hipStream_t st);
 // one stream for n points of one image; pts_rot == nullptr: points k0.. of `grid`.  local: gather from
 // pmap + 'sdfprediction_imgfeat', out = (add_in + sum) / out_div; global: 'sdfprediction' with b4 = the
@@ -248,8 +250,10 @@ hipError_t mlp_fused_launch(bool local, const void* image, const float* w1, cons
 
 // ---- conv_h2.hip: the single-image 3x3 convolution (two-term f16 split, halo in LDS, K parallel inside the workgroup) ----
 size_t conv_h2_image_bytes(int Cin, int Cout);
-// w: TF HWIO [3][3][Cin][Cout]; scratch: one device float
-hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, float* scratch, hipStream_t st);
+// w: TF HWIO [3][3][Cin][Cout] (taps = 9) or a [K = Cin][N = Cout] matrix (taps = 1, dense_h2.hip); scratch: one
+// device float; the image holds taps * Cin * Cout * 4 + 256 bytes
+hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, float* scratch, hipStream_t st,
+                               int taps = 9);
 bool conv_h2_supported(int H, int W, int Cin, int Cout);  // Cin, Cout multiples of 64
 // in_amax: 64 floats whose maximum is max |in|; out_amax (optional, 64 floats zeroed by the caller): atomic
 // max |out| spread over the slots; pool_out
@@ -262,11 +266,38 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
 hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu,
                                  float* out, float* out_amax, hipStream_t st);
 
+// ---- dense_h2.hip: the point-MLP layers at a few thousand rows (two-term f16 split, 1x1 sibling of conv_h2) ----
+struct DenseH2Prob {     // out[M][N] = act(f(A) . W + bias), A = [a (k1 columns) | a2 (K - k1)], f = relu(. + in_bias) or identity
+  const float* a;
+  int lda;
+  const float* a2;       // nullptr: one source (k1 == K)
+  int lda2, k1;
+  const float* in_bias;  // [K] (or [images][K] with in_bias_rows) or nullptr
+  int in_bias_rows;      // > 0: row m uses in_bias row m / in_bias_rows (a per-image bias, rows image-major)
+  const unsigned char* wimg;  // conv_h2_pack_launch(w [K][N], K, N, ..., taps = 1)
+  const float* bias;     // [N]
+  const float* in_amax;  // 64 slots: max |a|
+  const float* in_amax2; // 64 slots: max |a2| (nullptr with one source)
+  float* out;
+  int ldc;
+  float* out_amax;       // 64 slots (zeroed by the caller) or nullptr
+  int M, N, K, relu;
+};
+struct DenseH2Dev {
+  DenseH2Prob p[2];
+  int nprob, mtiles;
+};
+bool dense_h2_supported(int M, int K, int N, int k1);  // K, N multiples of 64; k1 a multiple of the chunk (256 when K % 256 == 0, else 64)
+// one or two problems of ONE shape in one launch (the same layer of the global and the local stream)
+hipError_t dense_h2_launch(const DenseH2Prob* probs, int nprob, hipStream_t st);
+
 // ---- mlp_small.hip ---------------------------------------------------------
 // relu(p . W1 + b1) for both streams: pts [M][3] -> out_g [M][64], out_l [M][64]
+// amax_gl (optional): 128 floats, [0..63] slots of max |out_g|, [64..127] of max |out_l| (dense_h2.hip reads the
+// maximum over the slots); zero / nzero (optional): floats this launch also clears
 hipError_t pt_embed_launch(const float* pts, int64_t M, const float* g_w1, const float* g_b1,
                            const float* l_w1, const float* l_b1, float* out_g, float* out_l,
-                           hipStream_t st);
+                           hipStream_t st, float* amax_gl = nullptr, float* zero = nullptr, int nzero = 0);
 // sdf[m] = (g5[m].g_w6 + g_b6) + (l5[m].l_w6 + l_b6); optional separate outputs
 hipError_t final_dot_launch(const float* g5, const float* l5, int64_t M, const float* g_w6,
                             const float* g_b6, const float* l_w6, const float* l_b6, float* sdf,

@@ -185,9 +185,11 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   }
 }
 
-static hipError_t amax_go(const float* x, size_t n, float* out, int slots, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(out, 0, slots * sizeof(float), st);
-  if (e != hipSuccess) return e;
+static hipError_t amax_go(const float* x, size_t n, float* out, int slots, hipStream_t st, bool clear = true) {
+  if (clear) {
+    const hipError_t e = hipMemsetAsync(out, 0, slots * sizeof(float), st);
+    if (e != hipSuccess) return e;
+  }
   const size_t n4 = n / 4;
   const int grid = (int)(n4 < 512 * 256 ? (n4 + 255) / 256 : 512);
   hipLaunchKernelGGL(amax_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, x, n4, out, slots);
@@ -196,6 +198,9 @@ static hipError_t amax_go(const float* x, size_t n, float* out, int slots, hipSt
 hipError_t amax_launch(const float* x, size_t n, float* out, hipStream_t st) { return amax_go(x, n, out, 1, st); }
 // the 64-slot form the conv_h2 kernels read (max over the slots = max |x|)
 hipError_t amax64_launch(const float* x, size_t n, float* out64, hipStream_t st) { return amax_go(x, n, out64, 64, st); }
+hipError_t amax64_accumulate_launch(const float* x, size_t n, float* out64, hipStream_t st) {
+  return amax_go(x, n, out64, 64, st, false);
+}
 
 __global__ void amax_fold_kernel(const float* __restrict__ slots64, float* __restrict__ out) {
   float m = slots64[threadIdx.x];

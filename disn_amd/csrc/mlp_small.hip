@@ -12,9 +12,15 @@ __global__ __launch_bounds__(256) void pt_embed_kernel(const float* __restrict__
                                                        const float* __restrict__ l_w1,
                                                        const float* __restrict__ l_b1,
                                                        float* __restrict__ out_g,
-                                                       float* __restrict__ out_l) {
+                                                       float* __restrict__ out_l,
+                                                       float* __restrict__ amax_gl,
+                                                       float* __restrict__ zero, int nzero) {
+  // side job of the first launch of a point-MLP chain (dense_h2.hip layers): clear the activation-maximum slots
+  // of the layers behind it and the all-zero bias row
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) zero[i] = 0.f;
   // thread -> (point, 4 channels of one stream): 32 threads per point (16 per stream)
   const int64_t total = M * 32;
+  float mx = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i >> 5;
@@ -34,17 +40,40 @@ __global__ __launch_bounds__(256) void pt_embed_kernel(const float* __restrict__
     o.z = fmaxf(x * w0.z + y * w1.z + z * w2.z + b4.z, 0.f);
     o.w = fmaxf(x * w0.w + y * w1.w + z * w2.w + b4.w, 0.f);
     *reinterpret_cast<float4*>((local ? out_l : out_g) + m * 64 + c) = o;
+    mx = fmaxf(fmaxf(fmaxf(mx, o.x), o.y), fmaxf(o.z, o.w));
+  }
+  if (amax_gl) {
+    // the maximum of each stream's output, one slot per workgroup (gridDim.x <= 64; the launcher clears nothing:
+    // slots of absent workgroups are written 0 by workgroup 0): amax_gl[0..63] global, [64..127] local.
+    // blockDim.x * gridDim.x is a multiple of 32, so a thread serves ONE stream for all its points.
+    __shared__ float red[2][4];
+    const bool local = (threadIdx.x & 31) >= 16;
+    float mg = local ? 0.f : mx, ml = local ? mx : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      mg = fmaxf(mg, __shfl_xor(mg, off));
+      ml = fmaxf(ml, __shfl_xor(ml, off));
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mg; red[1][threadIdx.x >> 6] = ml; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      const int st = threadIdx.x;
+      amax_gl[64 * st + blockIdx.x] = fmaxf(fmaxf(red[st][0], red[st][1]), fmaxf(red[st][2], red[st][3]));
+      if (blockIdx.x == 0)
+        for (int i = gridDim.x; i < 64; ++i) amax_gl[64 * st + i] = 0.f;
+    }
   }
 }
 
 hipError_t pt_embed_launch(const float* pts, int64_t M, const float* g_w1, const float* g_b1,
                            const float* l_w1, const float* l_b1, float* out_g, float* out_l,
-                           hipStream_t st) {
+                           hipStream_t st, float* amax_gl, float* zero, int nzero) {
   int64_t blocks = (M * 32 + 255) / 256;
   if (blocks > 16384) blocks = 16384;
+  if (amax_gl && blocks > 64) blocks = 64;  // one maximum slot per workgroup
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(pt_embed_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pts, M, g_w1, g_b1,
-                     l_w1, l_b1, out_g, out_l);
+                     l_w1, l_b1, out_g, out_l, amax_gl, zero, nzero);
   return hipGetLastError();
 }
 

@@ -93,6 +93,14 @@ class DeviceWeights:
             img = ops.mlp_fused_pack(dev(W(scope, "fold1/conv2")), dev(W(scope, "fold1/conv3")), dev(w4[:512]),
                                      dev(W(scope, "fold2/conv2")))
             setattr(m, pre + "_fused", self._hold(img).data_ptr())
+        # dense_h2.hip images (two-term f16): the layers of a small point set (the 2048-point step), one launch each
+        def d2(a):
+            return self._hold(ops.pack_dense_h2(dev(a))).data_ptr()
+
+        m.g_d2, m.g_d3, m.g_d4_point, m.g_d5 = (d2(W(g, "fold1/conv2")), d2(W(g, "fold1/conv3")), d2(w4g[:512]),
+                                                d2(W(g, "fold2/conv2")))
+        m.l_d2, m.l_d3, m.l_d4, m.l_d5 = (d2(W(l, "fold1/conv2")), d2(W(l, "fold1/conv3")), d2(w4l),
+                                          d2(W(l, "fold2/conv2")))
         for f in MLP_FIELDS:
             assert getattr(m, f), f
         self.mlp = m

@@ -169,6 +169,34 @@ def fc(x: torch.Tensor, w_kn: torch.Tensor, bias: torch.Tensor, relu: bool) -> t
     return out
 
 
+def pack_dense_h2(w_kn: torch.Tensor) -> torch.Tensor:
+    """disn_pack_dense_h2: W [K,N] -> the two-term f16 weight image of dense_h2.hip"""
+    w = _chk(w_kn, "w_kn")
+    K, N = w.shape
+    nbytes = lib().disn_pack_dense_h2_bytes(K, N)
+    if nbytes == 0:
+        raise ValueError("pack_dense_h2: K and N must be multiples of 64, got %d, %d" % (K, N))
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check("disn_pack_dense_h2", lib().disn_pack_dense_h2(w.data_ptr(), K, N, out.data_ptr(), _stream()))
+    return out
+
+
+def dense_h2(a1: torch.Tensor, image: torch.Tensor, bias: torch.Tensor, n_out: int, relu: bool = True,
+             a2: Optional[torch.Tensor] = None, in_bias: Optional[torch.Tensor] = None, want_amax: bool = False):
+    """disn_dense_h2: act(f([a1 | a2]) @ W + b), f = relu(. + in_bias) when in_bias is given"""
+    a1 = _chk(a1, "a1")
+    M, k1 = a1.shape
+    k2 = 0 if a2 is None else _chk(a2, "a2").shape[1]
+    out = torch.empty((M, n_out), dtype=torch.float32, device=a1.device)
+    amax = torch.zeros(1, dtype=torch.float32, device=a1.device) if want_amax else None
+    ws = _ws(lib().disn_dense_h2_workspace_bytes(), a1.device)
+    check("disn_dense_h2", lib().disn_dense_h2(
+        a1.data_ptr(), k1, k1, a2.data_ptr() if a2 is not None else None, k2, k2,
+        in_bias.data_ptr() if in_bias is not None else None, M, image.data_ptr(), bias.data_ptr(), n_out, int(relu),
+        out.data_ptr(), amax.data_ptr() if want_amax else None, ws.data_ptr(), ws.numel(), _stream()))
+    return (out, amax) if want_amax else out
+
+
 def get_loss(pred: torch.Tensor, gt: torch.Tensor, sdf_weight: float, mask_weight: float,
              regularization: float = 0.0) -> torch.Tensor:
     """disn_get_loss -> 5 device floats {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}"""

@@ -38,7 +38,7 @@ extern "C" {
 #define DISN_E_WS (-3)    /* workspace too small */
 
 /* ABI version of this header; disn_abi_version() returns the library's. */
-#define DISN_ABI_VERSION 5
+#define DISN_ABI_VERSION 6
 int disn_abi_version(void);
 
 /* ---------------------------------------------------------------------- *
@@ -164,6 +164,20 @@ int disn_fc_t(const float* x, int B, int K, const float* wt_nk, const float* bia
  * (the tf.concat(axis=3) of models/sdfnet.py:82,180 is read in place, never materialised).
  * k1, k2 multiples of 32 (k2 may be 0 with a2 NULL), N a multiple of 64,
  * w_packed = disn_pack_kn of W [k1+k2][N].  fp32 MFMA. */
+/* The same primitive for a few thousand rows (dense_h2.hip): fp32-accurate products from a two-term f16 split on
+ * the f16 MFMA pipes, one short launch, no split-K pass.  disn_pack_dense_h2: W [K][N] row-major (K, N multiples of
+ * 64) -> weight image (disn_pack_dense_h2_bytes).  disn_dense_h2: out = act(f([a1 | a2]) . W + bias) with
+ * f = relu(. + in_bias[k]) when in_bias != NULL (the deferred bias + ReLU of a layer whose product was formed before
+ * its bias existed), else the identity; lda1 == k1, lda2 == k2 (the rows' maxima are measured over the whole
+ * buffers); k1 a multiple of 256 when K = k1 + k2 is, else of 64.  Optional out_amax = max |out|.
+ * ws: disn_dense_h2_workspace_bytes(). */
+size_t disn_pack_dense_h2_bytes(int K, int N);
+int disn_pack_dense_h2(const float* w_kn, int K, int N, void* image, void* stream);
+size_t disn_dense_h2_workspace_bytes(void);
+int disn_dense_h2(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, const float* in_bias, int M,
+                  const void* image, const float* bias, int N, int relu, float* out, float* out_amax, void* ws,
+                  size_t ws_bytes, void* stream);
+
 /* Row K: the scalars of get_loss (models/model_normalization.py:273-299, regression branch) in one launch:
  * out5 = {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}; pred [M] = pred_sdf
  * (un-divided), gt [M] = ref_sdf; out5[3] is READ (the caller's wd/2 * sum w^2, 0 without regularization) and
@@ -233,6 +247,11 @@ typedef struct disn_mlp_weights {
   const void *g_fused, *l_fused;
   /* optional: g_w4_global transposed, [512][1024] row-major -- the per-image bias fold as one launch (see fc_w_t) */
   const float* g_w4_global_t;
+  /* optional (all eight or none): disn_pack_dense_h2 images of fold1/conv2, fold1/conv3, the point rows of the global
+   * fold2/conv1 and fold2/conv2 of the global stream, and of fold1/conv2, fold1/conv3, the WHOLE local fold2/conv1
+   * [1984][512] and fold2/conv2 of the local stream.  With them a point set of fewer than 8192 points per image runs
+   * its layers through dense_h2.hip (disn_encode_query, disn_query, disn_sdf_mlp): one short launch per layer. */
+  const void *g_d2, *g_d3, *g_d4_point, *g_d5, *l_d2, *l_d3, *l_d4, *l_d5;
 } disn_mlp_weights_t;
 
 /* scratch for one launch over B images x N points (N per image) */

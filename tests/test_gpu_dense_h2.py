@@ -1,0 +1,94 @@
+"""GPU parity of the small-batch point-MLP layer (disn_amd/csrc/dense_h2.hip, through the C ABI) against float64:
+the layer shapes of models/sdfnet.py:71-88,173-186 at a 2048-point batch, ragged row counts, the two-source
+(tf.concat read in place) form, the deferred bias + ReLU on load, run-to-run reproducibility."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import report_close
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from disn_amd import ops as _ops
+    return _ops
+
+
+def case(M, K, N, seed, positive=True):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    if positive:
+        a = np.maximum(a, 0) * 1.5
+    w = (rng.standard_normal((K, N)) * np.sqrt(2.0 / K)).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    return a, w, b
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(2048, 64, 256, True), (2048, 256, 512, True), (2048, 512, 512, False),
+                                        (2048, 512, 256, True), (777, 256, 512, True), (33, 512, 256, True),
+                                        (5000, 64, 256, True), (1, 512, 512, False), (4096, 1024, 512, True)])
+def test_layer_shapes_vs_float64(ops, M, K, N, relu):
+    a, w, b = case(M, K, N, M + K + N)
+    ref = a.astype(np.float64) @ w.astype(np.float64) + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    img = ops.pack_dense_h2(dev(w))
+    out, amax = ops.dense_h2(dev(a), img, dev(b), N, relu, want_amax=True)
+    got = host(out)
+    report_close("dense_h2 %s" % ((M, K, N),), got, ref, atol=1e-5, rtol=1e-5)
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    print("M %d K %d N %d: max err %.3g of scale %.3g (%.3g relative)" % (M, K, N, err, scale, err / scale))
+    assert err <= 2e-6 * scale
+    assert float(amax) == float(np.abs(got).max())
+    assert np.array_equal(got, host(ops.dense_h2(dev(a), img, dev(b), N, relu)))
+
+
+@pytest.mark.parametrize("M,k1,k2,N", [(2048, 512, 1472, 512), (700, 512, 1472, 512), (2048, 256, 256, 512),
+                                       (100, 64, 128, 256)])
+def test_two_sources_read_in_place(ops, M, k1, k2, N):
+    """[a1 | a2] . W without materialising the concat (models/sdfnet.py:180): the 1984-deep local fold2/conv1"""
+    a, w, b = case(M, k1 + k2, N, M + k1)
+    a1, a2 = np.ascontiguousarray(a[:, :k1]), np.ascontiguousarray(a[:, k1:]) * 4.0   # different magnitudes
+    a = np.concatenate([a1, a2], axis=1)
+    ref = np.maximum(a.astype(np.float64) @ w.astype(np.float64) + b, 0)
+    got = host(ops.dense_h2(dev(a1), ops.pack_dense_h2(dev(w)), dev(b), N, True, a2=dev(a2)))
+    # the bar of a 1984-term fp32 chain: relative to the output scale (an absolute 1e-5 is below the rounding of
+    # one fp32 product at |out| ~ 15)
+    scale = float(np.abs(ref).max())
+    print("two sources %s: max err %.3g of scale %.3g" % ((M, k1, k2, N), np.abs(got - ref).max(), scale))
+    assert np.abs(got - ref).max() <= 2e-6 * scale
+
+
+def test_deferred_bias_and_relu_on_load(ops):
+    """out = relu(relu(pre + in_bias) . W + b): the global fold2/conv1 -> fold2/conv2 hand-over of disn_encode_query"""
+    M, K, N = 2048, 512, 256
+    pre, w, b = case(M, K, N, 5, positive=False)
+    rng = np.random.default_rng(6)
+    ib = (rng.standard_normal(K) * 0.7).astype(np.float32)
+    h = np.maximum(pre.astype(np.float64) + ib, 0)
+    ref = np.maximum(h @ w.astype(np.float64) + b, 0)
+    got = host(ops.dense_h2(dev(pre), ops.pack_dense_h2(dev(w)), dev(b), N, True, in_bias=dev(ib)))
+    report_close("dense_h2 deferred bias", got, ref, atol=1e-5, rtol=1e-5)
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_argument_checks(ops):
+    from disn_amd import _lib
+    a, w, b = case(64, 64, 64, 1)
+    with pytest.raises(ValueError):
+        ops.pack_dense_h2(dev(np.zeros((48, 64), np.float32)))
+    img = ops.pack_dense_h2(dev(w))
+    with pytest.raises(_lib.DisnError) as e:       # k1 = 32 is not a multiple of the 64-column chunk
+        ops.dense_h2(dev(a[:, :32]), img, dev(b), 64, True, a2=dev(a[:, 32:]))
+    assert e.value.status == -2

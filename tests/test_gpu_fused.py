@@ -141,8 +141,9 @@ def test_counted_waits_equal_wait_for_everything():
     """the same launches in a tuning build with every LDS-DMA wait replaced by vmcnt(0): any under-counted
     wait in the product kernel shows as a difference (tools/fused_check.py runs both modes in one process)"""
     lib = os.path.join(ROOT, "disn_amd", "csrc", "libdisn_amd_tuning.so")
-    if not os.path.exists(lib):
-        pytest.skip("no tuning build (python -m disn_amd.csrc.build --tuning)")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(
+            os.path.join(ROOT, "disn_amd", "csrc", "libdisn_amd.so")) - 3600:
+        pytest.skip("no (or a stale) tuning build: python -m disn_amd.csrc.build --tuning")
     env = dict(os.environ, DISN_AMD_LIB=lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fused_check.py")], env=env,
                        capture_output=True, text=True, timeout=900)

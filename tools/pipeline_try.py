@@ -6,6 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from disn_amd.engine import StepPipeline
 from disn_amd.weights import WeightStore
 S = int(sys.argv[1]); K = int(sys.argv[2]) if len(sys.argv) > 2 else 240
+if os.environ.get("KNOB"):      # tuning build only: KNOB=name=value
+    import _tuning
+    k, v = os.environ["KNOB"].split("=")
+    _tuning.set_knob(k, int(v))
 pipe = StepPipeline(WeightStore.random_init(0), in_flight=S)
 rng = np.random.default_rng(0)
 img = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32)).cuda()
@@ -17,4 +21,4 @@ res = []
 for _ in range(3):
     t0 = time.perf_counter(); pipe.run([(img, pts, tm)] * K); torch.cuda.synchronize()
     res.append((time.perf_counter() - t0) / K * 1e3)
-print("queues %s in_flight %d: %s ms per step" % (os.environ.get("GPU_MAX_HW_QUEUES", "default"), S, " ".join("%.4f" % r for r in res)), flush=True)
+print("%s queues %s in_flight %d: %s ms per step" % (os.environ.get("KNOB", ""), os.environ.get("GPU_MAX_HW_QUEUES", "default"), S, " ".join("%.4f" % r for r in res)), flush=True)
