@@ -227,13 +227,16 @@ int mlp_g4_pre_h2(const disn_mlp_weights_t* w, int n, const MlpWs& s, int b, siz
 }
 
 // local fold2/conv1 on [h512a | feat] read in place, fold2/conv2
-int mlp_phase1_h2(const disn_mlp_weights_t* w, int n, const float* feat, const MlpWs& s, int b, size_t o,
+// feat rows have feat_ld floats: 1472 (K = 1984, 64-column chunks) or 1536 with zero padding (K = 2048, 256-column
+// chunks).  A k-wave sums its k16 blocks in ascending order either way and the padding adds exact zeros: the two
+// forms give the same bits.  l_d4 is the [1984][512] matrix packed with 2048 rows (zero rows at the end).
+int mlp_phase1_h2(const disn_mlp_weights_t* w, int n, const float* feat, int feat_ld, const MlpWs& s, int b, size_t o,
                   hipStream_t st) {
   float* A = h2_slots(s, b);
-  DISN_TRY(amax64_accumulate_launch(feat, (size_t)n * DISN_FEAT_DIM, A + 448, st));
-  DenseH2Prob p4 = h2_prob(s.h512a + o * 512, 512 + DISN_FEAT_DIM, w->l_d4, w->l_b4, 512, 1, A + 320, s.h512b + o * 512,
+  DISN_TRY(amax64_accumulate_launch(feat, (size_t)n * feat_ld, A + 448, st));
+  DenseH2Prob p4 = h2_prob(s.h512a + o * 512, 512 + feat_ld, w->l_d4, w->l_b4, 512, 1, A + 320, s.h512b + o * 512,
                            A + 512, n);
-  p4.lda = 512; p4.k1 = 512; p4.a2 = feat; p4.lda2 = DISN_FEAT_DIM; p4.in_amax2 = A + 448;
+  p4.lda = 512; p4.k1 = 512; p4.a2 = feat; p4.lda2 = feat_ld; p4.in_amax2 = A + 448; p4.Kimg = 2048;
   DISN_TRY(dense_h2_launch(&p4, 1, st));
   const DenseH2Prob p5 = h2_prob(s.h512b + o * 512, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5 + o * 256, nullptr, n);
   DISN_TRY(dense_h2_launch(&p5, 1, st));
@@ -373,7 +376,7 @@ int mlp_chunk(const disn_mlp_weights_t* w, const float* pts_rot, int n, const fl
   int rc;
   if (mlp_h2(w, n)) {  // the same launches as disn_encode_query, on one stream (bit-identical results)
     if ((rc = mlp_fold1_h2(w, pts_rot, n, s, 0, 0, st))) return rc;
-    if ((rc = mlp_phase1_h2(w, n, feat, s, 0, 0, st))) return rc;
+    if ((rc = mlp_phase1_h2(w, n, feat, DISN_FEAT_DIM, s, 0, 0, st))) return rc;
     if ((rc = mlp_g4_pre_h2(w, n, s, 0, 0, s.h512a, st))) return rc;   // h512a is free once the local fold2/conv1 ran
     if ((rc = mlp_g5_h2(w, n, s.h512a, gbias, s, 0, 0, st))) return rc;
     DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, sdf_g, sdf_l, out_div, st));
@@ -386,6 +389,8 @@ int mlp_chunk(const disn_mlp_weights_t* w, const float* pts_rot, int n, const fl
 
 const int kMapPixels = DISN_IMG_H * DISN_IMG_W;
 
+const int kFeatPad = 1536;   // gathered feature rows zero-padded to a multiple of 256 columns (dense_h2 chunks)
+
 struct QueryWs {
   float *gbias, *gemv_ws, *feat, *pts;
   MlpWs mlp;
@@ -397,7 +402,7 @@ QueryWs query_layout(void* ws, int B, int chunk, bool need_feat, bool need_pts, 
   QueryWs q;
   q.gbias = b.take((size_t)B * 512 * sizeof(float));
   q.gemv_ws = b.take(gemv_ws_bytes(B, DISN_EMBED_DIM, 512));
-  q.feat = need_feat ? b.take((size_t)chunk * DISN_FEAT_DIM * sizeof(float)) : nullptr;
+  q.feat = need_feat ? b.take((size_t)chunk * kFeatPad * sizeof(float)) : nullptr;
   q.pts = need_pts ? b.take((size_t)chunk * 3 * sizeof(float)) : nullptr;
   q.mlp = mlp_layout(b, chunk, split_g4);
   q.total = (b.off + 255) & ~size_t(255);
@@ -800,7 +805,9 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   // fold2/conv1 -- ~45 us of small launches beside resize / conv1_1 / conv1_2 (VALU work and a two-round kernel,
   // measured unaffected) -- then, behind conv5_3, the LOCAL stream's fold1, the gather and fold2 under the fc head.
   const float* pool5 = nullptr;
+  bool gather_on_st = false;
   const bool h2 = two && B <= kH2Imgs && mlp_h2(mw, N);   // small point sets: the dense_h2 layers, image by image
+  const int feat_ld = h2 && !featmap ? kFeatPad : DISN_FEAT_DIM;
   if (two) {
     DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (orders aux behind the caller's inputs)
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
@@ -822,6 +829,10 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
     rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 2, 13);
     if (rc) return rc;
+    // the gather from the taps on the caller's stream, BEFORE the fc head: alone it takes 14 us, under fc6's HBM
+    // stream 65-70 us (r02q trace) -- and the local fold2 layers behind it are the critical path of the tail
+    gather_on_st = h2 && !featmap;
+    if (gather_on_st) DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, st, feat_ld));
     DISN_TRY(hipEventRecord(ctx->ev[7], st));
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
     DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));  // next to the ev[7] record, where `st` drains anyway
@@ -832,19 +843,21 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     if ((rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, st))) return rc;
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
-  if (featmap) {
+  if (gather_on_st) {
+    // done above
+  } else if (featmap) {
     const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
     for (int b = 0; b < B; ++b)
       DISN_TRY(project_gather_launch(featmap + b * map_stride, trans_mat + (size_t)b * 12,
                                      pts + (size_t)b * N * 3, N,
                                      e.q.feat + (size_t)b * N * DISN_FEAT_DIM, ms));
   } else {  // no map: up-sample the taps at the touched pixels (bit-identical), all images in one launch
-    DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, ms));
+    DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, ms, feat_ld));
   }
   if (h2) {
     for (int b = 0; b < B; ++b) {
       const size_t o = (size_t)b * N;
-      if ((rc = mlp_phase1_h2(mw, N, e.q.feat + o * DISN_FEAT_DIM, e.q.mlp, b, o, ms))) return rc;
+      if ((rc = mlp_phase1_h2(mw, N, e.q.feat + o * feat_ld, feat_ld, e.q.mlp, b, o, ms))) return rc;
     }
   } else if ((rc = mlp_phase1(mw, B * N, e.q.feat, e.q.mlp, ms))) return rc;
   if (two) {

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256 * NW, 1) void dense_h2_kernel(const DenseH2Dev 
   load_chunk(0, ra0);
 
   // ---- scales (requested here, used after the weight queue is in flight) -------------------------------------
-  const float* meta = reinterpret_cast<const float*>(P.wimg + (size_t)K * N * 4);
+  const int Kimg = P.Kimg > 0 ? P.Kimg : K;
+  const float* meta = reinterpret_cast<const float*>(P.wimg + (size_t)Kimg * N * 4);
   float amax_lane = P.in_amax[lane];
   if (P.in_amax2) amax_lane = fmaxf(amax_lane, P.in_amax2[lane]);
   float bmax_lane = 0.f;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256 * NW, 1) void dense_h2_kernel(const DenseH2Dev 
   }
 
   // weight fragments of this wave: k16 block (c KPW + t) 4 + wk, t < KPW: 2 KiB each, 8 KiB apart
-  const unsigned char* wp = P.wimg + ((size_t)(n0 >> 5) * (K >> 4) + wk) * 2048 + lane * 16;
+  const unsigned char* wp = P.wimg + ((size_t)(n0 >> 5) * (Kimg >> 4) + wk) * 2048 + lane * 16;
   ch_h8 qh[KPW], ql[KPW];
 #pragma unroll
   for (int t = 0; t < KPW; ++t) {
@@ -236,6 +237,7 @@ hipError_t dense_h2_launch(const DenseH2Prob* probs, int nprob, hipStream_t st) 
     if (!d.p[i].a2) { d.p[i].a2 = d.p[i].a; d.p[i].lda2 = d.p[i].lda; d.p[i].k1 = d.p[i].K; }
     if (probs[i].M != probs[0].M || probs[i].N != probs[0].N || probs[i].K != probs[0].K || d.p[i].k1 != d.p[0].k1)
       return hipErrorInvalidValue;
+    if (d.p[i].Kimg != 0 && d.p[i].Kimg < d.p[i].K) return hipErrorInvalidValue;
   }
   d.nprob = nprob;
   const DenseH2Prob& p = d.p[0];

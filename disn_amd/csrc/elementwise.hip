@@ -314,13 +314,19 @@ __global__ __launch_bounds__(256) void project_gather_taps_kernel(TapSet t,
                                                                   const float* __restrict__ trans_mat,
                                                                   const float* __restrict__ pts, int B,
                                                                   int n, int c4_begin, int c4_count,
-                                                                  float* __restrict__ feat) {
-  // B images x n points each (rows image-major); tap k of image b at t.p[k] + b * t.stride[k]
+                                                                  float* __restrict__ feat, int feat_ld) {
+  // B images x n points each (rows image-major); tap k of image b at t.p[k] + b * t.stride[k].  feat_ld > 1472
+  // (all five taps only): rows of feat_ld floats, columns 1472 .. feat_ld - 1 written as zeros (c4_count covers
+  // them) -- a zero-padded K for a GEMM that wants 256-column chunks (dense_h2.hip)
   const size_t total = (size_t)B * n * c4_count;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
     const size_t pt = i / c4_count;
     const int c = (c4_begin + (int)(i - pt * c4_count)) * 4;
+    if (c >= DISN_FEAT) {  // padding columns
+      *reinterpret_cast<float4*>(feat + pt * feat_ld + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
     const int b = (int)(pt / n);
     float x, y;
     project_point(trans_mat + (size_t)b * 12, pts[pt * 3], pts[pt * 3 + 1], pts[pt * 3 + 2], x, y);
@@ -360,13 +366,13 @@ __global__ __launch_bounds__(256) void project_gather_taps_kernel(TapSet t,
       DISN_ACC(x) DISN_ACC(y) DISN_ACC(z) DISN_ACC(w)
 #undef DISN_ACC
     }
-    *reinterpret_cast<float4*>(feat + pt * DISN_FEAT + c) = o;
+    *reinterpret_cast<float4*>(feat + pt * feat_ld + c) = o;
   }
 }
 
 hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
                                       const float* pts, int B, int n, int tap_begin, int tap_end,
-                                      float* feat, hipStream_t st) {
+                                      float* feat, hipStream_t st, int feat_ld) {
   static const int c4_off[6] = {0, 16, 48, 112, 240, DISN_FEAT4};
   static const int ch[5] = {64, 128, 256, 512, 512};
   TapSet t;
@@ -375,10 +381,12 @@ hipError_t project_gather_taps_launch(const float* const taps[5], const float* t
     t.s[k] = (float)(224 >> k) / (float)DISN_IMG;
     t.stride[k] = (size_t)(224 >> k) * (224 >> k) * ch[k];
   }
-  const int c4_begin = c4_off[tap_begin], c4_count = c4_off[tap_end] - c4_begin;
+  if (feat_ld <= 0) feat_ld = DISN_FEAT;
+  const int c4_begin = c4_off[tap_begin];
+  const int c4_count = (tap_end == 5 && feat_ld > DISN_FEAT ? feat_ld / 4 : c4_off[tap_end]) - c4_begin;
   const size_t total = (size_t)B * n * c4_count;
   hipLaunchKernelGGL(project_gather_taps_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
-                     trans_mat, pts, B, n, c4_begin, c4_count, feat);
+                     trans_mat, pts, B, n, c4_begin, c4_count, feat, feat_ld);
   return hipGetLastError();
 }
 

@@ -125,7 +125,7 @@ hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_
 // tap_end) (taps[k] = [B,hw,hw,ch] NHWC) at the touched pixels, writes their channels of [B*n,1472]
 hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
                                       const float* pts, int B, int n, int tap_begin, int tap_end,
-                                      float* feat, hipStream_t st);
+                                      float* feat, hipStream_t st, int feat_ld = 0);  // feat_ld > 1472: zero-padded rows
 // folded local fold2/conv1 (disn_fold_local): h = relu(pre + resample(pmap_b)(pts) + bias), [n,512]
 hipError_t gather_fold_launch(const float* pmap_b, const float* trans_mat_b, const float* pts, int n,
                               const float* pre, const float* bias, float* h, hipStream_t st);
@@ -274,7 +274,8 @@ struct DenseH2Prob {     // out[M][N] = act(f(A) . W + bias), A = [a (k1 columns
   int lda2, k1;
   const float* in_bias;  // [K] (or [images][K] with in_bias_rows) or nullptr
   int in_bias_rows;      // > 0: row m uses in_bias row m / in_bias_rows (a per-image bias, rows image-major)
-  const unsigned char* wimg;  // conv_h2_pack_launch(w [K][N], K, N, ..., taps = 1)
+  const unsigned char* wimg;  // conv_h2_pack_launch(w [Kimg][N], Kimg, N, ..., taps = 1)
+  int Kimg;              // rows of the packed matrix (0: K); > K: an image zero-padded beyond the K used here
   const float* bias;     // [N]
   const float* in_amax;  // 64 slots: max |a|
   const float* in_amax2; // 64 slots: max |a2| (nullptr with one source)

@@ -99,7 +99,9 @@ class DeviceWeights:
 
         m.g_d2, m.g_d3, m.g_d4_point, m.g_d5 = (d2(W(g, "fold1/conv2")), d2(W(g, "fold1/conv3")), d2(w4g[:512]),
                                                 d2(W(g, "fold2/conv2")))
-        m.l_d2, m.l_d3, m.l_d4, m.l_d5 = (d2(W(l, "fold1/conv2")), d2(W(l, "fold1/conv3")), d2(w4l),
+        w4l_pad = np.zeros((2048, 512), np.float32)        # [1984][512] + 64 zero rows: 256-column chunks
+        w4l_pad[:w4l.shape[0]] = w4l
+        m.l_d2, m.l_d3, m.l_d4, m.l_d5 = (d2(W(l, "fold1/conv2")), d2(W(l, "fold1/conv3")), d2(w4l_pad),
                                           d2(W(l, "fold2/conv2")))
         for f in MLP_FIELDS:
             assert getattr(m, f), f

@@ -249,7 +249,7 @@ typedef struct disn_mlp_weights {
   const float* g_w4_global_t;
   /* optional (all eight or none): disn_pack_dense_h2 images of fold1/conv2, fold1/conv3, the point rows of the global
    * fold2/conv1 and fold2/conv2 of the global stream, and of fold1/conv2, fold1/conv3, the WHOLE local fold2/conv1
-   * [1984][512] and fold2/conv2 of the local stream.  With them a point set of fewer than 8192 points per image runs
+   * [1984][512] zero-padded to [2048][512] and fold2/conv2 of the local stream.  With them a point set of fewer than 8192 points per image runs
    * its layers through dense_h2.hip (disn_encode_query, disn_query, disn_sdf_mlp): one short launch per layer. */
   const void *g_d2, *g_d3, *g_d4_point, *g_d5, *l_d2, *l_d3, *l_d4, *l_d5;
 } disn_mlp_weights_t;
