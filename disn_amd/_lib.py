@@ -124,6 +124,7 @@ SIGNATURES = {
     "disn_stream_destroy": (I, [P]),
     "disn_ctx_create": (I, [C.POINTER(C.c_void_p)]),
     "disn_ctx_destroy": (I, [P]),
+    "disn_ctx_pipeline": (I, [P, P, P]),
     "disn_encode_workspace_bytes": (Z, [I]),
     "disn_encode": (I, [P, C.POINTER(VggWeights), P, I, P, C.POINTER(C.c_void_p * 5), P, P, P, Z, P]),
     "disn_encode_query_workspace_bytes": (Z, [I, I]),

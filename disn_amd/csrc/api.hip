@@ -679,10 +679,21 @@ EncQueryWs encq_layout(void* ws, int B, int N, int num_classes) {
 
 extern "C" {
 
+// ROCm binds a stream to one of its hardware queues when the stream first submits work: an empty launch (and a
+// wait for it) right after creation makes that binding happen HERE, in creation order, instead of in whatever order
+// several host threads happen to issue their first real launches
+__global__ void disn_bind_queue_kernel() {}
+static hipError_t bind_queue(hipStream_t st) {
+  hipLaunchKernelGGL(disn_bind_queue_kernel, dim3(1), dim3(64), 0, st);
+  const hipError_t e = hipGetLastError();
+  return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
 int disn_stream_create(void** stream) {
   if (!stream) return DISN_E_ARG;
   hipStream_t st = nullptr;
   DISN_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  DISN_TRY(bind_queue(st));
   *stream = st;
   return 0;
 }
@@ -699,6 +710,7 @@ int disn_ctx_create(disn_ctx_t** out) {
   disn_ctx* c = new (std::nothrow) disn_ctx();
   if (!c) return DISN_E_ARG;
   hipError_t e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+  if (e == hipSuccess) e = bind_queue(c->aux);
   for (int i = 0; i < 10 && e == hipSuccess; ++i)
     e = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -706,6 +718,13 @@ int disn_ctx_create(disn_ctx_t** out) {
     return (int)e;
   }
   *out = c;
+  return 0;
+}
+
+int disn_ctx_pipeline(disn_ctx_t* c, void* wait_event, void* record_event) {
+  if (!c) return DISN_E_ARG;
+  c->pipe_wait = (hipEvent_t)wait_event;
+  c->pipe_record = (hipEvent_t)record_event;
   return 0;
 }
 
@@ -806,6 +825,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   // measured unaffected) -- then, behind conv5_3, the LOCAL stream's fold1, the gather and fold2 under the fc head.
   const float* pool5 = nullptr;
   bool gather_on_st = false;
+  if (ctx->pipe_wait) DISN_TRY(hipStreamWaitEvent(st, ctx->pipe_wait, 0));  // behind the previous step's convolutions
   const bool h2 = two && B <= kH2Imgs && mlp_h2(mw, N);   // small point sets: the dense_h2 layers, image by image
   const int feat_ld = h2 && !featmap ? kFeatPad : DISN_FEAT_DIM;
   if (two) {
@@ -833,6 +853,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     // stream 65-70 us (r02q trace) -- and the local fold2 layers behind it are the critical path of the tail
     gather_on_st = h2 && !featmap;
     if (gather_on_st) DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, st, feat_ld));
+    if (ctx->pipe_record) DISN_TRY(hipEventRecord(ctx->pipe_record, st));  // the next step's convolutions may start
     DISN_TRY(hipEventRecord(ctx->ev[7], st));
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
     DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));  // next to the ev[7] record, where `st` drains anyway

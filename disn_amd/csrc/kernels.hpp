@@ -9,6 +9,9 @@
 struct disn_ctx {
   hipStream_t aux;
   hipEvent_t ev[10];
+  // software pipeline of consecutive steps (disn_ctx_pipeline): the convolution stack of this step starts behind
+  // `pipe_wait` (the previous step's `pipe_record`) and records `pipe_record` when it is done
+  hipEvent_t pipe_wait = nullptr, pipe_record = nullptr;
 };
 
 namespace disn {

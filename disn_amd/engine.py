@@ -336,13 +336,45 @@ class StepPipeline:
         except Exception:  # interpreter shutdown
             pass
 
-    def run(self, jobs, keep_encoded: bool = False):
+    def run(self, jobs, keep_encoded: bool = False, chained: Optional[bool] = None):
         """jobs: sequence of (imgs, pts, trans_mat[, pts_rot]) -> list of pred_sdf (or (Encoded, pred_sdf)) in
         job order.  Job k runs on engine context k % in_flight.  Returns with the work enqueued, not finished:
-        synchronise the device (or the returned tensors' use on the current stream) as usual."""
+        synchronise the device (or the returned tensors' use on the current stream) as usual.
+
+        ``chained`` (default False): ONE host thread enqueues the steps in order and the convolution stack of step
+        k+1 starts behind the one of step k (disn_ctx_pipeline): a deterministic two-stage pipeline -- convolutions
+        of one step beside the fc head and point MLPs of the previous one.  Measured 0.457 ms per step, every run
+        the same: the single host thread (~40 launches and event calls per step through Python) is the pacer, not
+        the GPU.  Default: every context is fed by its own host thread and the steps overlap as the hardware
+        schedules them: 0.33 ms per step on average at three in flight, 0.33 ... 0.40 ms from run to run (when two
+        steps' convolution stacks happen to run in phase they halve each other)."""
         S = len(self.engines)
+        if chained is None:
+            chained = False
         out = [None] * len(jobs)
         cur = torch.cuda.current_stream(self.device)
+        if chained:
+            with torch.cuda.device(self.device):
+                if not hasattr(self, "_conv_done"):
+                    self._conv_done = [torch.cuda.Event() for _ in range(S + 1)]
+                    for e in self._conv_done:
+                        e.record()                       # creates the hipEvent_t handles
+                for st in self.streams:
+                    st.wait_stream(cur)
+                prev = None
+                for k, job in enumerate(jobs):
+                    i = k % S
+                    rec = self._conv_done[k % (S + 1)]
+                    ops.ctx_pipeline(self.engines[i]._ctx, prev, rec)
+                    with torch.cuda.stream(self.streams[i]):
+                        enc, sdf = self.engines[i].encode_query(*job)
+                    out[k] = (enc, sdf) if keep_encoded else sdf
+                    prev = rec
+                for eng in self.engines:
+                    ops.ctx_pipeline(eng._ctx, None, None)
+            for st in self.streams:
+                cur.wait_stream(st)
+            return out
 
         def work(i):
             with torch.cuda.device(self.device), torch.cuda.stream(self.streams[i]):

@@ -298,6 +298,12 @@ def ctx_create() -> int:
     return h.value
 
 
+def ctx_pipeline(ctx: int, wait_event: Optional[torch.cuda.Event], record_event: Optional[torch.cuda.Event]) -> None:
+    """disn_ctx_pipeline: chain the convolution stacks of consecutive steps (events already created: .cuda_event)"""
+    check("disn_ctx_pipeline", lib().disn_ctx_pipeline(ctx, wait_event.cuda_event if wait_event is not None else None,
+                                                       record_event.cuda_event if record_event is not None else None))
+
+
 def ctx_destroy(ctx: int) -> None:
     if ctx:
         check("disn_ctx_destroy", lib().disn_ctx_destroy(ctx))

@@ -314,6 +314,14 @@ int disn_stream_destroy(void* stream);
  * ---------------------------------------------------------------------- */
 typedef struct disn_ctx disn_ctx_t;
 int disn_ctx_create(disn_ctx_t** out);
+/* Software pipeline of consecutive disn_encode_query calls on DIFFERENT contexts / streams (independent steps):
+ * the step of context c starts behind `wait_event` (hipEvent_t; NULL: at once) and records `record_event`
+ * (hipEvent_t; NULL: nothing) when its convolution stack is done.  Chaining step k's record to step k+1's wait
+ * keeps the convolution stacks of consecutive steps from running at the same time -- their kernels are ONE round of
+ * workgroups that each fill a CU and halve each other -- while step k's fc head and point MLPs run beside step
+ * k+1's convolutions.  The caller enqueues the steps from ONE host thread in step order (an event must be recorded
+ * before it is waited for).  disn_amd.engine.StepPipeline does exactly this. */
+int disn_ctx_pipeline(disn_ctx_t* ctx, void* wait_event, void* record_event);
 int disn_ctx_destroy(disn_ctx_t* ctx);
 
 /* Rows A, B, C, E for a batch of images: disn_vgg16_forward + disn_build_featmap

@@ -427,3 +427,23 @@ def test_step_pipeline_equals_single_stream_steps():
     for k, job in enumerate(jobs):
         ref = one.encode_query(*job)[1]
         assert torch.equal(got[k], ref), "job %d differs" % k
+
+
+def test_chained_pipeline_equals_single_stream_steps():
+    """StepPipeline.run(chained=True): one host thread, convolution stacks of consecutive steps chained by events
+    (disn_ctx_pipeline) -- same results as one engine, one step at a time"""
+    from disn_amd.engine import SdfEngine, StepPipeline
+    from disn_amd.weights import WeightStore
+    pipe = StepPipeline(WeightStore.random_init(4, mode="he"), in_flight=2)
+    jobs = []
+    for k in range(5):
+        d = O.synth_inputs(40 + k, 1, 512)
+        jobs.append((torch.from_numpy(d["imgs"]).cuda(), torch.from_numpy(d["sample_pc"]).cuda(),
+                     torch.from_numpy(d["trans_mat"]).cuda()))
+    got = pipe.run(jobs, chained=True)
+    got2 = pipe.run(jobs, chained=True)
+    torch.cuda.synchronize()
+    one = SdfEngine(None, weights=pipe.engines[0].weights)
+    for k, job in enumerate(jobs):
+        ref = one.encode_query(*job)[1]
+        assert torch.equal(got[k], ref) and torch.equal(got2[k], ref), "job %d differs" % k

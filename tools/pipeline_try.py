@@ -16,9 +16,10 @@ img = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32)).cuda()
 pts = torch.rand((1, 2048, 3), device="cuda") * 2 - 1
 tm = torch.tensor([[[-68.453156, 5.5086656, -0.37556022], [-17.138561, -84.685486, -0.250198],
                     [-47.284092, -3.6569588, 0.2493176], [101.133705, 101.34268, 1.4305686]]], device="cuda")
-pipe.run([(img, pts, tm)] * (4 * S)); torch.cuda.synchronize()
+CH = {"1": True, "0": False}.get(os.environ.get("CHAINED", ""), None)
+pipe.run([(img, pts, tm)] * (4 * S), chained=CH); torch.cuda.synchronize()
 res = []
 for _ in range(3):
-    t0 = time.perf_counter(); pipe.run([(img, pts, tm)] * K); torch.cuda.synchronize()
+    t0 = time.perf_counter(); pipe.run([(img, pts, tm)] * K, chained=CH); torch.cuda.synchronize()
     res.append((time.perf_counter() - t0) / K * 1e3)
-print("%s queues %s in_flight %d: %s ms per step" % (os.environ.get("KNOB", ""), os.environ.get("GPU_MAX_HW_QUEUES", "default"), S, " ".join("%.4f" % r for r in res)), flush=True)
+print("chained=%s %s queues %s in_flight %d: %s ms per step" % (os.environ.get("CHAINED", "default"), os.environ.get("KNOB", ""), os.environ.get("GPU_MAX_HW_QUEUES", "default"), S, " ".join("%.4f" % r for r in res)), flush=True)
