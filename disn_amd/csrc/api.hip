@@ -267,10 +267,6 @@ int dense_layer(const float* a1, int lda1, int k1, const float* a2, int lda2, in
     DISN_TRY(gemm_bf16_launch(p, GEMM_DENSE, x3, ws, ws ? ws_bytes : 0, st, 3));
     return 0;
   }
-  if (x3 && x3_enabled() && tune::small_x3 && K >= 256) {  // experiment: no split-K, one launch
-    DISN_TRY(gemm_bf16_launch(p, GEMM_DENSE, x3, nullptr, 0, st, 3));
-    return 0;
-  }
   const GemmPlan pl = gemm_plan(n, N, K, ws ? ws_bytes : 0);
   DISN_TRY(gemm_launch(p, GEMM_DENSE, pl, ws, st));
   return 0;
@@ -1288,7 +1284,6 @@ namespace tune {
 int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0;
 int gemm_force[3] = {0, 0, 0};
 int gemv_wgs = 0;
-int small_x3 = 0;
 long long* ch2_stamps = nullptr;
 }
 }  // namespace disn
@@ -1300,10 +1295,10 @@ extern "C" int disn_tuning_set_ptr(int key, void* p) {
 // tuning builds only (build.py --tuning -> libdisn_amd_tuning.so): 0 x3, 1 overlap, 2 bf_splits, 3 skip_pack,
 // 4 fused_safe
 extern "C" int disn_tuning_set(int key, int value) {
-  int* k[10] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
-                &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
-                &disn::tune::gemm_force[2], &disn::tune::gemv_wgs, &disn::tune::small_x3};
-  if (key < 0 || key > 9) return DISN_E_ARG;
+  int* k[9] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
+               &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
+               &disn::tune::gemm_force[2], &disn::tune::gemv_wgs};
+  if (key < 0 || key > 8) return DISN_E_ARG;
   *k[key] = value;
   return 0;
 }

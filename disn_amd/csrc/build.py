@@ -94,6 +94,18 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> s
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
         with open(stamp, "w") as f:
             f.write(want)
+    # objects of earlier source states (other digests) would otherwise pile up and travel with every snapshot;
+    # the twin build's objects (product <-> tuning) are recognised by ITS stamp's digest list and kept
+    keep = set(objs)
+    other = os.path.join(HERE, "build", "objs_tuning.txt" if not tuning else "objs.txt")
+    if os.path.exists(other):
+        keep.update(l.strip() for l in open(other))
+    with open(os.path.join(HERE, "build", "objs.txt" if not tuning else "objs_tuning.txt"), "w") as f:
+        f.write("\n".join(objs))
+    for fn in os.listdir(os.path.join(HERE, "build")):
+        fp = os.path.join(HERE, "build", fn)
+        if fn.endswith(".o") and fp not in keep:
+            os.remove(fp)
     return lib
 
 

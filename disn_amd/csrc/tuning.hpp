@@ -13,11 +13,10 @@ extern int bf_splits;   // > 0: force this split-K factor in the three-term kern
 extern int skip_pack;   // 1: disn_conv3x3_bf16 reuses the packed image of the previous call (timing only)
 extern int fused_safe;  // 1: fused point MLP waits for ALL LDS-DMA at every sync (debugging)
 extern int gemm_force[3];  // {BM, BN, workgroups}: plan of the f32-input GEMM when BM != 0 (tools/sweep_gemm.py)
-extern int small_x3;     // 1: small point-MLP layers through the three-term kernel without split-K (experiment)
 extern int gemv_wgs;     // > 0: workgroups of the split-K GEMV (default 2048 = every wave slot of the chip)
 extern long long* ch2_stamps;  // conv_h2 kernels write 16 clock stamps per workgroup here (tools/conv_h2_stamps.py)
 #else
-constexpr int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0, gemv_wgs = 0, small_x3 = 0;
+constexpr int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0, gemv_wgs = 0;
 constexpr int gemm_force[3] = {0, 0, 0};
 #endif
 }  // namespace tune
