@@ -263,8 +263,8 @@ def grid_bench(args, torch, dist, dev, world, rank, launched, shared_gpu, backen
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 300 query, 5 grid, 50 train)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 20 query, 1 grid, 5 train)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / grid / cpu legs")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="--workload query: independent steps in flight on this GPU (disn_amd.engine.StepPipeline: one "
@@ -286,6 +286,10 @@ def main():
                          "on the f32-input MFMA); bf16 = mixed precision (bf16 multiply, fp32 accumulate / "
                          "master weights / optimizer)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"query": 300, "grid": 5, "train": 50}[args.workload]
+    if args.warmup is None:
+        args.warmup = {"query": 20, "grid": 1, "train": 5}[args.workload]
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # torch.distributed.run / torchrun
     if args.gpus > 1 and not launched:
         sys.exit(self_launch(args, sys.argv[1:]))
