@@ -45,7 +45,9 @@ inline int conv_k(int cin) { return cin == 3 ? 32 : 9 * cin; }
 
 struct VggWs {
   float *resized, *bufA, *bufB, *bufP, *gemm_ws, *fc_ws, *fc6, *fc7;
-  float* amax;  // [14][64]: slot group i = max |input of conv layer i| (conv_h2.hip), written by layer i - 1
+  float* amax;  // [14][B][64]: slot group (i, b) = max |input of conv layer i| of image b (conv_h2.hip), written by
+                // layer i - 1: per image, so that an image's scales (hence every bit of its result) do not depend
+                // on the batch it travels in
   size_t total;
 };
 
@@ -74,7 +76,7 @@ VggWs vgg_layout(void* ws, int B, int num_classes) {
   w.fc_ws = b.take(fws);
   w.fc6 = b.take((size_t)B * 4096 * sizeof(float));
   w.fc7 = b.take((size_t)B * 4096 * sizeof(float));
-  w.amax = b.take(14 * 64 * sizeof(float));
+  w.amax = b.take((size_t)14 * B * 64 * sizeof(float));
   w.total = (b.off + 255) & ~size_t(255);
   return w;
 }
@@ -593,7 +595,7 @@ int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* re
   for (int i = 0; i < 13; ++i) h2 = h2 && w->conv_w_h2[i] != nullptr;
   if (i0 == 0)
     DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, resized, DISN_VGG_SIZE,
-                                    DISN_VGG_SIZE, 3, 0, st, 0, h2 ? s.amax : nullptr, h2 ? 14 * 64 : 0));
+                                    DISN_VGG_SIZE, 3, 0, st, 0, h2 ? s.amax : nullptr, h2 ? 14 * B * 64 : 0));
   const float* x = i0 == 0 ? resized : *xio;
   bool toggle = false;  // (a pool precedes every layer that uses the bufA / bufB toggle first: restarts agree)
   const size_t gws_cap = (size_t)((char*)s.fc_ws - (char*)s.gemm_ws);
@@ -608,10 +610,11 @@ int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* re
     int rc = 0;
     if (h2 && i == 0) {
       DISN_TRY(conv1_1_direct_launch(x, B, L.hw, L.hw, static_cast<const float*>(w->conv_w_h2[0]), w->conv_b[0], 1, out,
-                                     s.amax + 64, st));
+                                     s.amax + (size_t)B * 64, st, 64));
     } else if (h2) {
-      DISN_TRY(conv_h2_launch(x, B, L.hw, L.hw, L.cin, w->conv_w_h2[i], w->conv_b[i], L.cout, 1, s.amax + 64 * i, out,
-                              kPoolAfter[i] ? s.bufP : nullptr, s.amax + 64 * (i + 1), st));
+      DISN_TRY(conv_h2_launch(x, B, L.hw, L.hw, L.cin, w->conv_w_h2[i], w->conv_b[i], L.cout, 1,
+                              s.amax + (size_t)B * 64 * i, out, kPoolAfter[i] ? s.bufP : nullptr,
+                              s.amax + (size_t)B * 64 * (i + 1), st, 0, 64));
       pooled = kPoolAfter[i];
     } else {
       rc = conv3x3_impl(x, B, L.hw, L.hw, L.cin, w->conv_w[i], w->conv_b[i], L.cout, 1, out, s.gemm_ws, gws_cap, st,

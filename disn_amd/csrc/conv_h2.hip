@@ -112,6 +112,7 @@ struct ConvH2Dev {
   int B, H, W, Cin, Cout;
   int tiles_x, tiles_y;
   int relu;
+  int amax_stride;            // floats between the slot groups of consecutive images (0: one group for the whole batch)
   long long* stamps;  // tuning builds: 16 clock stamps per workgroup (nullptr in the product)
 };
 
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(64 * WK * NW, 1) void conv_h2_kernel(const ConvH2De
   // ---- scales: the producer's maximum (64 slots, see the epilogue) and the weight image's; requested here, used
   // after the weight queue below is in flight (loads return in order: waiting for these must not wait for those) ----
   const float* meta = reinterpret_cast<const float*>(P.wimg + (size_t)Cin * 9 * Cout * 4);
-  float amax_lane = P.in_amax[lane];
+  float amax_lane = P.in_amax[(size_t)b * P.amax_stride + lane];
   const float inv_sw = meta[1];
 
   // ---- A rows of this lane: logical row sigma(i) of block mb -> centre pixel in the halo -----------------------
@@ -373,7 +374,9 @@ __global__ __launch_bounds__(64 * WK * NW, 1) void conv_h2_kernel(const ConvH2De
   if (P.out_amax) {  // 64 slots: same-address atomics serialise in L2 (~10 ns each)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(P.out_amax) + ((blockIdx.x * WK * NW + wave) & 63), __float_as_uint(vmax));
+    if (lane == 0)
+      atomicMax(reinterpret_cast<unsigned*>(P.out_amax) + (size_t)b * P.amax_stride + ((blockIdx.x * WK * NW + wave) & 63),
+                __float_as_uint(vmax));
   }
   if (P.pool_out) {  // H, W even; y0, x0 even: a 2x2 window never leaves the tile, nor this wave's quad
     const int Hp = H >> 1, Wp = W >> 1;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(64 * WK * NW, 1) void conv_h2_kernel(const ConvH2De
 __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                              const float* __restrict__ bias, int B, int H, int W,
                                                              int relu, float* __restrict__ out,
-                                                             float* __restrict__ out_amax) {
+                                                             float* __restrict__ out_amax, int amax_stride) {
   __shared__ float win[2][3 * 34 * 3 + 2];
   __shared__ __attribute__((aligned(16))) float wl[27 * 64];
   __shared__ float red[4];
@@ -427,11 +430,27 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
   const int segs_x = (W + 31) >> 5;
   const long nseg = (long)B * H * segs_x;
   float vmax = 0.f;
-  int buf = 0;
+  int buf = 0, bcur = -1;
+  // the maximum is kept per IMAGE (amax_stride floats between the images' slot groups): a workgroup that walks
+  // from one image into the next hands its maximum in first
+  auto flush = [&](int bimg) {
+    float m = vmax;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0)
+      atomicMax(reinterpret_cast<unsigned*>(out_amax) + (size_t)bimg * amax_stride + (blockIdx.x & 63),
+                __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    __syncthreads();
+    vmax = 0.f;
+  };
   for (long sg = blockIdx.x; sg < nseg; sg += gridDim.x, buf ^= 1) {
     const int sx = (int)(sg % segs_x);
     const long by = sg / segs_x;
     const int y = (int)(by % H), b = (int)(by / H);
+    if (out_amax && amax_stride && bcur >= 0 && b != bcur) flush(bcur);
+    bcur = b;
     const int x0 = sx * 32;
     const float* img = in + (size_t)b * H * W * 3;
     for (int i = tid; i < 3 * 34 * 3; i += 256) {  // window element (row r, pixel px, channel c)
@@ -459,23 +478,15 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
       }
     }
   }
-  if (out_amax) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-    if ((tid & 63) == 0) red[tid >> 6] = vmax;
-    __syncthreads();
-    if (tid == 0)
-      atomicMax(reinterpret_cast<unsigned*>(out_amax) + (blockIdx.x & 63),
-                __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
-  }
+  if (out_amax && bcur >= 0) flush(amax_stride ? bcur : 0);
 }
 
-// w: the TF tensor [3][3][3][64] as is; out_amax: 64 slots zeroed by the caller, or nullptr
+// w: the TF tensor [3][3][3][64] as is; out_amax: 64 slots (per image when amax_stride > 0) zeroed by the caller, or nullptr
 hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu,
-                                 float* out, float* out_amax, hipStream_t st) {
+                                 float* out, float* out_amax, hipStream_t st, int amax_stride) {
   const long nseg = (long)B * H * ((W + 31) / 32);
   const int grid = (int)(nseg < 512 ? nseg : 512);  // two workgroups per CU, ~3 segments each at 224 x 224
-  hipLaunchKernelGGL(conv1_1_direct_kernel, dim3(grid), dim3(256), 0, st, in, w_hwio, bias, B, H, W, relu, out, out_amax);
+  hipLaunchKernelGGL(conv1_1_direct_kernel, dim3(grid), dim3(256), 0, st, in, w_hwio, bias, B, H, W, relu, out, out_amax, amax_stride);
   return hipGetLastError();
 }
 
@@ -497,11 +508,11 @@ bool conv_h2_supported(int H, int W, int Cin, int Cout) {
 // cfg: 0 = by shape; 1..4 force <1,1,16,14>, <2,1,32,28>, <2,2,32,28>, <4,2,16,16> (tests: every shape through every tiling)
 hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const void* wimg, const float* bias,
                           int Cout, int relu, const float* in_amax, float* out, float* pool_out, float* out_amax,
-                          hipStream_t st, int cfg) {
+                          hipStream_t st, int cfg, int amax_stride) {
   ConvH2Dev d{};
   d.in = in; d.wimg = static_cast<const unsigned char*>(wimg); d.bias = bias; d.in_amax = in_amax;
   d.out = out; d.pool_out = pool_out; d.out_amax = out_amax;
-  d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.relu = relu;
+  d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.relu = relu; d.amax_stride = amax_stride;
 #ifdef DISN_TUNING
   d.stamps = tune::ch2_stamps;
 #endif
@@ -509,7 +520,9 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
     // patch shape by image width; n-blocks per workgroup so that one image still gives >= ~200 workgroups
     if (W <= 14) cfg = 1;
     else if (W <= 28 || (W % 28 == 0 && W % 16 != 0)) {
-      const long wgs1 = (long)B * ((H + 1) / 2) * ((W + 27) / 28) * (Cout / 32);
+      // by the workgroups ONE image gives, whatever the batch: the tiling fixes the number of k-waves, i.e. the
+      // summation order -- an image's bits must not depend on the batch it travels in
+      const long wgs1 = (long)((H + 1) / 2) * ((W + 27) / 28) * (Cout / 32);
       cfg = wgs1 <= 320 ? 2 : 3;
     } else cfg = 4;
   }

@@ -263,11 +263,11 @@ bool conv_h2_supported(int H, int W, int Cin, int Cout);  // Cin, Cout multiples
 // (optional, H and W even): the 2x2 max pool of out; tiling 0: by shape
 hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const void* wimg, const float* bias,
                           int Cout, int relu, const float* in_amax, float* out, float* pool_out, float* out_amax,
-                          hipStream_t st, int tiling = 0);
+                          hipStream_t st, int tiling = 0, int amax_stride = 0);  // amax_stride > 0: slot groups PER IMAGE
 
 // conv1_1 (Cin = 3, Cout = 64) as a direct fp32 FMA convolution; w_hwio: the TF tensor [3][3][3][64] as is
 hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu,
-                                 float* out, float* out_amax, hipStream_t st);
+                                 float* out, float* out_amax, hipStream_t st, int amax_stride = 0);
 
 // ---- dense_h2.hip: the point-MLP layers at a few thousand rows (two-term f16 split, 1x1 sibling of conv_h2) ----
 struct DenseH2Prob {     // out[M][N] = act(f(A) . W + bias), A = [a (k1 columns) | a2 (K - k1)], f = relu(. + in_bias) or identity

@@ -300,8 +300,14 @@ class StepPipeline:
     all of its work; nothing is shared or cached between steps, and each result equals the single-stream one bit
     for bit (the kernels and their launch order within a step are the same)."""
 
-    def __init__(self, store: WeightStore, device: Optional[torch.device] = None, in_flight: int = 3):
+    def __init__(self, store: WeightStore, device: Optional[torch.device] = None, in_flight: int = 3,
+                 batch: int = 1):
+        """``batch``: consecutive jobs of equal shape are submitted ``batch`` at a time as ONE disn_encode_query call
+        (images and point sets concatenated): the 495 MB of fc weights are read once per call instead of once per
+        image, and every launch has ``batch`` times the work against the same fixed cost.  Every image keeps its own
+        activation scales and its own MLP launches, so its result is bit for bit what it gets alone."""
         import threading
+        self.batch = max(1, int(batch))
         self._threading = threading
         # Stream / context creation ORDER matters: ROCm hands out its hardware queues (GPU_MAX_HW_QUEUES, default
         # 4 including the null stream's) to streams in creation order and shares them afterwards, and two streams
@@ -351,6 +357,8 @@ class StepPipeline:
         S = len(self.engines)
         if chained is None:
             chained = False
+        if self.batch > 1:
+            return self._run_batched(jobs, keep_encoded)
         out = [None] * len(jobs)
         cur = torch.cuda.current_stream(self.device)
         if chained:
@@ -390,4 +398,43 @@ class StepPipeline:
             t.join()
         for st in self.streams:
             cur.wait_stream(st)                            # results are ordered before later work on the caller's stream
+        return out
+
+    def _run_batched(self, jobs, keep_encoded):
+        """groups of ``batch`` consecutive jobs -> one call each; group g runs on context g % in_flight"""
+        S, Bn = len(self.engines), self.batch
+        groups = [list(range(i, min(i + Bn, len(jobs)))) for i in range(0, len(jobs), Bn)]
+        out = [None] * len(jobs)
+        cur = torch.cuda.current_stream(self.device)
+
+        def cat(idx, pos):
+            ts = [self.engines[0]._dev(jobs[k][pos]) for k in idx]
+            return ts[0] if len(ts) == 1 else torch.cat(ts, dim=0)
+
+        def work(i):
+            with torch.cuda.device(self.device), torch.cuda.stream(self.streams[i]):
+                self.streams[i].wait_stream(cur)
+                for g in range(i, len(groups), S):
+                    idx = groups[g]
+                    if len({tuple(jobs[k][1].shape) for k in idx}) != 1:
+                        raise ValueError("jobs of one batch must have point sets of one shape")
+                    args = [cat(idx, p) for p in range(len(jobs[idx[0]]))]
+                    enc, sdf = self.engines[i].encode_query(*args)
+                    o = 0
+                    for k in idx:
+                        b = jobs[k][0].shape[0]
+                        if keep_encoded:
+                            e = Encoded(enc.resized[o:o + b], [t[o:o + b] for t in enc.taps], enc.embedding[o:o + b], None)
+                            out[k] = (e, sdf[o:o + b])
+                        else:
+                            out[k] = sdf[o:o + b]
+                        o += b
+
+        threads = [self._threading.Thread(target=work, args=(i,)) for i in range(min(S, len(groups)))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for st in self.streams:
+            cur.wait_stream(st)
         return out

@@ -447,3 +447,23 @@ def test_chained_pipeline_equals_single_stream_steps():
     for k, job in enumerate(jobs):
         ref = one.encode_query(*job)[1]
         assert torch.equal(got[k], ref) and torch.equal(got2[k], ref), "job %d differs" % k
+
+
+def test_batched_pipeline_equals_single_image_steps():
+    """StepPipeline(batch=3): three independent (image, point set) steps per disn_encode_query call -- every image
+    keeps its own activation scales (conv stack and point MLPs), so each result is bit for bit the single-image one"""
+    from disn_amd.engine import SdfEngine, StepPipeline
+    from disn_amd.weights import WeightStore
+    pipe = StepPipeline(WeightStore.random_init(6, mode="he"), in_flight=2, batch=3)
+    jobs = []
+    for k in range(8):                                   # 3 + 3 + 2: a ragged last batch
+        d = O.synth_inputs(60 + k, 1, 1024)
+        d["imgs"] *= np.float32(0.25 + 0.25 * k)          # different brightness: different activation maxima
+        jobs.append((torch.from_numpy(d["imgs"]).cuda(), torch.from_numpy(d["sample_pc"]).cuda(),
+                     torch.from_numpy(d["trans_mat"]).cuda()))
+    got = pipe.run(jobs)
+    torch.cuda.synchronize()
+    one = SdfEngine(None, weights=pipe.engines[0].weights)
+    for k, job in enumerate(jobs):
+        ref = one.encode_query(*job)[1]
+        assert torch.equal(got[k], ref), "job %d differs from its single-image run" % k
