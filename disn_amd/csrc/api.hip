@@ -122,10 +122,9 @@ struct MlpWs {
   float *g4pre, *zero512, *gemm_ws2;
   // dense_h2 path (small point sets): 16 x 64 activation-maximum slots, directly in front of zero512 so that the
   // chain's first launch clears both in one go.  Slot groups: 0 e1g, 1 e1l, 2 g256, 3 h256, 4 g512, 5 h512a,
-  // 6 g4pre, 7 feat, 8 h512b (local fold2/conv1 out).  One set per image (the maxima are per image so that a
-  // batch gives every image exactly what it would get alone); sets 1 .. kH2Imgs - 1 follow zero512.
+  // 6 g4pre, 7 feat, 8 h512b (local fold2/conv1 out).  One set of 1024 floats per image (the maxima are per image so
+  // that a batch gives every image exactly what it would get alone), kH2Imgs sets back to back, zero512 behind.
   float* amax;
-  float* amax_more;
   size_t gemm_ws_bytes, total;
 };
 
@@ -163,9 +162,8 @@ MlpWs mlp_layout(Bump& b, int n, bool split_g4 = false) {
   w.gemm_ws_bytes = mlp_gemm_ws(n);
   w.gemm_ws = b.take(w.gemm_ws_bytes);
   w.g4pre = split_g4 ? b.take((size_t)n * 512 * f) : nullptr;
-  w.amax = b.take(16 * 64 * f);
+  w.amax = b.take((size_t)kH2Imgs * 16 * 64 * f);
   w.zero512 = b.take(512 * f);
-  w.amax_more = b.take((size_t)(kH2Imgs - 1) * 16 * 64 * f);
   w.gemm_ws2 = split_g4 ? b.take(w.gemm_ws_bytes) : nullptr;
   w.total = b.off;
   return w;
@@ -199,57 +197,67 @@ DenseH2Prob h2_prob(const float* a, int K, const void* img, const float* bias, i
   return p;
 }
 
-// Slot set of image b; rows of image b start at row o in every per-point buffer.  All h2 phases work on ONE image
-// (n rows): the activation maxima -- hence the scales, hence every bit of the result -- do not depend on what else
-// is in the batch or on which entry point runs the layers.
-float* h2_slots(const MlpWs& s, int b) { return b == 0 ? s.amax : s.amax_more + (size_t)(b - 1) * 1024; }
+// The h2 phases work on `imgs` images of n rows each (rows image-major, first row o): ONE launch per layer for the
+// whole batch when n is a multiple of 64 (a 64-row tile then lies in one image and picks that image's maxima),
+// otherwise the caller loops over the images.  Either way the activation maxima -- hence the scales, hence every bit
+// of an image's result -- are the image's own: independent of the batch and of the entry point that runs the layers.
+float* h2_slots(const MlpWs& s, int b) { return s.amax + (size_t)b * 1024; }
 
-// fold1 of BOTH streams: embedding (+ its maxima, + clearing the later layers' slots and, for image 0, the zero
-// bias row behind them), then conv2 and conv3 of the two streams as two paired launches
-int mlp_fold1_h2(const disn_mlp_weights_t* w, const float* pts_rot, int n, const MlpWs& s, int b, size_t o,
+DenseH2Prob h2_batched(DenseH2Prob p, int imgs, int n) {
+  if (imgs > 1) { p.M = imgs * n; p.amax_rows = n; p.amax_stride = 1024; }
+  return p;
+}
+
+// fold1 of BOTH streams: embedding (+ its maxima per image, + clearing the later layers' slots and the zero bias
+// row), then conv2 and conv3 of the two streams as two paired launches
+int mlp_fold1_h2(const disn_mlp_weights_t* w, const float* pts_rot, int n, const MlpWs& s, int b, size_t o, int imgs,
                  hipStream_t st) {
   float* A = h2_slots(s, b);
-  DISN_TRY(pt_embed_launch(pts_rot, n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g + o * 64, s.e1l + o * 64, st, A, A + 128,
-                           14 * 64 + (b == 0 ? 512 : 0)));
-  DenseH2Prob p2[2] = {h2_prob(s.e1g + o * 64, 64, w->g_d2, w->g_b2, 256, 1, A + 0, s.g256 + o * 256, A + 128, n),
-                       h2_prob(s.e1l + o * 64, 64, w->l_d2, w->l_b2, 256, 1, A + 64, s.h256 + o * 256, A + 192, n)};
+  DISN_TRY(pt_embed_launch(pts_rot, (int64_t)imgs * n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g + o * 64, s.e1l + o * 64, st,
+                           A, b == 0 ? s.zero512 : nullptr, b == 0 ? 512 : 0, imgs));
+  DenseH2Prob p2[2] = {h2_batched(h2_prob(s.e1g + o * 64, 64, w->g_d2, w->g_b2, 256, 1, A + 0, s.g256 + o * 256, A + 128, n), imgs, n),
+                       h2_batched(h2_prob(s.e1l + o * 64, 64, w->l_d2, w->l_b2, 256, 1, A + 64, s.h256 + o * 256, A + 192, n), imgs, n)};
   DISN_TRY(dense_h2_launch(p2, 2, st));
-  DenseH2Prob p3[2] = {h2_prob(s.g256 + o * 256, 256, w->g_d3, w->g_b3, 512, 1, A + 128, s.g512 + o * 512, A + 256, n),
-                       h2_prob(s.h256 + o * 256, 256, w->l_d3, w->l_b3, 512, 1, A + 192, s.h512a + o * 512, A + 320, n)};
+  DenseH2Prob p3[2] = {h2_batched(h2_prob(s.g256 + o * 256, 256, w->g_d3, w->g_b3, 512, 1, A + 128, s.g512 + o * 512, A + 256, n), imgs, n),
+                       h2_batched(h2_prob(s.h256 + o * 256, 256, w->l_d3, w->l_b3, 512, 1, A + 192, s.h512a + o * 512, A + 320, n), imgs, n)};
   DISN_TRY(dense_h2_launch(p3, 2, st));
   return 0;
 }
 
 // the point half of the global fold2/conv1: g512 . W4_point, no bias, no ReLU -> `pre` (+ its maximum)
-int mlp_g4_pre_h2(const disn_mlp_weights_t* w, int n, const MlpWs& s, int b, size_t o, float* pre, hipStream_t st) {
+int mlp_g4_pre_h2(const disn_mlp_weights_t* w, int n, const MlpWs& s, int b, size_t o, int imgs, float* pre,
+                  hipStream_t st) {
   float* A = h2_slots(s, b);
-  const DenseH2Prob p = h2_prob(s.g512 + o * 512, 512, w->g_d4_point, s.zero512, 512, 0, A + 256, pre, A + 384, n);
+  const DenseH2Prob p = h2_batched(h2_prob(s.g512 + o * 512, 512, w->g_d4_point, s.zero512, 512, 0, A + 256, pre, A + 384, n), imgs, n);
   DISN_TRY(dense_h2_launch(&p, 1, st));
   return 0;
 }
 
-// local fold2/conv1 on [h512a | feat] read in place, fold2/conv2
+// local fold2/conv1 on [h512a | feat] read in place, fold2/conv2.
 // feat rows have feat_ld floats: 1472 (K = 1984, 64-column chunks) or 1536 with zero padding (K = 2048, 256-column
 // chunks).  A k-wave sums its k16 blocks in ascending order either way and the padding adds exact zeros: the two
 // forms give the same bits.  l_d4 is the [1984][512] matrix packed with 2048 rows (zero rows at the end).
 int mlp_phase1_h2(const disn_mlp_weights_t* w, int n, const float* feat, int feat_ld, const MlpWs& s, int b, size_t o,
-                  hipStream_t st) {
+                  int imgs, hipStream_t st) {
   float* A = h2_slots(s, b);
-  DISN_TRY(amax64_accumulate_launch(feat, (size_t)n * feat_ld, A + 448, st));
+  DISN_TRY(amax64_accumulate_launch(feat, (size_t)n * feat_ld, A + 448, st, imgs, 1024));
   DenseH2Prob p4 = h2_prob(s.h512a + o * 512, 512 + feat_ld, w->l_d4, w->l_b4, 512, 1, A + 320, s.h512b + o * 512,
                            A + 512, n);
   p4.lda = 512; p4.k1 = 512; p4.a2 = feat; p4.lda2 = feat_ld; p4.in_amax2 = A + 448; p4.Kimg = 2048;
+  p4 = h2_batched(p4, imgs, n);
   DISN_TRY(dense_h2_launch(&p4, 1, st));
-  const DenseH2Prob p5 = h2_prob(s.h512b + o * 512, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5 + o * 256, nullptr, n);
+  const DenseH2Prob p5 = h2_batched(h2_prob(s.h512b + o * 512, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5 + o * 256, nullptr, n), imgs, n);
   DISN_TRY(dense_h2_launch(&p5, 1, st));
   return 0;
 }
 
-// global fold2/conv2 on relu(pre + this image's bias row): the deferred bias + ReLU
+// global fold2/conv2 on relu(pre + the image's bias row): the deferred bias + ReLU
 int mlp_g5_h2(const disn_mlp_weights_t* w, int n, const float* pre, const float* gbias_b, const MlpWs& s, int b, size_t o,
-              hipStream_t st) {
+              int imgs, hipStream_t st) {
   DenseH2Prob p = h2_prob(pre, 512, w->g_d5, w->g_b5, 256, 1, h2_slots(s, b) + 384, s.g5 + o * 256, nullptr, n);
   p.in_bias = gbias_b;
+  if (imgs > 1) p.in_bias_rows = n;
+  p = h2_batched(p, imgs, n);
   DISN_TRY(dense_h2_launch(&p, 1, st));
   return 0;
 }
@@ -373,10 +381,10 @@ int mlp_chunk(const disn_mlp_weights_t* w, const float* pts_rot, int n, const fl
               const MlpWs& s, hipStream_t st) {
   int rc;
   if (mlp_h2(w, n)) {  // the same launches as disn_encode_query, on one stream (bit-identical results)
-    if ((rc = mlp_fold1_h2(w, pts_rot, n, s, 0, 0, st))) return rc;
-    if ((rc = mlp_phase1_h2(w, n, feat, DISN_FEAT_DIM, s, 0, 0, st))) return rc;
-    if ((rc = mlp_g4_pre_h2(w, n, s, 0, 0, s.h512a, st))) return rc;   // h512a is free once the local fold2/conv1 ran
-    if ((rc = mlp_g5_h2(w, n, s.h512a, gbias, s, 0, 0, st))) return rc;
+    if ((rc = mlp_fold1_h2(w, pts_rot, n, s, 0, 0, 1, st))) return rc;
+    if ((rc = mlp_phase1_h2(w, n, feat, DISN_FEAT_DIM, s, 0, 0, 1, st))) return rc;
+    if ((rc = mlp_g4_pre_h2(w, n, s, 0, 0, 1, s.h512a, st))) return rc;   // h512a is free once the local fold2/conv1 ran
+    if ((rc = mlp_g5_h2(w, n, s.h512a, gbias, s, 0, 0, 1, st))) return rc;
     DISN_TRY(final_dot_launch(s.g5, s.l5, n, w->g_w6, w->g_b6, w->l_w6, w->l_b6, sdf, sdf_g, sdf_l, out_div, st));
     return 0;
   }
@@ -827,6 +835,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   if (ctx->pipe_wait) DISN_TRY(hipStreamWaitEvent(st, ctx->pipe_wait, 0));  // behind the previous step's convolutions
   const bool h2 = two && B <= kH2Imgs && mlp_h2(mw, N);   // small point sets: the dense_h2 layers, image by image
   const int feat_ld = h2 && !featmap ? kFeatPad : DISN_FEAT_DIM;
+  const int hb = h2 && N % 64 == 0 ? B : 1;   // images per h2 launch
   if (two) {
     DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (orders aux behind the caller's inputs)
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
@@ -834,11 +843,12 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     // the auxiliary stream its launches, then the rest of the stack
     rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 0, 2);
     if (rc) return rc;
-    if (h2) {  // per image: fold1 of both streams (paired launches) and the point half of the global fold2/conv1
-      for (int b = 0; b < B; ++b) {
+    if (h2) {  // fold1 of both streams (paired launches) and the point half of the global fold2/conv1: one launch
+               // per layer for the whole batch (hb = B images at once) or image by image (hb = 1)
+      for (int b = 0; b < B; b += hb) {
         const size_t o = (size_t)b * N;
-        if ((rc = mlp_fold1_h2(mw, pts_rot + o * 3, N, e.q.mlp, b, o, ctx->aux))) return rc;
-        if ((rc = mlp_g4_pre_h2(mw, N, e.q.mlp, b, o, e.q.mlp.g4pre + o * 512, ctx->aux))) return rc;
+        if ((rc = mlp_fold1_h2(mw, pts_rot + o * 3, N, e.q.mlp, b, o, hb, ctx->aux))) return rc;
+        if ((rc = mlp_g4_pre_h2(mw, N, e.q.mlp, b, o, hb, e.q.mlp.g4pre + o * 512, ctx->aux))) return rc;
       }
     } else {
       DISN_TRY(pt_embed_launch(pts_rot, B * N, mw->g_w1, mw->g_b1, mw->l_w1, mw->l_b1, e.q.mlp.e1g, e.q.mlp.e1l, ctx->aux));
@@ -875,9 +885,9 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, ms, feat_ld));
   }
   if (h2) {
-    for (int b = 0; b < B; ++b) {
+    for (int b = 0; b < B; b += hb) {
       const size_t o = (size_t)b * N;
-      if ((rc = mlp_phase1_h2(mw, N, e.q.feat + o * feat_ld, feat_ld, e.q.mlp, b, o, ms))) return rc;
+      if ((rc = mlp_phase1_h2(mw, N, e.q.feat + o * feat_ld, feat_ld, e.q.mlp, b, o, hb, ms))) return rc;
     }
   } else if ((rc = mlp_phase1(mw, B * N, e.q.feat, e.q.mlp, ms))) return rc;
   if (two) {
@@ -886,9 +896,9 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   }
   { const int grc = gbias_layer(mw, embedding, B, e.q.gbias, e.q.gemv_ws, st); if (grc) return grc; }
   if (h2) {  // global fold2/conv2 on relu(pre + bias) per image, then -- behind ev[6] -- both fold2/conv5 and the sum
-    for (int b = 0; b < B; ++b) {
+    for (int b = 0; b < B; b += hb) {
       const size_t o = (size_t)b * N;
-      if ((rc = mlp_g5_h2(mw, N, e.q.mlp.g4pre + o * 512, e.q.gbias + (size_t)b * 512, e.q.mlp, b, o, st))) return rc;
+      if ((rc = mlp_g5_h2(mw, N, e.q.mlp.g4pre + o * 512, e.q.gbias + (size_t)b * 512, e.q.mlp, b, o, hb, st))) return rc;
     }
     DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
     DISN_TRY(final_dot_launch(e.q.mlp.g5, e.q.mlp.l5, (int64_t)B * N, mw->g_w6, mw->g_b6, mw->l_w6, mw->l_b6, sdf, nullptr,

@@ -107,12 +107,17 @@ __global__ __launch_bounds__(256 * NW, 1) void dense_h2_kernel(const DenseH2Dev 
   // ---- scales (requested here, used after the weight queue is in flight) -------------------------------------
   const int Kimg = P.Kimg > 0 ? P.Kimg : K;
   const float* meta = reinterpret_cast<const float*>(P.wimg + (size_t)Kimg * N * 4);
-  float amax_lane = P.in_amax[lane];
-  if (P.in_amax2) amax_lane = fmaxf(amax_lane, P.in_amax2[lane]);
+  const size_t aoff = P.amax_rows > 0 ? (size_t)(m0 / P.amax_rows) * P.amax_stride : 0;  // this tile's image
+  float amax_lane = P.in_amax[aoff + lane];
+  if (P.in_amax2) amax_lane = fmaxf(amax_lane, P.in_amax2[aoff + lane]);
   float bmax_lane = 0.f;
   if (P.in_bias) {
-    const int nb = P.in_bias_rows > 0 ? ((M + P.in_bias_rows - 1) / P.in_bias_rows) * K : K;
-    for (int i = lane; i < nb; i += 64) bmax_lane = fmaxf(bmax_lane, fabsf(P.in_bias[i]));
+    // the bound max|a| + max|in_bias|: over this tile's image when the maxima are per image (tiles do not straddle
+    // images then: the scale must not depend on the batch), else over every bias row of the call
+    const float* ib = P.in_bias;
+    int nb = P.in_bias_rows > 0 ? ((M + P.in_bias_rows - 1) / P.in_bias_rows) * K : K;
+    if (P.amax_rows > 0 && P.in_bias_rows > 0) { ib += (size_t)(m0 / P.in_bias_rows) * K; nb = K; }
+    for (int i = lane; i < nb; i += 64) bmax_lane = fmaxf(bmax_lane, fabsf(ib[i]));
   }
   const float inv_sw = meta[1];
 
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256 * NW, 1) void dense_h2_kernel(const DenseH2Dev 
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
     if (lane == 0)
-      atomicMax(reinterpret_cast<unsigned*>(P.out_amax) + ((blockIdx.x * WK * NW + wave) & 63), __float_as_uint(vmax));
+      atomicMax(reinterpret_cast<unsigned*>(P.out_amax) + aoff + ((blockIdx.x * WK * NW + wave) & 63), __float_as_uint(vmax));
   }
 }
 
@@ -238,6 +243,7 @@ hipError_t dense_h2_launch(const DenseH2Prob* probs, int nprob, hipStream_t st) 
     if (probs[i].M != probs[0].M || probs[i].N != probs[0].N || probs[i].K != probs[0].K || d.p[i].k1 != d.p[0].k1)
       return hipErrorInvalidValue;
     if (d.p[i].Kimg != 0 && d.p[i].Kimg < d.p[i].K) return hipErrorInvalidValue;
+    if (d.p[i].amax_rows > 0 && d.p[i].amax_rows % 64) return hipErrorInvalidValue;  // a 64-row tile must lie in one image
   }
   d.nprob = nprob;
   const DenseH2Prob& p = d.p[0];

@@ -240,7 +240,9 @@ hipError_t amax_launch(const float* x, size_t n, float* out, hipStream_t st);  /
 // the same into 64 slots (their maximum is max |x|) / the maximum of 64 slots -> out[0]
 hipError_t amax64_launch(const float* x, size_t n, float* out64, hipStream_t st);
 // the same without clearing the slots first (the caller's chain cleared them): one launch
-hipError_t amax64_accumulate_launch(const float* x, size_t n, float* out64, hipStream_t st);
+// images > 1: `images` arrays of n floats back to back, the slots of image i at out64 + i * out_stride
+hipError_t amax64_accumulate_launch(const float* x, size_t n, float* out64, hipStream_t st, int images = 1,
+                                    size_t out_stride = 0);
 hipError_t amax_fold_launch(const float* slots64, float* out, hipStream_t st);
 // one stream for n points of one image; pts_rot == nullptr: points k0.. of `grid`.  local: gather from
 // pmap + 'sdfprediction_imgfeat', out = (add_in + sum) / out_div; global: 'sdfprediction' with b4 = the
@@ -286,6 +288,8 @@ struct DenseH2Prob {     // out[M][N] = act(f(A) . W + bias), A = [a (k1 columns
   int ldc;
   float* out_amax;       // 64 slots (zeroed by the caller) or nullptr
   int M, N, K, relu;
+  int amax_rows;         // > 0: rows per image (a multiple of 64): the maxima of the tile's image are read / written at
+  int amax_stride;       //      in_amax / in_amax2 / out_amax + image * amax_stride
 };
 struct DenseH2Dev {
   DenseH2Prob p[2];
@@ -299,9 +303,13 @@ hipError_t dense_h2_launch(const DenseH2Prob* probs, int nprob, hipStream_t st);
 // relu(p . W1 + b1) for both streams: pts [M][3] -> out_g [M][64], out_l [M][64]
 // amax_gl (optional): 128 floats, [0..63] slots of max |out_g|, [64..127] of max |out_l| (dense_h2.hip reads the
 // maximum over the slots); zero / nzero (optional): floats this launch also clears
+// images > 1 (with amax_gl): M = images * rows_per_image rows image-major; the slot set of image i (1024 floats:
+// see api.hip MlpWs) at amax_gl + i * 1024: [0..63] / [64..127] its two maxima, [128..1023] cleared; zero / nzero
+// additionally cleared once
 hipError_t pt_embed_launch(const float* pts, int64_t M, const float* g_w1, const float* g_b1,
                            const float* l_w1, const float* l_b1, float* out_g, float* out_l,
-                           hipStream_t st, float* amax_gl = nullptr, float* zero = nullptr, int nzero = 0);
+                           hipStream_t st, float* amax_gl = nullptr, float* zero = nullptr, int nzero = 0,
+                           int images = 1);
 // sdf[m] = (g5[m].g_w6 + g_b6) + (l5[m].l_w6 + l_b6); optional separate outputs
 hipError_t final_dot_launch(const float* g5, const float* l5, int64_t M, const float* g_w6,
                             const float* g_b6, const float* l_w6, const float* l_b6, float* sdf,

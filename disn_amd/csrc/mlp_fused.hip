@@ -168,7 +168,10 @@ hipError_t mlp_fused_pack_launch(const float* w2, const float* w3, const float* 
 // per workgroup; same-address atomics serialise in L2 at ~10 ns each, hence few workgroups and optional slots).
 // out[0 .. slots) must be zeroed first (the launchers do)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, size_t n4, float* __restrict__ out,
-                                                   int slots) {
+                                                   int slots, size_t out_stride) {
+  // blockIdx.y: image -- n4 float4 each, back to back; its slots at out + image * out_stride
+  x += (size_t)blockIdx.y * n4 * 4;
+  out += (size_t)blockIdx.y * out_stride;
   __shared__ float red[4];
   float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -185,21 +188,23 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   }
 }
 
-static hipError_t amax_go(const float* x, size_t n, float* out, int slots, hipStream_t st, bool clear = true) {
+static hipError_t amax_go(const float* x, size_t n, float* out, int slots, hipStream_t st, bool clear = true,
+                          int images = 1, size_t out_stride = 0) {
   if (clear) {
     const hipError_t e = hipMemsetAsync(out, 0, slots * sizeof(float), st);
     if (e != hipSuccess) return e;
   }
   const size_t n4 = n / 4;
   const int grid = (int)(n4 < 512 * 256 ? (n4 + 255) / 256 : 512);
-  hipLaunchKernelGGL(amax_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, x, n4, out, slots);
+  hipLaunchKernelGGL(amax_kernel, dim3(grid > 0 ? grid : 1, images), dim3(256), 0, st, x, n4, out, slots, out_stride);
   return hipGetLastError();
 }
 hipError_t amax_launch(const float* x, size_t n, float* out, hipStream_t st) { return amax_go(x, n, out, 1, st); }
 // the 64-slot form the conv_h2 kernels read (max over the slots = max |x|)
 hipError_t amax64_launch(const float* x, size_t n, float* out64, hipStream_t st) { return amax_go(x, n, out64, 64, st); }
-hipError_t amax64_accumulate_launch(const float* x, size_t n, float* out64, hipStream_t st) {
-  return amax_go(x, n, out64, 64, st, false);
+hipError_t amax64_accumulate_launch(const float* x, size_t n, float* out64, hipStream_t st, int images,
+                                    size_t out_stride) {
+  return amax_go(x, n, out64, 64, st, false, images, out_stride);
 }
 
 __global__ void amax_fold_kernel(const float* __restrict__ slots64, float* __restrict__ out) {

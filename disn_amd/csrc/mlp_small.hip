@@ -14,16 +14,21 @@ __global__ __launch_bounds__(256) void pt_embed_kernel(const float* __restrict__
                                                        float* __restrict__ out_g,
                                                        float* __restrict__ out_l,
                                                        float* __restrict__ amax_gl,
-                                                       float* __restrict__ zero, int nzero) {
+                                                       float* __restrict__ zero, int nzero, int images) {
   // side job of the first launch of a point-MLP chain (dense_h2.hip layers): clear the activation-maximum slots
-  // of the layers behind it and the all-zero bias row
+  // of the layers behind it (slots 128..1023 of every image's set) and the all-zero bias row
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) zero[i] = 0.f;
+  // with maxima: gridDim.x = images * G workgroups, workgroup (img, iw) walks the rows of image img only
+  const int G = amax_gl ? gridDim.x / images : gridDim.x;
+  const int img = amax_gl ? blockIdx.x / G : 0, iw = amax_gl ? blockIdx.x - img * G : blockIdx.x;
+  const int64_t rows = amax_gl ? M / images : M;
+  if (amax_gl)
+    for (int i = iw * blockDim.x + threadIdx.x; i < 896; i += G * blockDim.x) amax_gl[(size_t)img * 1024 + 128 + i] = 0.f;
   // thread -> (point, 4 channels of one stream): 32 threads per point (16 per stream)
-  const int64_t total = M * 32;
+  const int64_t total = rows * 32;
   float mx = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i >> 5;
+  for (int64_t i = (int64_t)iw * blockDim.x + threadIdx.x; i < total; i += (int64_t)G * blockDim.x) {
+    const int64_t m = (int64_t)img * rows + (i >> 5);
     const int q = (int)(i & 31);
     const bool local = q >= 16;
     const int c = (q & 15) * 4;
@@ -58,22 +63,24 @@ __global__ __launch_bounds__(256) void pt_embed_kernel(const float* __restrict__
     __syncthreads();
     if (threadIdx.x < 2) {
       const int st = threadIdx.x;
-      amax_gl[64 * st + blockIdx.x] = fmaxf(fmaxf(red[st][0], red[st][1]), fmaxf(red[st][2], red[st][3]));
-      if (blockIdx.x == 0)
-        for (int i = gridDim.x; i < 64; ++i) amax_gl[64 * st + i] = 0.f;
+      float* a = amax_gl + (size_t)img * 1024 + 64 * st;
+      a[iw] = fmaxf(fmaxf(red[st][0], red[st][1]), fmaxf(red[st][2], red[st][3]));
+      if (iw == 0)
+        for (int i = G; i < 64; ++i) a[i] = 0.f;
     }
   }
 }
 
 hipError_t pt_embed_launch(const float* pts, int64_t M, const float* g_w1, const float* g_b1,
                            const float* l_w1, const float* l_b1, float* out_g, float* out_l,
-                           hipStream_t st, float* amax_gl, float* zero, int nzero) {
-  int64_t blocks = (M * 32 + 255) / 256;
+                           hipStream_t st, float* amax_gl, float* zero, int nzero, int images) {
+  if (images < 1 || !amax_gl) images = 1;
+  int64_t blocks = (M / images * 32 + 255) / 256;  // per image
   if (blocks > 16384) blocks = 16384;
   if (amax_gl && blocks > 64) blocks = 64;  // one maximum slot per workgroup
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(pt_embed_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pts, M, g_w1, g_b1,
-                     l_w1, l_b1, out_g, out_l, amax_gl, zero, nzero);
+  hipLaunchKernelGGL(pt_embed_kernel, dim3((unsigned)(blocks * images)), dim3(256), 0, st, pts, M, g_w1, g_b1,
+                     l_w1, l_b1, out_g, out_l, amax_gl, zero, nzero, images);
   return hipGetLastError();
 }
 
