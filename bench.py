@@ -24,7 +24,8 @@ Besides the contract line's fields the JSON carries
   roofline      -- the dominant kernel family (the 13 convolutions of one step: conv_h2.hip, two-term f16
                    split on the f16 MFMA pipes): their algorithmic FLOP / the duration of the launch chain
                    measured with events on the launch stream, against the 157.3 TFLOP/s fp32-MFMA peak;
-  single_stream -- one step at a time (the main line keeps --in-flight independent steps on the GPU);
+  single_stream -- one step at a time (the main line submits --batch independent steps per call and keeps
+                   --in-flight calls on the GPU);
   roofline_gather -- the gathers that are actually on the timed paths: project_gather_taps_kernel (the
                    step), gather_fold_kernel (layer-by-layer dense grid), and gather_kernel from
                    materialised maps incl. a 3-image case that exceeds the 256 MB Infinity Cache;
@@ -266,9 +267,13 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 300 query, 5 grid, 50 train)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 20 query, 1 grid, 5 train)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / grid / cpu legs")
-    ap.add_argument("--in-flight", type=int, default=3,
-                    help="--workload query: independent steps in flight on this GPU (disn_amd.engine.StepPipeline: one "
-                         "HIP stream + host thread per step context); 1 = one step at a time")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="--workload query: independent submissions in flight on this GPU (disn_amd.engine.StepPipeline: "
+                         "one HIP stream + host thread per context); 1 = one at a time")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="--workload query: consecutive independent steps (image + 2048 points each) submitted as ONE "
+                         "disn_encode_query call (StepPipeline(batch=)); every image keeps its own activation scales, "
+                         "so its result is bit for bit the single-step one; 1 = one step per call")
     ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--workload", choices=("query", "grid", "train"), default="query",
                     help="query: BASELINE.json metric (default); grid: configs 3/4 (dense grid + gather + marching "
@@ -343,7 +348,8 @@ def main():
     from disn_amd.engine import StepPipeline
     store = WeightStore.random_init(0, mode="xavier")          # "random-init weights" (create_sdf.py:184-192)
     S = max(1, args.in_flight)
-    pipe = StepPipeline(store, dev, in_flight=S)
+    SB = max(1, args.batch)
+    pipe = StepPipeline(store, dev, in_flight=S, batch=SB)
     eng = pipe.engines[0]
     rng = np.random.default_rng(1000 + rank)
     img = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32)).to(dev)
@@ -351,11 +357,11 @@ def main():
     tm = torch.tensor([DEMO_TM], dtype=torch.float32, device=dev)
 
     def run_steps(k):
-        # rows A..H, every step, through the single overlapped entry (disn_encode_query); S steps in flight:
-        # step j runs on engine context j % S (own HIP stream, own host thread); nothing shared between steps
+        # rows A..H, every step, through the single overlapped entry (disn_encode_query): SB consecutive steps per
+        # call, call j on engine context j % S (own HIP stream, own host thread); nothing cached between steps
         return pipe.run([(img, pts, tm)] * k)
 
-    run_steps(max(args.warmup, S))
+    run_steps(max(args.warmup, S * SB))
     torch.cuda.synchronize()
     if launched:
         dist.barrier()
@@ -383,11 +389,15 @@ def main():
         "config": {"workload": "BASELINE config 2: VGG-16 encode + 2048 random query points, img_feat_twostream, "
                                "fp32, random-init (xavier) weights, nothing cached between steps",
                    "images_per_step_per_gpu": 1, "points_per_step_per_gpu": N_POINTS,
-                   "steps_in_flight": S,
-                   "steps_in_flight_note": "independent steps (own image, own workspaces, own HIP stream and host "
-                                           "thread) overlap on the GPU and fill the gaps between each other's ~35 "
-                                           "dependent launches; every step does all of its work; --in-flight 1 = "
-                                           "one step at a time (see single_stream)",
+                   "steps_per_call": SB, "calls_in_flight": S,
+                   "submission_note": "a STEP is one image + its 2048 query points, all of rows A..H; %d consecutive "
+                                      "independent steps go into one disn_encode_query call (the fc weights, 495 MB, "
+                                      "are read once per call; every launch carries %d images against the same fixed "
+                                      "cost; per-image activation scales keep every image's result bit-identical to "
+                                      "the step run alone: tests/test_gpu_model.py) and %d such calls are in flight "
+                                      "(own workspaces, HIP stream and host thread each), filling the gaps between "
+                                      "each other's dependent launches; --batch 1 --in-flight 1 = one step at a "
+                                      "time (see single_stream)" % (SB, SB, S),
                    "parallelism": "replicas x%d (no data-path collective)%s" % (
                        world, "; ranks SHARE GPUs (plumbing run)" if shared_gpu else "")},
     }
@@ -396,18 +406,29 @@ def main():
         print("[bench] main line: %.4g points/s, %.4f ms/step" % (value, line["ms_per_step"]), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_extras:   # roofline / cpu legs: N=1 only (bench contract)
         # ---- one step at a time (the latency of a step; the main line overlaps S independent steps) ----------
-        if S > 1:
+        if S > 1 or SB > 1:
             ms1 = ev_time_ms(lambda: eng.encode_query(img, pts, tm), 50, torch)
             line["single_stream"] = {"ms_per_step": ms1, "points_per_s": N_POINTS / ms1 * 1e3,
-                                     "note": "--in-flight 1: one step at a time, its ~35 dependent launches back to back"}
+                                     "note": "--batch 1 --in-flight 1: one step at a time, its ~35 dependent launches back to back "
+                                             "(the latency of a step)"}
         # ---- roofline of the dominant kernel family: the 13 convolution launches of one step ----------------
         # Timed as the step runs them: ONE disn_vgg16_conv_stack call = resize + conv1_1_direct_kernel + 12
         # conv_h2_kernel launches (two-term f16 split: fp32-accurate, f16 MFMA pipes, fused pools), back to back
         # on the launch stream, HIP events around the call.  The resize launch (~5 us, 0.08 GFLOP-equivalent of
         # nothing) is inside the bracket and charged to the family.
-        stack = ops.ConvStackRun(eng.weights.vgg, img, want_pool5=False)
-        tot_ms = ev_time_ms(stack.run, 50, torch)
-        tot_flop = sum(2.0 * hw * hw * cout * 9 * cin for cin, cout, hw in VGG_LAYERS)
+        # The main line submits SB images per call, so the launches of the timed region are the SB-image ones:
+        # they are the roofline's primary figures; the single-image chain (what rounds 1 and 2a reported, and what a
+        # step run alone executes) is kept beside them as `single_image`.
+        flop1 = sum(2.0 * hw * hw * cout * 9 * cin for cin, cout, hw in VGG_LAYERS)
+        stack1 = ops.ConvStackRun(eng.weights.vgg, img, want_pool5=False)
+        ms_1 = ev_time_ms(stack1.run, 50, torch)
+        if SB > 1:
+            imgs_sb = torch.from_numpy(rng.random((SB, 137, 137, 3), dtype=np.float32)).to(dev)
+            stack = ops.ConvStackRun(eng.weights.vgg, imgs_sb, want_pool5=False)
+            tot_ms = ev_time_ms(stack.run, 50, torch)
+        else:
+            tot_ms = ms_1
+        tot_flop = flop1 * SB
         ach = tot_flop / tot_ms / 1e9
         # HBM-side bytes of the same 13 launches from the PMC passes of the last profiled build
         # (profiles/pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/gpu_pmc_traffic.sh,
@@ -416,11 +437,15 @@ def main():
         traffic, pmc = None, {}
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            traffic = pmc["conv_family_per_step"]["hbm_bytes"]
+            if SB == 1:
+                traffic = pmc["conv_family_per_step"]["hbm_bytes"]
+            elif (pmc.get("conv_family_batched") or {}).get("images") == SB:
+                traffic = pmc["conv_family_batched"]["hbm_bytes"]
         except Exception:
             pass
         peak_h2 = 2500.0 / 3.0   # fp32-equivalent ceiling of the two-term method: 3 f16 MFMAs (2.5 PFLOP/s dense) per block
-        line["roofline"] = {"kernel": "the 13 convolutions of one VGG-16 forward at B=1, as one disn_vgg16_conv_stack call: "
+        line["roofline"] = {"kernel": "the 13 convolutions of one VGG-16 forward on the %d image(s) of one submitted call, "
+                                      "as one disn_vgg16_conv_stack call: " % SB +
                                       "conv1_1_direct_kernel (fp32 FMA) + 12 conv_h2_kernel launches (two-term f16 split, "
                                       "fp32-accurate, f16 MFMA pipes, pools fused) + the resize launch",
                             "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -430,12 +455,17 @@ def main():
                                          "is 2500/3 = 833 TFLOP/s (frac_of_two_term_ceiling)",
                             "frac_of_two_term_ceiling": ach / peak_h2, "traffic": traffic,
                             "traffic_measured_on": pmc.get("build"),
-                            "traffic_note": "memory-side bytes per step of the 13 conv launches (FETCH_SIZE x2 + calibrated "
+                            "traffic_note": "memory-side bytes per call of the 13 conv launches (FETCH_SIZE x2 + calibrated "
                                             "WRITE_SIZE; L2 misses served by MALL count), replayed from "
                                             "profiles/pmc_traffic.json (PMC passes of tools/gpu_pmc_traffic.sh on the build "
-                                            "named in traffic_measured_on); algorithmic ~165 MB (two-plane f16 weights 59 + "
-                                            "inputs 36 + outputs and pooled copies 68)",
-                            "flop_per_step": tot_flop, "ms_per_step": tot_ms, "launches": 14,
+                                            "named in traffic_measured_on); algorithmic per call ~59 MB two-plane f16 weights "
+                                            "+ ~104 MB per image (inputs 36 + outputs and pooled copies 68)",
+                            "images_per_call": SB, "flop_per_call": tot_flop, "ms_per_call": tot_ms, "launches": 14,
+                            "single_image": {"ms": ms_1, "achieved": flop1 / ms_1 / 1e9,
+                                             "frac": flop1 / ms_1 / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+                                             "traffic": (pmc.get("conv_family_per_step") or {}).get("hbm_bytes"),
+                                             "note": "the same chain on ONE image (a step run alone; the figure of "
+                                                     "the earlier rounds)"},
                             "per_launch": "profiles/r02*_conv_stack_trace.txt (rocprofv3 kernel trace of the same call); a "
                                           "layer alone takes 9-21 us, ~5-8 us more as a link of the chain"}
         # ---- gathers (HBM / cache bound): the kernels that ARE on the timed paths ---------------------

@@ -305,7 +305,8 @@ class StepPipeline:
         """``batch``: consecutive jobs of equal shape are submitted ``batch`` at a time as ONE disn_encode_query call
         (images and point sets concatenated): the 495 MB of fc weights are read once per call instead of once per
         image, and every launch has ``batch`` times the work against the same fixed cost.  Every image keeps its own
-        activation scales and its own MLP launches, so its result is bit for bit what it gets alone."""
+        activation scales (one slot set per image, picked per row tile inside the one launch of a layer), so its result
+        is bit for bit what it gets alone."""
         import threading
         self.batch = max(1, int(batch))
         self._threading = threading

@@ -1,5 +1,6 @@
 """Conv stack only (resize + 13 convolutions, no fc head), repeated: per-launch durations under rocprofv3 show what
-the layers cost when nothing else (fc6's 411 MB stream) passes through the caches between two forwards."""
+the layers cost when nothing else (fc6's 411 MB stream) passes through the caches between two forwards.
+usage: conv_stack_time.py [B]   (B images per call, default 1)"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,9 +8,10 @@ from disn_amd import ops
 from disn_amd.engine import SdfEngine
 from disn_amd.weights import WeightStore
 eng = SdfEngine(WeightStore.random_init(0))
-img = torch.from_numpy(np.random.default_rng(0).random((1, 137, 137, 3), dtype=np.float32)).cuda()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+img = torch.from_numpy(np.random.default_rng(0).random((B, 137, 137, 3), dtype=np.float32)).cuda()
 r = ops.ConvStackRun(eng.weights.vgg, img, want_pool5=False)
 for _ in range(5): r.run()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(100): r.run()
-torch.cuda.synchronize(); print("conv stack: %.1f us per forward" % ((time.perf_counter() - t0) / 100 * 1e6))
+torch.cuda.synchronize(); print("conv stack, %d image(s) per call: %.1f us per call" % (B, (time.perf_counter() - t0) / 100 * 1e6))

@@ -14,18 +14,28 @@ if has tests; then
 fi
 if has bench; then
   timeout 600 python bench.py --steps 200 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; tail -3 $OUT/bench.err
-  timeout 120 python bench.py --steps 200 --warmup 10 --in-flight 1 --no-extras 2>&1 | tail -2 | cut -c1-120
+  for v in "--batch 1 --in-flight 1" "--batch 1 --in-flight 3" "--batch 4 --in-flight 1" "--batch 6 --in-flight 2"; do
+    echo "variant $v" | tee -a $OUT/bench_variants.txt
+    timeout 120 python bench.py --steps 240 --warmup 24 $v --no-extras 2>/dev/null | tail -1 | cut -c1-260 | tee -a $OUT/bench_variants.txt
+  done
 fi
 if has grid; then
   timeout 300 python bench.py --workload grid --steps 3 --warmup 1 > $OUT/bench_grid1.json 2> $OUT/bench_grid1.err; echo "grid exit $?"; tail -c 400 $OUT/bench_grid1.json
 fi
 if has prof; then
-  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-extras --in-flight 1 > /tmp/prof_$TAG.log 2>&1; echo "rocprof exit $?")
-  for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/bench_kernel_stats.csv; done
+  # (a) the main line's own command (default --batch / --in-flight), kernel stats
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profm_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 8 --no-extras > /tmp/profm_$TAG.log 2>&1; echo "rocprof main exit $?")
+  for f in $(find /tmp/profm_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/bench_kernel_stats.csv; done
+  # (b) one step at a time: the launch sequence of a step
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-extras --in-flight 1 --batch 1 > /tmp/prof_$TAG.log 2>&1; echo "rocprof exit $?")
+  for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/bench_single_kernel_stats.csv; done
   python tools/trace_step.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null | grep -v "at::native\|rocclr_copy" > $OUT/infer_step_trace.txt; tail -3 $OUT/infer_step_trace.txt
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profc_$TAG -o trace -- python $GRAFT_REPO_ROOT/tools/conv_stack_time.py > /tmp/profc_$TAG.log 2>&1; echo "rocprof conv stack exit $?")
   for f in $(find /tmp/profc_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/conv_stack_kernel_stats.csv; done
   python tools/trace_step.py $(find /tmp/profc_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null > $OUT/conv_stack_trace.txt; tail -2 $OUT/conv_stack_trace.txt
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profc4_$TAG -o trace -- python $GRAFT_REPO_ROOT/tools/conv_stack_time.py 4 > /tmp/profc4_$TAG.log 2>&1; echo "rocprof conv stack x4 exit $?")
+  for f in $(find /tmp/profc4_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/conv_stack_b4_kernel_stats.csv; done
+  python tools/trace_step.py $(find /tmp/profc4_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null > $OUT/conv_stack_b4_trace.txt; tail -2 $OUT/conv_stack_b4_trace.txt
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profk_$TAG -o trace -- python $GRAFT_REPO_ROOT/tools/prof_kernels.py > /tmp/profk_$TAG.log 2>&1; echo "rocprof kernels exit $?")
   for f in $(find /tmp/profk_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/kernels_kernel_stats.csv; done
 fi

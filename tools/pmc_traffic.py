@@ -44,6 +44,10 @@ for pos, i in enumerate(ids):
             nxt = fetch[ids[pos + 1]]["name"]
             if "splitk_reduce" in nxt or "streamk_fixup" in nxt:
                 conv.append(ids[pos + 1])
+# the LAST 13 conv launches, when there are more than the steps' (prof_kernels.py ends with one PROF_BATCH-image stack)
+all_conv = [i for i in ids if is_conv(fetch[i]["name"])]
+batched = all_conv[-13:] if len(all_conv) >= 39 else []
+batch_images = int(os.environ.get("PROF_BATCH", "4"))
 gathers = [i for i in ids if "gather_kernel" in fetch[i]["name"] and "project" not in fetch[i]["name"]]
 g_small = [i for i in gathers if int(fetch[i]["grid"]) < 1_000_000][-1]
 g_big = [i for i in gathers if int(fetch[i]["grid"]) >= 1_000_000][-1]
@@ -73,6 +77,10 @@ out = {"build": build, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separ
                                     "inputs ~36 MB + outputs ~54 MB (+ 14 MB pooled copies); every workgroup re-reads its "
                                     "n-block's weights and its halo through L2 (hits there are not counted, MALL hits "
                                     "are); three-term build: weights 88 MB + split-K partials"),
+       "conv_family_batched": (dict(hbm(batched), images=batch_images,
+                                    note="one disn_vgg16_conv_stack call on %d images (what bench.py's main line "
+                                         "submits per call): the weights are fetched once for the batch" % batch_images)
+                               if batched else None),
        "gather_n2048": dict(hbm([g_small]), algorithmic_bytes=2048 * 29440),
        "gather_n262144": dict(hbm([g_big]), algorithmic_bytes=262144 * 29440),
        "gather_from_taps_n2048": (dict(hbm(g_taps[-1:]), algorithmic_bytes=2048 * (16 * 5888 + 5888),

@@ -1,6 +1,8 @@
 """Small, bounded workload for rocprofv3 passes (kernel trace or one PMC counter at a time):
 PROF_STEPS x (encode + 2048-point query), one standalone gather at 2048 and 262144 points,
-one 65536-point query through the layer-by-layer chain and through the fused kernels, one single-call step (disn_encode_query: no feature map, gather from the taps)."""
+one 65536-point query through the layer-by-layer chain and through the fused kernels, one single-call step
+(disn_encode_query: no feature map, gather from the taps), and LAST one convolution stack on PROF_BATCH images
+(default 4: the batch bench.py's main line submits per call)."""
 import os, sys
 import numpy as np
 import torch
@@ -30,5 +32,10 @@ for _ in range(2):
 for _ in range(2):
     eng.query(enc, p, tm, fused=True)       # mlp_fused_kernel<global>, <local>
 eng.encode_query(img, pts, tm)
+torch.cuda.synchronize()
+PB = int(os.environ.get("PROF_BATCH", "4"))
+if PB > 0:
+    imgs = torch.from_numpy(rng.random((PB, 137, 137, 3), dtype=np.float32)).cuda()
+    ops.ConvStackRun(eng.weights.vgg, imgs, want_pool5=False).run()
 torch.cuda.synchronize()
 print("done")
