@@ -11,6 +11,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
+import time
+
 import numpy as np
 import torch
 
@@ -307,8 +309,10 @@ class StepPipeline:
         image, and every launch has ``batch`` times the work against the same fixed cost.  Every image keeps its own
         activation scales (one slot set per image, picked per row tile inside the one launch of a layer), so its result
         is bit for bit what it gets alone."""
+        import queue
         import threading
         self.batch = max(1, int(batch))
+        self.trace = None      # a list: run() appends (context, call index, time.perf_counter() after enqueueing)
         self._threading = threading
         # Stream / context creation ORDER matters: ROCm hands out its hardware queues (GPU_MAX_HW_QUEUES, default
         # 4 including the null stream's) to streams in creation order and shares them afterwards, and two streams
@@ -331,10 +335,53 @@ class StepPipeline:
                 eng = SdfEngine(store if weights is None else None, self.device, weights=weights)
                 weights = eng.weights
                 self.engines.append(eng)
+        # one host thread per context, alive for the pipeline's life (a thread started per run() costs ~0.5 ms
+        # before its first launch: visible when a run is only a few calls long); it keeps its stream current
+        self._queues = [queue.SimpleQueue() for _ in range(in_flight)]
+        self._workers = [threading.Thread(target=StepPipeline._worker, daemon=True,
+                                          args=(i, self._queues[i], self.device, self.streams[i]))
+                         for i in range(in_flight)]      # (no reference to self: the pipeline stays collectable)
+        for t in self._workers:
+            t.start()
+
+    @staticmethod
+    def _worker(i, q, device, stream):
+        with torch.cuda.device(device), torch.cuda.stream(stream):
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                fn, errs, done = item
+                try:
+                    fn(i)
+                except BaseException as e:  # noqa: BLE001 -- handed to the caller of run()
+                    errs.append(e)
+                finally:
+                    del fn, item
+                    done.release()
+
+    def _dispatch(self, fn, n):
+        """fn(i) on the host thread of context i for i < n; returns when all have returned, re-raises their errors"""
+        errs, done = [], self._threading.Semaphore(0)
+        for i in range(n):
+            self._queues[i].put((fn, errs, done))
+        for _ in range(n):
+            done.acquire()
+        if errs:
+            raise errs[0]
+
+    def close(self):
+        """stop the host threads, free the contexts and streams (also done when the pipeline is collected)"""
+        self.__del__()
 
     def __del__(self):
         try:
             with torch.cuda.device(self.device):
+                for q in getattr(self, "_queues", []):
+                    q.put(None)
+                for t in getattr(self, "_workers", []):
+                    t.join(timeout=5)
+                self._queues, self._workers = [], []
                 torch.cuda.synchronize(self.device)
                 self.engines = []
                 for h in self._handles:
@@ -385,18 +432,13 @@ class StepPipeline:
                 cur.wait_stream(st)
             return out
 
-        def work(i):
-            with torch.cuda.device(self.device), torch.cuda.stream(self.streams[i]):
-                self.streams[i].wait_stream(cur)          # inputs produced on the caller's stream
-                for k in range(i, len(jobs), S):
-                    enc, sdf = self.engines[i].encode_query(*jobs[k])
-                    out[k] = (enc, sdf) if keep_encoded else sdf
+        def work(i):                                      # on context i's host thread: its stream is current
+            self.streams[i].wait_stream(cur)              # inputs produced on the caller's stream
+            for k in range(i, len(jobs), S):
+                enc, sdf = self.engines[i].encode_query(*jobs[k])
+                out[k] = (enc, sdf) if keep_encoded else sdf
 
-        threads = [self._threading.Thread(target=work, args=(i,)) for i in range(min(S, len(jobs)))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        self._dispatch(work, min(S, len(jobs)))
         for st in self.streams:
             cur.wait_stream(st)                            # results are ordered before later work on the caller's stream
         return out
@@ -413,29 +455,26 @@ class StepPipeline:
             return ts[0] if len(ts) == 1 else torch.cat(ts, dim=0)
 
         def work(i):
-            with torch.cuda.device(self.device), torch.cuda.stream(self.streams[i]):
-                self.streams[i].wait_stream(cur)
-                for g in range(i, len(groups), S):
-                    idx = groups[g]
-                    if len({tuple(jobs[k][1].shape) for k in idx}) != 1:
-                        raise ValueError("jobs of one batch must have point sets of one shape")
-                    args = [cat(idx, p) for p in range(len(jobs[idx[0]]))]
-                    enc, sdf = self.engines[i].encode_query(*args)
-                    o = 0
-                    for k in idx:
-                        b = jobs[k][0].shape[0]
-                        if keep_encoded:
-                            e = Encoded(enc.resized[o:o + b], [t[o:o + b] for t in enc.taps], enc.embedding[o:o + b], None)
-                            out[k] = (e, sdf[o:o + b])
-                        else:
-                            out[k] = sdf[o:o + b]
-                        o += b
+            self.streams[i].wait_stream(cur)
+            for g in range(i, len(groups), S):
+                idx = groups[g]
+                if len({tuple(jobs[k][1].shape) for k in idx}) != 1:
+                    raise ValueError("jobs of one batch must have point sets of one shape")
+                args = [cat(idx, p) for p in range(len(jobs[idx[0]]))]
+                enc, sdf = self.engines[i].encode_query(*args)
+                if self.trace is not None:       # host-side pacing: when this call's launches were all enqueued
+                    self.trace.append((i, g, time.perf_counter()))
+                o = 0
+                for k in idx:
+                    b = jobs[k][0].shape[0]
+                    if keep_encoded:
+                        e = Encoded(enc.resized[o:o + b], [t[o:o + b] for t in enc.taps], enc.embedding[o:o + b], None)
+                        out[k] = (e, sdf[o:o + b])
+                    else:
+                        out[k] = sdf[o:o + b]
+                    o += b
 
-        threads = [self._threading.Thread(target=work, args=(i,)) for i in range(min(S, len(groups)))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        self._dispatch(work, min(S, len(groups)))
         for st in self.streams:
             cur.wait_stream(st)
         return out

@@ -6,14 +6,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from disn_amd.engine import StepPipeline
 from disn_amd.weights import WeightStore
 B = int(sys.argv[1]); S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+if os.environ.get("ORDER") == "bench":      # bisecting bench.py vs this tool: the same preamble as bench.py
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
 pipe = StepPipeline(WeightStore.random_init(0), in_flight=S, batch=B)
 rng = np.random.default_rng(0)
 img = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32)).cuda()
 pts = torch.rand((1, 2048, 3), device="cuda") * 2 - 1
+if os.environ.get("SRC") == "bench":
+    rng = np.random.default_rng(1000)
+    img = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32)).cuda()
+    pts = torch.from_numpy((rng.random((1, 2048, 3), dtype=np.float32) * 2 - 1).astype(np.float32)).cuda()
 tm1 = [[-68.453156, 5.5086656, -0.37556022], [-17.138561, -84.685486, -0.250198],
        [-47.284092, -3.6569588, 0.2493176], [101.133705, 101.34268, 1.4305686]]
 tm = torch.tensor([tm1], device="cuda")
-K = 360
+K = int(os.environ.get('K', '360'))
 pipe.run([(img, pts, tm)] * (3 * S * B)); torch.cuda.synchronize()
 res = []
 for _ in range(3):
