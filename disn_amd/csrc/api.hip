@@ -202,6 +202,7 @@ DenseH2Prob h2_prob(const float* a, int K, const void* img, const float* bias, i
 // otherwise the caller loops over the images.  Either way the activation maxima -- hence the scales, hence every bit
 // of an image's result -- are the image's own: independent of the batch and of the entry point that runs the layers.
 float* h2_slots(const MlpWs& s, int b) { return s.amax + (size_t)b * 1024; }
+constexpr int kFeatMaxSlot = 576;  // floats 576 .. 1023 of a set: up to 448 per-workgroup maxima of the gather
 
 DenseH2Prob h2_batched(DenseH2Prob p, int imgs, int n) {
   if (imgs > 1) { p.M = imgs * n; p.amax_rows = n; p.amax_stride = 1024; }
@@ -237,13 +238,15 @@ int mlp_g4_pre_h2(const disn_mlp_weights_t* w, int n, const MlpWs& s, int b, siz
 // feat rows have feat_ld floats: 1472 (K = 1984, 64-column chunks) or 1536 with zero padding (K = 2048, 256-column
 // chunks).  A k-wave sums its k16 blocks in ascending order either way and the padding adds exact zeros: the two
 // forms give the same bits.  l_d4 is the [1984][512] matrix packed with 2048 rows (zero rows at the end).
+// feat_amax_done: the gather left its per-workgroup maxima of |feat| in the set's free tail (project_gather_taps_kernel)
 int mlp_phase1_h2(const disn_mlp_weights_t* w, int n, const float* feat, int feat_ld, const MlpWs& s, int b, size_t o,
-                  int imgs, hipStream_t st) {
+                  int imgs, hipStream_t st, bool feat_amax_done = false) {
   float* A = h2_slots(s, b);
-  DISN_TRY(amax64_accumulate_launch(feat, (size_t)n * feat_ld, A + 448, st, imgs, 1024));
+  if (!feat_amax_done) DISN_TRY(amax64_accumulate_launch(feat, (size_t)n * feat_ld, A + 448, st, imgs, 1024));
   DenseH2Prob p4 = h2_prob(s.h512a + o * 512, 512 + feat_ld, w->l_d4, w->l_b4, 512, 1, A + 320, s.h512b + o * 512,
                            A + 512, n);
   p4.lda = 512; p4.k1 = 512; p4.a2 = feat; p4.lda2 = feat_ld; p4.in_amax2 = A + 448; p4.Kimg = 2048;
+  if (feat_amax_done) { p4.in_amax2 = A + kFeatMaxSlot; p4.in_amax2_n = project_gather_taps_amax_blocks(n, feat_ld); }
   p4 = h2_batched(p4, imgs, n);
   DISN_TRY(dense_h2_launch(&p4, 1, st));
   const DenseH2Prob p5 = h2_batched(h2_prob(s.h512b + o * 512, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5 + o * 256, nullptr, n), imgs, n);
@@ -860,12 +863,16 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     if (rc) return rc;
     // the gather from the taps on the caller's stream, BEFORE the fc head: alone it takes 14 us, under fc6's HBM
     // stream 65-70 us (r02q trace) -- and the local fold2 layers behind it are the critical path of the tail
+    // The kernel also leaves max |feat| per image in the slots the local fold2/conv1 reads its scale from (cleared
+    // by pt_embed on the auxiliary stream, hence the ev[8] wait first -- recorded a whole convolution stack ago).
     gather_on_st = h2 && !featmap;
-    if (gather_on_st) DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, st, feat_ld));
+    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));
+    if (gather_on_st)
+      DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, st, feat_ld,
+                                          h2_slots(e.q.mlp, 0) + kFeatMaxSlot, 1024));
     if (ctx->pipe_record) DISN_TRY(hipEventRecord(ctx->pipe_record, st));  // the next step's convolutions may start
     DISN_TRY(hipEventRecord(ctx->ev[7], st));
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
-    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));  // next to the ev[7] record, where `st` drains anyway
     if (!h2 && (rc = mlp_fold1_local(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws, ctx->aux))) return rc;
   } else {
     rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st);
@@ -887,7 +894,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   if (h2) {
     for (int b = 0; b < B; b += hb) {
       const size_t o = (size_t)b * N;
-      if ((rc = mlp_phase1_h2(mw, N, e.q.feat + o * feat_ld, feat_ld, e.q.mlp, b, o, hb, ms))) return rc;
+      if ((rc = mlp_phase1_h2(mw, N, e.q.feat + o * feat_ld, feat_ld, e.q.mlp, b, o, hb, ms, gather_on_st))) return rc;
     }
   } else if ((rc = mlp_phase1(mw, B * N, e.q.feat, e.q.mlp, ms))) return rc;
   if (two) {
@@ -1297,6 +1304,7 @@ namespace tune {
 int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0;
 int gemm_force[3] = {0, 0, 0};
 int gemv_wgs = 0;
+int dense_mb = 0, dense_nw = 0, dense_kpw = 0;
 long long* ch2_stamps = nullptr;
 }
 }  // namespace disn
@@ -1306,12 +1314,13 @@ extern "C" int disn_tuning_set_ptr(int key, void* p) {
   return 0;
 }
 // tuning builds only (build.py --tuning -> libdisn_amd_tuning.so): 0 x3, 1 overlap, 2 bf_splits, 3 skip_pack,
-// 4 fused_safe
+// 4 fused_safe, 5-7 gemm_force, 8 gemv_wgs, 9 dense_mb, 10 dense_nw, 11 dense_kpw
 extern "C" int disn_tuning_set(int key, int value) {
-  int* k[9] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
-               &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
-               &disn::tune::gemm_force[2], &disn::tune::gemv_wgs};
-  if (key < 0 || key > 8) return DISN_E_ARG;
+  int* k[12] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
+                &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
+                &disn::tune::gemm_force[2], &disn::tune::gemv_wgs, &disn::tune::dense_mb,
+                &disn::tune::dense_nw, &disn::tune::dense_kpw};
+  if (key < 0 || key > 11) return DISN_E_ARG;
   *k[key] = value;
   return 0;
 }

@@ -18,6 +18,7 @@
 // computed before its per-image bias existed (the split global fold2/conv1 of disn_encode_query).
 #include "kernels.hpp"
 #include "h2_common.hpp"
+#include "tuning.hpp"
 
 #include <type_traits>
 
@@ -109,7 +110,10 @@ __global__ __launch_bounds__(256 * NW, 1) void dense_h2_kernel(const DenseH2Dev 
   const float* meta = reinterpret_cast<const float*>(P.wimg + (size_t)Kimg * N * 4);
   const size_t aoff = P.amax_rows > 0 ? (size_t)(m0 / P.amax_rows) * P.amax_stride : 0;  // this tile's image
   float amax_lane = P.in_amax[aoff + lane];
-  if (P.in_amax2) amax_lane = fmaxf(amax_lane, P.in_amax2[aoff + lane]);
+  if (P.in_amax2) {
+    const int n2 = P.in_amax2_n > 0 ? P.in_amax2_n : 64;
+    for (int i = lane; i < n2; i += 64) amax_lane = fmaxf(amax_lane, P.in_amax2[aoff + i]);
+  }
   float bmax_lane = 0.f;
   if (P.in_bias) {
     // the bound max|a| + max|in_bias|: over this tile's image when the maxima are per image (tiles do not straddle
@@ -243,21 +247,40 @@ hipError_t dense_h2_launch(const DenseH2Prob* probs, int nprob, hipStream_t st) 
     if (probs[i].M != probs[0].M || probs[i].N != probs[0].N || probs[i].K != probs[0].K || d.p[i].k1 != d.p[0].k1)
       return hipErrorInvalidValue;
     if (d.p[i].Kimg != 0 && d.p[i].Kimg < d.p[i].K) return hipErrorInvalidValue;
-    if (d.p[i].amax_rows > 0 && d.p[i].amax_rows % 64) return hipErrorInvalidValue;  // a 64-row tile must lie in one image
   }
   d.nprob = nprob;
   const DenseH2Prob& p = d.p[0];
-  const bool big = p.K % 256 == 0 && p.k1 % 256 == 0;  // 256-column chunks (four k16 blocks per wave and chunk)
-  // 64 x 64 tiles when that still gives ~200 workgroups, else 32 x 64
+  // Tile rows BM = 32 MB.  Neither the tile shape nor the chunk width changes a result bit (a k-wave adds its k16
+  // blocks in ascending order and the four partial tiles are summed in one fixed order whatever the tiling):
+  //   64 rows when that gives ~200 workgroups, else 32 (a single image's 2048 rows: latency-bound); 128 rows
+  //   (instantiated, tuning builds) measured no faster than 64 at 8192 rows.
   const long t64 = (long)((p.M + 63) / 64) * (p.N / 64) * nprob;
-  const bool mb2 = t64 >= 192;
-  d.mtiles = mb2 ? (p.M + 63) / 64 : (p.M + 31) / 32;
-  const dim3 grid(d.mtiles * (p.N / 64), nprob);
-  if (big) {
-    if (mb2) hipLaunchKernelGGL((dense_h2_kernel<2, 2, 4>), grid, dim3(512), 0, st, d);
+  int mb = t64 >= 192 ? 2 : 1;
+  if (tune::dense_mb > 0) mb = tune::dense_mb;
+  for (int i = 0; i < nprob; ++i)
+    if (d.p[i].amax_rows > 0 && d.p[i].amax_rows % (32 * mb)) return hipErrorInvalidValue;  // a tile lies in one image
+  d.mtiles = (p.M + 32 * mb - 1) / (32 * mb);
+  // 128 columns (16 waves) when 64 x 128 tiles still give a full round: the batched calls' thousands of rows.  Every
+  // workgroup splits its rows' operand chunk itself, so at 64 columns the split is done N / 64 times per element --
+  // measured at 8192 rows (tools/dense_h2_mb.py): 2048 -> 512: 123 -> 86 us, 512 -> 512: 50 -> 34 us.
+  const long t128 = (long)((p.M + 63) / 64) * (p.N / 128) * nprob;
+  int nw = mb == 2 && p.N % 128 == 0 && t128 >= 256 ? 4 : 2;
+  if (tune::dense_nw > 0) nw = tune::dense_nw == 4 && mb == 2 && p.N % 128 == 0 ? 4 : 2;
+  const dim3 grid(d.mtiles * (p.N / (32 * nw)), nprob);
+  const bool c256 = p.K % 256 == 0 && p.k1 % 256 == 0;  // 256-column chunks (four k16 blocks per wave and chunk)
+  const bool c128 = p.K % 128 == 0 && p.k1 % 128 == 0;
+  if (nw == 4) {
+    if (c256 && tune::dense_kpw == 4) hipLaunchKernelGGL((dense_h2_kernel<2, 4, 4>), grid, dim3(1024), 0, st, d);
+    else if (c128) hipLaunchKernelGGL((dense_h2_kernel<2, 4, 2>), grid, dim3(1024), 0, st, d);
+    else hipLaunchKernelGGL((dense_h2_kernel<2, 4, 1>), grid, dim3(1024), 0, st, d);
+  } else if (mb == 4) {
+    if (c128) hipLaunchKernelGGL((dense_h2_kernel<4, 2, 2>), grid, dim3(512), 0, st, d);
+    else hipLaunchKernelGGL((dense_h2_kernel<4, 2, 1>), grid, dim3(512), 0, st, d);
+  } else if (c256) {
+    if (mb == 2) hipLaunchKernelGGL((dense_h2_kernel<2, 2, 4>), grid, dim3(512), 0, st, d);
     else hipLaunchKernelGGL((dense_h2_kernel<1, 2, 4>), grid, dim3(512), 0, st, d);
   } else {
-    if (mb2) hipLaunchKernelGGL((dense_h2_kernel<2, 2, 1>), grid, dim3(512), 0, st, d);
+    if (mb == 2) hipLaunchKernelGGL((dense_h2_kernel<2, 2, 1>), grid, dim3(512), 0, st, d);
     else hipLaunchKernelGGL((dense_h2_kernel<1, 2, 1>), grid, dim3(512), 0, st, d);
   }
   return hipGetLastError();

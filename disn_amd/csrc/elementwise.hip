@@ -310,17 +310,36 @@ __device__ __forceinline__ float4 tap_pixel(const float* __restrict__ tap, int h
   return o;
 }
 
-__global__ __launch_bounds__(256) void project_gather_taps_kernel(TapSet t,
-                                                                  const float* __restrict__ trans_mat,
-                                                                  const float* __restrict__ pts, int B,
-                                                                  int n, int c4_begin, int c4_count,
-                                                                  float* __restrict__ feat, int feat_ld) {
+__global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
+                                                                   const float* __restrict__ trans_mat,
+                                                                   const float* __restrict__ pts, int B,
+                                                                   int n, int c4_begin, int c4_count,
+                                                                   float* __restrict__ feat, int feat_ld,
+                                                                   float* __restrict__ amax, size_t amax_stride) {
   // B images x n points each (rows image-major); tap k of image b at t.p[k] + b * t.stride[k].  feat_ld > 1472
   // (all five taps only): rows of feat_ld floats, columns 1472 .. feat_ld - 1 written as zeros (c4_count covers
-  // them) -- a zero-padded K for a GEMM that wants 256-column chunks (dense_h2.hip)
-  const size_t total = (size_t)B * n * c4_count;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
+  // them) -- a zero-padded K for a GEMM that wants 256-column chunks (dense_h2.hip).
+  // amax != nullptr: gridDim.x = B * G, workgroup (b, iw) walks image b only and stores the maximum |feat| it wrote
+  // at amax[b * amax_stride + iw] (plain store, every (b, iw) writes): the dense_h2 layer behind takes the maximum
+  // over the G entries as its operand scale -- no extra pass over feat and no atomics (same-line atomics cost ~4 ns
+  // EACH on this part: one per wave made the 14 us kernel a 60 us one).
+  const size_t per_img = (size_t)n * c4_count;
+  size_t i, end, step;
+  int iw = 0, bimg = 0;
+  if (amax) {
+    const int G = gridDim.x / B;
+    bimg = blockIdx.x / G;
+    iw = blockIdx.x - bimg * G;
+    i = (size_t)bimg * per_img + (size_t)iw * blockDim.x + threadIdx.x;
+    end = (size_t)(bimg + 1) * per_img;
+    step = (size_t)G * blockDim.x;
+  } else {
+    i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    end = (size_t)B * per_img;
+    step = (size_t)gridDim.x * blockDim.x;
+  }
+  float vmax = 0.f;
+  for (; i < end; i += step) {
     const size_t pt = i / c4_count;
     const int c = (c4_begin + (int)(i - pt * c4_count)) * 4;
     if (c >= DISN_FEAT) {  // padding columns
@@ -367,12 +386,33 @@ __global__ __launch_bounds__(256) void project_gather_taps_kernel(TapSet t,
 #undef DISN_ACC
     }
     *reinterpret_cast<float4*>(feat + pt * feat_ld + c) = o;
+    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
   }
+  if (amax) {
+    __shared__ float red[16];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+      amax[(size_t)bimg * amax_stride + iw] = m;
+    }
+  }
+}
+
+// workgroups per image of the launch with maxima (1024 threads each) -- the count of entries the consumer reads
+int project_gather_taps_amax_blocks(int n, int feat_ld) {
+  const size_t per_img = (size_t)n * (feat_ld > DISN_FEAT ? feat_ld / 4 : DISN_FEAT4);
+  const size_t g = (per_img + 1023) / 1024;
+  return (int)(g < 1 ? 1 : (g > 448 ? 448 : g));
 }
 
 hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
                                       const float* pts, int B, int n, int tap_begin, int tap_end,
-                                      float* feat, hipStream_t st, int feat_ld) {
+                                      float* feat, hipStream_t st, int feat_ld, float* amax,
+                                      size_t amax_stride) {
   static const int c4_off[6] = {0, 16, 48, 112, 240, DISN_FEAT4};
   static const int ch[5] = {64, 128, 256, 512, 512};
   TapSet t;
@@ -385,8 +425,15 @@ hipError_t project_gather_taps_launch(const float* const taps[5], const float* t
   const int c4_begin = c4_off[tap_begin];
   const int c4_count = (tap_end == 5 && feat_ld > DISN_FEAT ? feat_ld / 4 : c4_off[tap_end]) - c4_begin;
   const size_t total = (size_t)B * n * c4_count;
+  if (amax) {
+    if (tap_begin != 0 || tap_end != 5) return hipErrorInvalidValue;
+    const int G = project_gather_taps_amax_blocks(n, feat_ld);
+    hipLaunchKernelGGL(project_gather_taps_kernel, dim3((unsigned)(B * G)), dim3(1024), 0, st, t, trans_mat, pts, B, n,
+                       c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(project_gather_taps_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
-                     trans_mat, pts, B, n, c4_begin, c4_count, feat, feat_ld);
+                     trans_mat, pts, B, n, c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
   return hipGetLastError();
 }
 

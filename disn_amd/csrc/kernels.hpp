@@ -128,7 +128,10 @@ hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_
 // tap_end) (taps[k] = [B,hw,hw,ch] NHWC) at the touched pixels, writes their channels of [B*n,1472]
 hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
                                       const float* pts, int B, int n, int tap_begin, int tap_end,
-                                      float* feat, hipStream_t st, int feat_ld = 0);  // feat_ld > 1472: zero-padded rows
+                                      float* feat, hipStream_t st, int feat_ld = 0, float* amax = nullptr,
+                                      size_t amax_stride = 0);
+// amax != nullptr (all five taps): max |feat| per workgroup at amax[b * amax_stride + (0 .. blocks - 1)]
+int project_gather_taps_amax_blocks(int n, int feat_ld);  // feat_ld > 1472: zero-padded rows
 // folded local fold2/conv1 (disn_fold_local): h = relu(pre + resample(pmap_b)(pts) + bias), [n,512]
 hipError_t gather_fold_launch(const float* pmap_b, const float* trans_mat_b, const float* pts, int n,
                               const float* pre, const float* bias, float* h, hipStream_t st);
@@ -284,6 +287,7 @@ struct DenseH2Prob {     // out[M][N] = act(f(A) . W + bias), A = [a (k1 columns
   const float* bias;     // [N]
   const float* in_amax;  // 64 slots: max |a|
   const float* in_amax2; // 64 slots: max |a2| (nullptr with one source)
+  int in_amax2_n;        // > 0: in_amax2 has this many entries instead of 64 (per-workgroup maxima of a producer)
   float* out;
   int ldc;
   float* out_amax;       // 64 slots (zeroed by the caller) or nullptr

@@ -14,9 +14,12 @@ extern int skip_pack;   // 1: disn_conv3x3_bf16 reuses the packed image of the p
 extern int fused_safe;  // 1: fused point MLP waits for ALL LDS-DMA at every sync (debugging)
 extern int gemm_force[3];  // {BM, BN, workgroups}: plan of the f32-input GEMM when BM != 0 (tools/sweep_gemm.py)
 extern int gemv_wgs;     // > 0: workgroups of the split-K GEMV (default 2048 = every wave slot of the chip)
+extern int dense_mb;     // > 0: row blocks (of 32) per dense_h2 tile: 1, 2 or 4 (tools/dense_h2_time.py)
+extern int dense_nw;     // 4: 128-column dense_h2 tiles (16 waves) with dense_mb = 2
+extern int dense_kpw;    // 4: 256-column chunks with dense_nw = 4
 extern long long* ch2_stamps;  // conv_h2 kernels write 16 clock stamps per workgroup here (tools/conv_h2_stamps.py)
 #else
-constexpr int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0, gemv_wgs = 0;
+constexpr int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0, gemv_wgs = 0, dense_mb = 0, dense_nw = 0, dense_kpw = 0;
 constexpr int gemm_force[3] = {0, 0, 0};
 #endif
 }  // namespace tune

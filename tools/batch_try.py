@@ -6,6 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from disn_amd.engine import StepPipeline
 from disn_amd.weights import WeightStore
 B = int(sys.argv[1]); S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+if os.environ.get("KNOB"):      # tuning build only: KNOB=name=value[,name=value]
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _tuning
+    for kv in os.environ["KNOB"].split(","):
+        k, v = kv.split("=")
+        _tuning.set_knob(k, int(v))
 if os.environ.get("ORDER") == "bench":      # bisecting bench.py vs this tool: the same preamble as bench.py
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -27,4 +33,4 @@ res = []
 for _ in range(3):
     t0 = time.perf_counter(); pipe.run([(img, pts, tm)] * K); torch.cuda.synchronize()
     res.append((time.perf_counter() - t0) / K * 1e3)
-print("batch %d, %d batches in flight: %s ms per (image + 2048 points)" % (B, S, " ".join("%.4f" % r for r in res)), flush=True)
+print("%s batch %d, %d batches in flight: %s ms per (image + 2048 points)" % (os.environ.get("KNOB", ""), B, S, " ".join("%.4f" % r for r in res)), flush=True)
