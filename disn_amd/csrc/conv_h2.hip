@@ -129,8 +129,10 @@ struct ConvH2Dev {
 // cover.
 // ABL (tools/ubench/conv_h2_ablate.hip only; 0 in the library): 1 no weight loads in the loop, 2 no halo loads,
 // 4 no split + LDS store, 8 no A-fragment reads in the loop (wrong results: timing only)
-template <int MB, int NW, int SEG, int TW, int D, int WK, int ABL = 0>
-__global__ __launch_bounds__(64 * WK * NW, 1) void conv_h2_kernel(const ConvH2Dev P) {
+// OCC: workgroups per CU the register budget is cut for (2: the batched calls' multi-round grids, tuning builds)
+template <int MB, int NW, int SEG, int TW, int D, int WK, int ABL = 0, int OCC = 1>
+__global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) void conv_h2_kernel(const ConvH2Dev P) {
+  // (HIP's second launch-bound is waves per SIMD, not workgroups per CU)
   constexpr int CK = 16 * WK;         // input channels per chunk
   constexpr int KPIX = CK * 4 + 16;   // bytes per halo pixel: h plane, l plane, pad -- an odd multiple of 16
   constexpr int UPP = CK / 4;         // float4 units per pixel
@@ -490,13 +492,13 @@ hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const flo
   return hipGetLastError();
 }
 
-template <int MB, int NW, int SEG, int TW, int D, int WK>
+template <int MB, int NW, int SEG, int TW, int D, int WK, int OCC = 1>
 static hipError_t conv_h2_go(ConvH2Dev d, hipStream_t st) {
   constexpr int TH = MB * (32 / SEG);
   d.tiles_x = (d.W + TW - 1) / TW;
   d.tiles_y = (d.H + TH - 1) / TH;
   const int grid = d.B * d.tiles_x * d.tiles_y * (d.Cout / (32 * NW));
-  hipLaunchKernelGGL((conv_h2_kernel<MB, NW, SEG, TW, D, WK>), dim3(grid), dim3(64 * WK * NW), 0, st, d);
+  hipLaunchKernelGGL((conv_h2_kernel<MB, NW, SEG, TW, D, WK, 0, OCC>), dim3(grid), dim3(64 * WK * NW), 0, st, d);
   return hipGetLastError();
 }
 
@@ -528,6 +530,24 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
   }
   // one n-block per workgroup: eight k-waves (two waves per SIMD) when the channel count allows 128-channel chunks
   const bool wk8 = Cin % 128 == 0;
+  // Launches of more than one round of workgroups (the batched calls; the 224 / 112-pixel layers of a single image):
+  // variants cut for TWO workgroups per CU -- 128 registers (weight queue one pair deep: the other workgroup's waves
+  // hide the L2 latency instead), <= 80 KB LDS (half-height patches at 16 x 16) -- so that one workgroup's prologue,
+  // chunk barriers and epilogue run under the other's MFMAs.  Same k-waves, same summation order: same bits.
+  // Measured (tools/conv_stack_time.py 4, r02v): the 13 layers of four images 697 -> 631 us.
+  if (tune::conv_occ != 1) {
+    const long per_img_tiles = cfg == 1 ? (long)((H + 1) / 2) * ((W + 13) / 14)
+                             : cfg == 3 ? (long)((H + 1) / 2) * ((W + 27) / 28)
+                             : cfg == 4 ? (long)((H + 3) / 4) * ((W + 15) / 16) : 0;
+    const long wgs = B * per_img_tiles * (Cout / (cfg == 1 ? 32 : 64));
+    const int m = tune::conv_occ_mask;   // bit per tiling (tuning builds)
+    // From 1.5 workgroups per CU on where the patch stays the same; where it is halved (more halo per output) from 6
+    // per CU on -- a single image's 224 / 112-pixel layers are slower with it (the 13 layers 276 -> 308 us), two
+    // images' the same, four images' faster.
+    if (cfg == 1 && wk8 && (m & 1) && wgs >= tune::conv_occ_min) return conv_h2_go<1, 1, 16, 14, 3, 8, 2>(d, st);
+    if (cfg == 3 && (m & 2) && wgs >= tune::conv_occ_min) return conv_h2_go<2, 2, 32, 28, 1, 4, 2>(d, st);
+    if (cfg == 4 && (m & 4) && wgs >= 4 * tune::conv_occ_min) return conv_h2_go<2, 2, 16, 16, 1, 4, 2>(d, st);
+  }
   switch (cfg) {
     case 1: return wk8 ? conv_h2_go<1, 1, 16, 14, 9, 8>(d, st) : conv_h2_go<1, 1, 16, 14, 9, 4>(d, st);
     case 2: return wk8 ? conv_h2_go<2, 1, 32, 28, 9, 8>(d, st) : conv_h2_go<2, 1, 32, 28, 9, 4>(d, st);

@@ -17,9 +17,12 @@ extern int gemv_wgs;     // > 0: workgroups of the split-K GEMV (default 2048 = 
 extern int dense_mb;     // > 0: row blocks (of 32) per dense_h2 tile: 1, 2 or 4 (tools/dense_h2_time.py)
 extern int dense_nw;     // 4: 128-column dense_h2 tiles (16 waves) with dense_mb = 2
 extern int dense_kpw;    // 4: 256-column chunks with dense_nw = 4
+extern int conv_occ;     // 1: never the two-workgroups-per-CU conv_h2 variants (tools/conv_stack_time.py)
+extern int conv_occ_mask;  // which tilings get them (bit 0: <1,1,16,14>, bit 1: <2,2,32,28>, bit 2: <4,2,16,16> -> <2,2,16,16>)
+extern int conv_occ_min; // from this many workgroups per launch on
 extern long long* ch2_stamps;  // conv_h2 kernels write 16 clock stamps per workgroup here (tools/conv_h2_stamps.py)
 #else
-constexpr int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0, gemv_wgs = 0, dense_mb = 0, dense_nw = 0, dense_kpw = 0;
+constexpr int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0, gemv_wgs = 0, dense_mb = 0, dense_nw = 0, dense_kpw = 0, conv_occ = 0, conv_occ_mask = 7, conv_occ_min = 384;
 constexpr int gemm_force[3] = {0, 0, 0};
 #endif
 }  // namespace tune
