@@ -9,7 +9,8 @@ float64 and accumulated in float64 (the MFMA accumulates in fp32: its rounding i
 """
 import numpy as np
 
-TILINGS = {1: (1, 1, 16, 14), 2: (2, 1, 32, 28), 3: (2, 2, 32, 28), 4: (4, 2, 16, 16)}   # MB, NW, SEG, TW
+TILINGS = {1: (1, 1, 16, 14), 2: (2, 1, 32, 28), 3: (2, 2, 32, 28), 4: (4, 2, 16, 16),   # MB, NW, SEG, TW
+           5: (2, 2, 16, 16)}   # the half-height patch of the two-workgroups-per-CU variant (multi-round launches)
 
 
 def k_waves(tiling, cin):

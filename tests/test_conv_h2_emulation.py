@@ -28,7 +28,8 @@ def case(H, W, cin, cout, seed=0):
     return x, w, b
 
 
-@pytest.mark.parametrize("tiling,H,W", [(1, 4, 14), (1, 6, 10), (2, 4, 28), (3, 2, 30), (4, 8, 16), (4, 10, 20)])
+@pytest.mark.parametrize("tiling,H,W", [(1, 4, 14), (1, 6, 10), (2, 4, 28), (3, 2, 30), (4, 8, 16), (4, 10, 20), (5, 4, 16),
+                                        (5, 6, 20)])
 def test_every_tiling_reproduces_the_convolution(tiling, H, W):
     x, w, b = case(H, W, 64, 64, seed=tiling)
     out, pooled, vmax = E.conv(x, w, b, tiling)
@@ -60,7 +61,7 @@ def test_exact_operands_give_the_exact_convolution():
     assert np.abs(out - ref).max() <= 2e-7 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("tiling,wk", [(1, 4), (2, 4), (3, 4), (4, 4), (1, 8), (2, 8)])
+@pytest.mark.parametrize("tiling,wk", [(1, 4), (2, 4), (3, 4), (4, 4), (1, 8), (2, 8), (5, 4)])
 def test_a_fragment_reads_are_bank_conflict_free(tiling, wk):
     assert E.lds_read_conflicts(tiling, wk) == 0
 

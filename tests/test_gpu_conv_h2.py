@@ -101,6 +101,20 @@ def test_tilings_agree_bit_for_bit_and_runs_repeat(ops):
         assert np.array_equal(o[0], v)
 
 
+@pytest.mark.parametrize("hw,cin,cout", [(224, 64, 64), (112, 128, 128), (56, 256, 256), (14, 512, 512)])
+def test_multi_round_variants_give_the_single_image_bits(ops, hw, cin, cout):
+    """A launch of several rounds of workgroups (here: four copies of one image) goes through the
+    two-workgroups-per-CU variants (smaller register budget, one-pair weight queue, 16 x 16 layers on half-height
+    patches); k-waves and summation order are the single-image tiling's, so are the bits -- and the pooled copy's."""
+    x, w, b = case(1, hw, hw, cin, cout, 77 + hw)
+    img = ops.pack_conv_h2(dev(w))
+    one, pool1, _ = ops.conv3x3_h2(dev(x), img, dev(b), cout, True, pool=True, want_amax=True)
+    four, pool4, amax4 = ops.conv3x3_h2(dev(np.repeat(x, 4, axis=0)), img, dev(b), cout, True, pool=True, want_amax=True)
+    for k in range(4):
+        assert torch.equal(four[k], one[0]) and torch.equal(pool4[k], pool1[0]), k
+    assert float(amax4) == float(one.abs().max())
+
+
 def test_zero_input_and_tiny_activations(ops):
     x, w, b = case(1, 14, 14, 64, 64, 9)
     img = ops.pack_conv_h2(dev(w))
