@@ -719,7 +719,20 @@ int disn_ctx_create(disn_ctx_t** out) {
   if (!out) return DISN_E_ARG;
   disn_ctx* c = new (std::nothrow) disn_ctx();
   if (!c) return DISN_E_ARG;
-  hipError_t e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+  hipError_t e;
+#ifdef DISN_TUNING
+  if (tune::aux_cu_mode > 0) {  // experiment: the auxiliary stream on a subset of the 256 CUs
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 256; ++i) {
+      const int m = tune::aux_cu_mode;
+      const bool on = m == 1 ? i < 192 : m == 2 ? (i & 3) != 3 : m == 3 ? i < 128 : m == 4 ? (i & 1) == 0
+                    : m == 5 ? i >= 64 : (i & 7) < 6;
+      if (on) mask[i >> 5] |= 1u << (i & 31);
+    }
+    e = hipExtStreamCreateWithCUMask(&c->aux, 8, mask);
+  } else
+#endif
+  e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
   if (e == hipSuccess) e = bind_queue(c->aux);
   for (int i = 0; i < 10 && e == hipSuccess; ++i)
     e = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
@@ -1306,6 +1319,7 @@ int gemm_force[3] = {0, 0, 0};
 int gemv_wgs = 0;
 int dense_mb = 0, dense_nw = 0, dense_kpw = 0;
 int conv_occ = 0, conv_occ_mask = 7, conv_occ_min = 384;
+int aux_cu_mode = 0;
 long long* ch2_stamps = nullptr;
 }
 }  // namespace disn
@@ -1315,14 +1329,14 @@ extern "C" int disn_tuning_set_ptr(int key, void* p) {
   return 0;
 }
 // tuning builds only (build.py --tuning -> libdisn_amd_tuning.so): 0 x3, 1 overlap, 2 bf_splits, 3 skip_pack,
-// 4 fused_safe, 5-7 gemm_force, 8 gemv_wgs, 9 dense_mb, 10 dense_nw, 11 dense_kpw, 12 conv_occ, 13 conv_occ_mask, 14 conv_occ_min
+// 4 fused_safe, 5-7 gemm_force, 8 gemv_wgs, 9 dense_mb, 10 dense_nw, 11 dense_kpw, 12 conv_occ, 13 conv_occ_mask, 14 conv_occ_min, 15 aux_cu_mode
 extern "C" int disn_tuning_set(int key, int value) {
-  int* k[15] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
+  int* k[16] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
                 &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
                 &disn::tune::gemm_force[2], &disn::tune::gemv_wgs, &disn::tune::dense_mb,
                 &disn::tune::dense_nw, &disn::tune::dense_kpw, &disn::tune::conv_occ, &disn::tune::conv_occ_mask,
-                &disn::tune::conv_occ_min};
-  if (key < 0 || key > 14) return DISN_E_ARG;
+                &disn::tune::conv_occ_min, &disn::tune::aux_cu_mode};
+  if (key < 0 || key > 15) return DISN_E_ARG;
   *k[key] = value;
   return 0;
 }
