@@ -270,7 +270,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2,
                     help="--workload query: independent submissions in flight on this GPU (disn_amd.engine.StepPipeline: "
                          "one HIP stream + host thread per context); 1 = one at a time")
-    ap.add_argument("--batch", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=8,
                     help="--workload query: consecutive independent steps (image + 2048 points each) submitted as ONE "
                          "disn_encode_query call (StepPipeline(batch=)); every image keeps its own activation scales, "
                          "so its result is bit for bit the single-step one; 1 = one step per call")
