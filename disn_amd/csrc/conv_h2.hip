@@ -113,6 +113,7 @@ struct ConvH2Dev {
   int tiles_x, tiles_y;
   int relu;
   int amax_stride;            // floats between the slot groups of consecutive images (0: one group for the whole batch)
+  int img_major;              // tile order [image][n-tile][patch] instead of [n-tile][image][patch] (see the launcher)
   long long* stamps;  // tuning builds: 16 clock stamps per workgroup (nullptr in the product)
 };
 
@@ -163,11 +164,20 @@ __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) voi
     l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int per_img = P.tiles_y * P.tiles_x;
-  const int mtiles = P.B * per_img;
-  const int nt = l / mtiles;
-  int mt = l - nt * mtiles;
-  const int b = mt / per_img;
-  mt -= b * per_img;
+  int nt, b, mt;
+  if (P.img_major) {   // an XCD's eighth = whole images (or a share of one): its L2 keeps the image's input
+    const int per_b = (P.Cout / (32 * NW)) * per_img;
+    b = l / per_b;
+    mt = l - b * per_b;
+    nt = mt / per_img;
+    mt -= nt * per_img;
+  } else {             // an XCD's eighth = whole n-tiles: its L2 keeps their weights
+    const int mtiles = P.B * per_img;
+    nt = l / mtiles;
+    mt = l - nt * mtiles;
+    b = mt / per_img;
+    mt -= b * per_img;
+  }
   const int tyi = mt / P.tiles_x, txi = mt - tyi * P.tiles_x;
   const int y0 = tyi * TH, x0 = txi * TW;
   const int n0 = (nt * NW + wn) * 32;
@@ -518,6 +528,13 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
 #ifdef DISN_TUNING
   d.stamps = tune::ch2_stamps;
 #endif
+  // Which operand an XCD's L2 keeps: with the n-tile-major order every XCD streams the whole input of the launch
+  // (8 x B H W Cin floats over the fabric) and reads its own eighth of the weights once; image-major it is the other
+  // way round.  Measured on the 13 layers of 2 / 4 / 8 images (tools/conv_stack_time.py, knob conv_img_major):
+  // image-major where B H W > 9 Cout 388 / 645-658 / 1059-1078 us against 385 / 627 / 1089 n-tile-major, everywhere
+  // 399 / 665 / 1112 -- no gain: the launches are not bound by fabric traffic.  n-tile-major stays.
+  d.img_major = 0;
+  if (tune::conv_img_major >= 0) d.img_major = tune::conv_img_major;
   if (cfg == 0) {
     // patch shape by image width; n-blocks per workgroup so that one image still gives >= ~200 workgroups
     if (W <= 14) cfg = 1;
