@@ -119,8 +119,10 @@ hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, co
   const bool two = N >= 4096;
   const int waves = two ? (N + 1) / 2 : N;
   const dim3 grid((waves + 3) / 4);
-  for (int b0 = 0; b0 < B; b0 += 4) {
-    const int nb = (B - b0) < 4 ? (B - b0) : 4;
+  // up to eight batch rows per launch: the matrix is read once per launch, and a batch row's sum is the same
+  // instruction sequence whatever NB (an eight-step call must not read fc7's 67 MB twice)
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    const int nb = (B - b0) < 8 ? (B - b0) : 8;
     switch (nb) {
 #define DISN_GR_CASE(NB)                                                                                          \
   case NB:                                                                                                        \
@@ -128,6 +130,7 @@ hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, co
     else hipLaunchKernelGGL((gemv_rows_kernel<NB, 1, 8>), grid, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, b0);    \
     break;
       DISN_GR_CASE(1) DISN_GR_CASE(2) DISN_GR_CASE(3) DISN_GR_CASE(4)
+      DISN_GR_CASE(5) DISN_GR_CASE(6) DISN_GR_CASE(7) DISN_GR_CASE(8)
 #undef DISN_GR_CASE
     }
     const hipError_t e = hipGetLastError();
