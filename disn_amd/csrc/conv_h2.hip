@@ -562,6 +562,10 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
     // per CU on -- a single image's 224 / 112-pixel layers are slower with it (the 13 layers 276 -> 308 us), two
     // images' the same, four images' faster.
     if (cfg == 1 && wk8 && (m & 1) && wgs >= tune::conv_occ_min) return conv_h2_go<1, 1, 16, 14, 3, 8, 2>(d, st);
+    // 28-pixel layers with eight k-waves (conv4): their own tiling needs 131 KB of LDS; the 2 x 14 patch of conv5
+    // has the same halo overhead (2.3x against 2.1x) and fits twice
+    if (cfg == 2 && wk8 && (m & 8) && B * (long)((H + 1) / 2) * ((W + 13) / 14) * (Cout / 32) >= 4 * tune::conv_occ_min)
+      return conv_h2_go<1, 1, 16, 14, 3, 8, 2>(d, st);
     if (cfg == 3 && (m & 2) && wgs >= tune::conv_occ_min) return conv_h2_go<2, 2, 32, 28, 1, 4, 2>(d, st);
     if (cfg == 4 && (m & 4) && wgs >= 4 * tune::conv_occ_min) return conv_h2_go<2, 2, 16, 16, 1, 4, 2>(d, st);
   }
