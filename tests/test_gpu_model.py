@@ -449,15 +449,18 @@ def test_chained_pipeline_equals_single_stream_steps():
         assert torch.equal(got[k], ref) and torch.equal(got2[k], ref), "job %d differs" % k
 
 
-def test_batched_pipeline_equals_single_image_steps():
-    """StepPipeline(batch=3): three independent (image, point set) steps per disn_encode_query call -- every image
-    keeps its own activation scales (conv stack and point MLPs), so each result is bit for bit the single-image one"""
+@pytest.mark.parametrize("batch,npts,njobs", [(3, 1024, 8), (8, 2048, 10), (2, 1000, 3)])
+def test_batched_pipeline_equals_single_image_steps(batch, npts, njobs):
+    """StepPipeline(batch=B): B independent (image, point set) steps per disn_encode_query call -- every image keeps
+    its own activation scales (conv stack and point MLPs), so each result is bit for bit the single-image one.
+    (8, 2048) is bench.py's configuration (multi-round convolution variants, 128-column dense tiles, eight-row fc
+    launches); 1000 points per image are not a multiple of 64: the point-MLP layers then run image by image."""
     from disn_amd.engine import SdfEngine, StepPipeline
     from disn_amd.weights import WeightStore
-    pipe = StepPipeline(WeightStore.random_init(6, mode="he"), in_flight=2, batch=3)
+    pipe = StepPipeline(WeightStore.random_init(6, mode="he"), in_flight=2, batch=batch)
     jobs = []
-    for k in range(8):                                   # 3 + 3 + 2: a ragged last batch
-        d = O.synth_inputs(60 + k, 1, 1024)
+    for k in range(njobs):                               # a ragged last batch
+        d = O.synth_inputs(60 + k, 1, npts)
         d["imgs"] *= np.float32(0.25 + 0.25 * k)          # different brightness: different activation maxima
         jobs.append((torch.from_numpy(d["imgs"]).cuda(), torch.from_numpy(d["sample_pc"]).cuda(),
                      torch.from_numpy(d["trans_mat"]).cuda()))
