@@ -336,7 +336,11 @@ int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, 
  * B*N <= 65536.  Outputs as disn_encode plus sdf [B,N].  featmap may be NULL: the
  * [B,137,137,1472] map is an intermediate of the graph, not something sess.run returns, and
  * with NULL it is never materialised -- the gather bilinearly up-samples the taps on the fly
- * (same expression, bit-identical sdf; the right trade for N up to ~10^4 per image). */
+ * (same expression, bit-identical sdf; the right trade for N up to ~10^4 per image).
+ * B > 1 = B independent requests (image b, its N points, its camera) in one call -- the throughput form
+ * (disn_amd.engine.StepPipeline(batch=B), bench.py --batch): the fc weights are read once per call and every launch
+ * carries B images.  On the fast small-point-set path (B <= 16, N < 8192, conv_w_h2 / *_d* images present) every
+ * activation scale is per image, so request b's outputs are bit for bit those of the same request in a B = 1 call. */
 size_t disn_encode_query_workspace_bytes(int B, int N);
 int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw,
                       const disn_mlp_weights_t* mw, const float* img, const float* trans_mat,
