@@ -33,6 +33,7 @@ SOURCES = {
     "mlp_small.hip": [],
     "mlp_fused.hip": [],
     "conv_h2.hip": [],
+    "conv_h2w.hip": [],
     "dense_h2.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],
     "marching_cubes.hip": ["-ffp-contract=off"],

@@ -101,21 +101,7 @@ hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, f
 #endif  // CH2_UBENCH
 
 // ---------------------------------------------------------------------------------------------------
-struct ConvH2Dev {
-  const float* in;            // [B][H][W][Cin]
-  const unsigned char* wimg;  // conv_h2_pack image
-  const float* bias;          // [Cout]
-  const float* in_amax;       // 64 floats whose maximum is max |in|
-  float* out;                 // [B][H][W][Cout]
-  float* pool_out;            // [B][H/2][W/2][Cout] or nullptr
-  float* out_amax;            // 64 floats (zeroed by the caller): atomic max |out| spread over the slots, or nullptr
-  int B, H, W, Cin, Cout;
-  int tiles_x, tiles_y;
-  int relu;
-  int amax_stride;            // floats between the slot groups of consecutive images (0: one group for the whole batch)
-  int img_major;              // tile order [image][n-tile][patch] instead of [n-tile][image][patch] (see the launcher)
-  long long* stamps;  // tuning builds: 16 clock stamps per workgroup (nullptr in the product)
-};
+// struct ConvH2Dev: h2_common.hpp (shared with conv_h2w.hip)
 
 #ifdef DISN_TUNING
 #define CH2_STAMP(i) \
@@ -517,7 +503,8 @@ bool conv_h2_supported(int H, int W, int Cin, int Cout) {
          (size_t)H * W * (Cin > Cout ? Cin : Cout) < (size_t)1 << 31;
 }
 
-// cfg: 0 = by shape; 1..4 force <1,1,16,14>, <2,1,32,28>, <2,2,32,28>, <4,2,16,16> (tests: every shape through every tiling)
+// cfg: 0 = by shape and batch; 1..4 force <1,1,16,14>, <2,1,32,28>, <2,2,32,28>, <4,2,16,16> (tests: every shape through
+// every tiling); 5..9 force variants 1..5 of the batched form (conv_h2w.hip)
 hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const void* wimg, const float* bias,
                           int Cout, int relu, const float* in_amax, float* out, float* pool_out, float* out_amax,
                           hipStream_t st, int cfg, int amax_stride) {
@@ -535,6 +522,12 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
   // 399 / 665 / 1112 -- no gain: the launches are not bound by fabric traffic.  n-tile-major stays.
   d.img_major = 0;
   if (tune::conv_img_major >= 0) d.img_major = tune::conv_img_major;
+  // Calls of several images (the steps of a batched call): the batched form of conv_h2w.hip -- waves own n-blocks
+  // and walk K sequentially, 12 .. 21 MFMAs per weight pair.  Its summation order differs from the k-wave tree
+  // below (fp32 rounding; both inside the 1e-5 bar): an image's bits depend on WHICH FORM runs it (fewer than
+  // kConvWideMinImages images per call or not), never on the other images of its call.  tiling 5..9: forced variants.
+  if (cfg >= 5) return conv_h2w_supported(H, W, Cin, Cout) ? conv_h2w_launch(d, st, cfg - 4) : hipErrorInvalidValue;
+  if (cfg == 0 && B >= tune::conv_wide_min && conv_h2w_supported(H, W, Cin, Cout)) return conv_h2w_launch(d, st, 0);
   if (cfg == 0) {
     // patch shape by image width; n-blocks per workgroup so that one image still gives >= ~200 workgroups
     if (W <= 14) cfg = 1;
@@ -599,27 +592,28 @@ int disn_pack_conv_h2(const float* w_hwio, int Cin, int Cout, void* image, void*
   return e == hipSuccess ? 0 : (int)e;
 }
 
-size_t disn_conv3x3_h2_workspace_bytes(void) { return 512; }
+size_t disn_conv3x3_h2_workspace_bytes(int B) { return B > 0 ? (size_t)B * 512 : 0; }
 
 int disn_conv3x3_h2(const float* in, int B, int H, int W, int Cin, const void* image, const float* bias, int Cout,
                     int relu, float* out, float* pool_out, float* out_amax, int tiling, void* ws, size_t ws_bytes,
                     void* stream) {
   if (!in || !image || !bias || !out || !ws || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
-  if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 4 || (pool_out && ((H | W) & 1)))
+  if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 9 || (pool_out && ((H | W) & 1)))
     return DISN_E_SHAPE;
-  if (ws_bytes < 512) return DISN_E_WS;
+  if (tiling >= 5 && !disn::conv_h2w_supported(H, W, Cin, Cout)) return DISN_E_SHAPE;
+  if (ws_bytes < (size_t)B * 512) return DISN_E_WS;
   hipStream_t st = (hipStream_t)stream;
-  float* amax_in = static_cast<float*>(ws);  // 64 slots in, 64 slots out
-  float* amax_out = amax_in + 64;
-  hipError_t e = disn::amax64_launch(in, (size_t)B * H * W * Cin, amax_in, st);
+  // every image its own 64 slots in / 64 slots out, as inside disn_encode*: an image's scale, hence its bits, do
+  // not depend on the other images of the call
+  float* amax_in = static_cast<float*>(ws);
+  float* amax_out = amax_in + (size_t)B * 64;
+  hipError_t e = hipMemsetAsync(amax_in, 0, (size_t)B * 512, st);
   if (e != hipSuccess) return (int)e;
-  if (out_amax) {
-    e = hipMemsetAsync(amax_out, 0, 64 * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-  }
+  e = disn::amax64_accumulate_launch(in, (size_t)H * W * Cin, amax_in, st, B, 64);
+  if (e != hipSuccess) return (int)e;
   e = disn::conv_h2_launch(in, B, H, W, Cin, image, bias, Cout, relu, amax_in, out, pool_out,
-                           out_amax ? amax_out : nullptr, st, tiling);
-  if (e == hipSuccess && out_amax) e = disn::amax_fold_launch(amax_out, out_amax, st);
+                           out_amax ? amax_out : nullptr, st, tiling, 64);
+  if (e == hipSuccess && out_amax) e = disn::amax_fold_launch(amax_out, out_amax, st, B * 64);
   return e == hipSuccess ? 0 : (int)e;
 }
 

@@ -1,0 +1,373 @@
+// 3x3 SAME convolution of the VGG-16 stack (models/CNN/vgg.py:187-196, 'conv1_2' .. 'conv4_3'; called from
+// models/model_normalization.py:74-76) for a BATCH of images (the calls of several steps at once): the throughput
+// sibling of conv_h2.hip.  Same arithmetic (two-term f16 split of both operands, l_a h_b + h_a l_b + h_a h_b on
+// v_mfma_f32_32x32x16_f16, fp32 accumulate), same weight image (conv_h2_pack_kernel), same activation-maximum
+// slots; what changes is who owns what:
+//
+//  * conv_h2.hip is cut for ONE image: all K parallelism inside the workgroup (4 / 8 k-waves per n-block), tiles
+//    of 32 .. 128 pixels, so that 196 .. 50176 pixels still give a few hundred workgroups.  Per weight fragment
+//    pair (2 KiB from L2) a wave issues 3 .. 12 MFMAs: with thousands of workgroups (a batch) the weight stream
+//    per MFMA, not the matrix pipe, sets the pace (r02w: 0.26 of the f16 peak, 4.2x the algorithmic reads).
+//  * Here a wave owns ONE 32-channel n-block for MB = 4 .. 7 row blocks (128 .. 224 pixels) and walks K
+//    sequentially (optionally two k-waves where a layer's M x N is too small for 1024 SIMDs): 12 .. 21 MFMAs per
+//    weight pair, the pair queue three taps deep, and a workgroup's NWV n-waves share one halo patch in LDS.
+//    The patch is 8 rows x 28 (or 32) pixels = exactly 7 (8) blocks of 32: no padded MFMA rows where the image
+//    size is a multiple of the patch (224, 112, 56: all of conv1_2 .. conv3_3; 28-pixel images waste the patch rows
+//    28 .. 31).
+//  * Row <-> pixel map: logical rows 4w .. 4w + 3 of the tile are the 2x2 WINDOW w (windows row-major over the
+//    patch).  The C layout of the MFMA hands a lane four consecutive logical rows per register quad
+//    (h2_common.hpp), i.e. one window: the fused 2x2 max pool is a maximum of four registers, no cross-lane
+//    traffic, whatever the patch width.
+//  * LDS: a halo pixel is CK f16 of h, CK of l, 16 B pad (80 B at CK = 16, 144 B at CK = 32: odd multiples of
+//    16), and a halo ROW is padded to 128 (mod 256) bytes: the 16 lanes of a ds_read_b128 group read 2 rows x 8
+//    consecutive pixels (four windows) and land on 16 different 16-byte slots (tests/conv_h2w_emulation.py
+//    counts the conflicts of every configuration).  Tap shifts are immediate offsets of the read.
+//
+// Summation order of one output element: k16 blocks in ascending channel order within a k-wave, taps 0..8 inside a
+// block, then (two k-waves) p0 + p1.  It depends on WK only -- fixed per LAYER by the launcher -- never on the patch,
+// the number of n-waves or the batch: an image's bits do not depend on the images it travels with.  They DO differ
+// (fp32 rounding, both within the 1e-5 bar of the float64 oracle) from conv_h2.hip's four / eight-k-wave tree, which
+// serves calls of fewer than four images: see conv_h2_launch.
+#include "kernels.hpp"
+#include "tuning.hpp"
+#include "h2_common.hpp"
+
+#include <type_traits>
+
+namespace disn {
+
+namespace {
+constexpr int w_row_bytes(int raw) {  // smallest size >= raw that is 128 (mod 256)
+  int r = (raw / 256) * 256 + 128;
+  return r >= raw ? r : r + 256;
+}
+}  // namespace
+
+#ifdef DISN_TUNING
+#define CH2W_STAMP(i) \
+  if (P.stamps && threadIdx.x == 0) P.stamps[(size_t)blockIdx.x * 16 + (i)] = (i) == 0 ? (long long)wall_clock64() : (long long)clock64()
+#else
+#define CH2W_STAMP(i)
+#endif
+
+// MB row blocks per wave, MWV m-waves x NWV n-waves x WK k-waves per workgroup, patch TH x TW (= 32 MB MWV pixels),
+// OCC workgroups per CU the register budget is cut for
+template <int MB, int MWV, int NWV, int WK, int TH, int TW, int OCC>
+__global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4) void conv_h2w_kernel(const ConvH2Dev P) {
+  constexpr int NWAVES = MWV * NWV * WK, NT = 64 * NWAVES;
+  constexpr int CK = 16 * WK;              // input channels per chunk: one k16 block per k-wave
+  constexpr int KPIX = CK * 4 + 16;        // bytes per halo pixel
+  constexpr int UPP = CK / 4;              // float4 units per pixel
+  constexpr int RP = TW + 2, HR = TH + 2;  // halo pixels per row, halo rows
+  constexpr int ROWB = w_row_bytes(RP * KPIX);
+  constexpr int BUF = HR * ROWB;
+  constexpr int UNITS = HR * RP * UPP;
+  constexpr int LP = (UNITS + NT - 1) / NT;
+  constexpr int WPR = TW / 2;              // windows per patch row pair
+  constexpr int D = 3;                     // weight pairs in flight per wave (taps ahead)
+  constexpr int XCH = WK == 2 ? MWV * NWV * MB * 4096 : 0;
+  constexpr int LDS_BYTES = 2 * BUF > XCH ? 2 * BUF : XCH;
+  static_assert(TH * TW == 32 * MB * MWV && TH % 2 == 0 && TW % 2 == 0, "patch = whole row blocks of 2x2 windows");
+  static_assert(WK == 1 || WK == 2, "k-waves");
+  static_assert(LDS_BYTES * OCC <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave % WK, wn = (wave / WK) % NWV, wm = wave / (WK * NWV);
+  const int j = lane & 31, g = lane >> 5;
+  CH2W_STAMP(0);
+  CH2W_STAMP(1);
+
+  // ---- tile: n-tile major, every XCD (hardware workgroup L runs on XCD L % 8) a contiguous eighth --------------
+  int l;
+  {
+    const int T = gridDim.x, L = blockIdx.x, q = T >> 3, r = T & 7, xcd = L & 7, idx = L >> 3;
+    l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int per_img = P.tiles_y * P.tiles_x;
+  const int mtiles = P.B * per_img;
+  const int nt = l / mtiles;
+  int mt = l - nt * mtiles;
+  const int b = mt / per_img;
+  mt -= b * per_img;
+  const int tyi = mt / P.tiles_x, txi = mt - tyi * P.tiles_x;
+  const int y0 = tyi * TH, x0 = txi * TW;
+  const int n0 = (nt * NWV + wn) * 32;
+  const int H = P.H, W = P.W, Cin = P.Cin, Cout = P.Cout;
+  const int NC = Cin / CK;
+  const float* inb = P.in + (size_t)b * H * W * Cin;
+
+  // ---- halo loader: unit u = (halo pixel, float4 of the chunk's CK channels).  Every load is unconditional and
+  // every loaded value is used (an out-of-image unit reads a valid address and is ANDed with 0): no exec-mask
+  // branches around loads, so the compiler can count the loads in flight (s_waitcnt vmcnt(N)) ----------------------
+  int goff[LP], woff[LP];
+  unsigned vbits = 0;
+#pragma unroll
+  for (int k = 0; k < LP; ++k) {
+    // (threads beyond the last unit repeat it: same address, same value -- no branch around a load or a store)
+    const int u = tid + k * NT < UNITS ? tid + k * NT : UNITS - 1;
+    const int hp = u / UPP, c4 = u % UPP;
+    const int hy = hp / RP, hx = hp - hy * RP;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+    goff[k] = ok ? (y * W + x) * Cin + 4 * c4 : 4 * c4;
+    vbits |= ok ? (1u << k) : 0u;
+    woff[k] = hy * ROWB + hx * KPIX + 8 * c4;
+  }
+  auto load_chunk = [&](int c, float4 (&ra)[LP]) {
+#pragma unroll
+    for (int k = 0; k < LP; ++k) ra[k] = *reinterpret_cast<const float4*>(inb + goff[k] + CK * c);
+  };
+  float sa = 1.0f;
+  auto store_unit = [&](int buf, const float4 (&ra)[LP], int k) {
+    const unsigned msk = 0u - ((vbits >> k) & 1u);
+    const float x[4] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w};
+    ch_h4 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = __uint_as_float(__float_as_uint(x[e]) & msk) * sa;
+      const _Float16 h = (_Float16)v;
+      hh[e] = h;
+      ll[e] = (_Float16)(v - (float)h);
+    }
+    *reinterpret_cast<ch_h4*>(&lds[buf * BUF + woff[k]]) = hh;
+    *reinterpret_cast<ch_h4*>(&lds[buf * BUF + woff[k] + CK * 2]) = ll;
+  };
+
+  // the first halo is requested before anything else (loads return in order: nothing may queue in front of it)
+  float4 ra0[LP];
+  load_chunk(0, ra0);
+
+  const float* meta = reinterpret_cast<const float*>(P.wimg + (size_t)Cin * 9 * Cout * 4);
+  float amax_lane = P.in_amax[(size_t)b * P.amax_stride + lane];
+  const float inv_sw = meta[1];
+
+  // ---- A rows of this lane: hardware row i of block bg is logical row sigma(i) -> tile row 32 bg + sigma(i) ->
+  // window (row-major over the patch) and position in it -> top-left tap of that pixel in the halo -----------------
+  int arow[MB];
+  {
+    const int Lr = ch2::sigma(lane & 31);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int m = 32 * (wm * MB + mb) + Lr;
+      const int w = m >> 2, e = m & 3;
+      const int wy = w / WPR, wx = w - wy * WPR;
+      arow[mb] = (2 * wy + (e >> 1)) * ROWB + (2 * wx + (e & 1)) * KPIX + (16 * wk + 8 * g) * 2;
+    }
+  }
+
+  // ---- this wave's weight stream: k16 block WK c + wk in chunk c, nine contiguous 2-KiB pairs per chunk ---------
+  const unsigned char* wp = P.wimg + ((size_t)((n0 >> 5) * (Cin >> 4) + wk) * 9) * 2048 + lane * 16;
+  constexpr size_t kChunkStride = (size_t)WK * 9 * 2048;
+  ch_h8 qh[D], ql[D];
+#pragma unroll
+  for (int t = 0; t < D; ++t) {
+    qh[t] = *reinterpret_cast<const ch_h8*>(wp + (size_t)t * 2048);
+    ql[t] = *reinterpret_cast<const ch_h8*>(wp + (size_t)t * 2048 + 1024);
+  }
+
+  ch_f16v acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) amax_lane = fmaxf(amax_lane, __shfl_xor(amax_lane, off));
+  sa = ch2::pow2_scale(amax_lane, 14);
+  const float descale = (1.0f / sa) * inv_sw;
+
+  CH2W_STAMP(2);
+#pragma unroll
+  for (int k = 0; k < LP; ++k) store_unit(0, ra0, k);
+  __syncthreads();
+  CH2W_STAMP(3);
+
+  // ---- one chunk: 9 taps x MB blocks = 9 MB sub-steps of three MFMAs from LDS buffer c & 1.  The A pair of
+  // sub-step s + 2 is read while the MFMAs of s run (three rolling register pairs); each tap requests the weight
+  // pair D taps ahead into the queue slot it just freed; MORE: the next chunk's halo is requested at the top and
+  // split into the other buffer one unit at a time between the MFMAs of taps T0..8 ------------------------------
+  constexpr int S = 9 * MB;
+  constexpr int T0 = 4;
+  constexpr int SLOTS = (9 - T0) * MB;   // sub-steps that may carry a unit of the next halo
+  auto chunk = [&](int c, auto more_c) {
+    constexpr bool MORE = decltype(more_c)::value;
+    float4 ra[LP];
+    if (MORE) load_chunk(c + 1, ra);
+    int ab[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) ab[mb] = arow[mb] + (c & 1) * BUF;
+    const unsigned char* wcur = wp + (size_t)c * kChunkStride;
+    ch_h8 ah[3], al[3], bh, bl;
+    auto rd = [&](int s) {
+      const int t = s / MB, mb = s % MB;
+      const int off = (t / 3) * ROWB + (t % 3) * KPIX;
+      ah[s % 3] = *reinterpret_cast<const ch_h8*>(&lds[ab[mb] + off]);
+      al[s % 3] = *reinterpret_cast<const ch_h8*>(&lds[ab[mb] + off + CK * 2]);
+    };
+    rd(0);
+    rd(1);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int t = s / MB, mb = s % MB;
+      if (mb == 0) {
+        bh = qh[t % D];
+        bl = ql[t % D];
+        if (MORE || t + D < 9) {  // the pair D taps ahead: this chunk's or the next one's
+          const unsigned char* wa = wcur + ((t + D) / 9) * kChunkStride + (size_t)((t + D) % 9) * 2048;
+          qh[t % D] = *reinterpret_cast<const ch_h8*>(wa);
+          ql[t % D] = *reinterpret_cast<const ch_h8*>(wa + 1024);
+        }
+      }
+      if (s + 2 < S) rd(s + 2);
+      __builtin_amdgcn_sched_barrier(0);  // the loads above are ISSUED here, not sunk next to their uses
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % 3], bh, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 3], bl, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 3], bh, acc[mb], 0, 0, 0);
+      if (MORE && t >= T0) {  // unit k rides on sub-step T0 MB + k SLOTS / LP (LP <= SLOTS)
+        const int i = s - T0 * MB;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < LP; ++k)
+          if ((k * SLOTS) / LP == i) { store_unit((c + 1) & 1, ra, k); any = true; }
+        if (any) {
+#pragma unroll
+          for (int m3 = 0; m3 < 3; ++m3) {  // one MFMA, then up to 12 VALU instructions of the split
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  };
+  static_assert(LP <= SLOTS, "halo units per thread");
+#pragma unroll 1
+  for (int c = 0; c + 1 < NC; ++c) {
+    chunk(c, std::true_type{});
+    if (c < 8) { CH2W_STAMP(4 + c); }
+  }
+  chunk(NC - 1, std::false_type{});
+  CH2W_STAMP(12);
+
+  // ---- two k-waves: p0 + p1 through LDS.  k-wave 0 finishes blocks 0 .. MBH - 1, k-wave 1 the others: each hands
+  // over the blocks it does not finish ----------------------------------------------------------------------------
+  constexpr int MBH = WK == 2 ? (MB + 1) / 2 : MB;
+  const int mb_lo = WK == 2 && wk == 1 ? MBH : 0;
+  const int mb_hi = WK == 2 && wk == 0 ? MBH : MB;
+  if (WK == 2) {
+    float* xch = reinterpret_cast<float*>(lds);
+    auto xaddr = [&](int mb, int r) { return ((((wm * NWV + wn) * MB + mb) * 16 + r) * 64 + lane); };
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const bool mine = mb >= mb_lo && mb < mb_hi;
+      if (!mine) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[xaddr(mb, r)] = acc[mb][r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const bool mine = mb >= mb_lo && mb < mb_hi;
+      if (mine) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float o = xch[xaddr(mb, r)];
+          acc[mb][r] = wk == 0 ? acc[mb][r] + o : o + acc[mb][r];   // p0 + p1
+        }
+      }
+    }
+  }
+  CH2W_STAMP(13);
+
+  // ---- epilogue: bias, ReLU, fp32 NHWC store (32 lanes = 128 contiguous bytes of one pixel), 2x2 max pool of the
+  // lane's window, maximum of |out| for the next layer's scale ------------------------------------------------------
+  const float bias_j = P.bias[n0 + j];
+  float* outb = P.out + (size_t)b * H * W * Cout + n0 + j;
+  float* pb = P.pool_out ? P.pool_out + (size_t)b * (H >> 1) * (W >> 1) * Cout + n0 + j : nullptr;
+  float vmax = 0.f;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    if (mb < mb_lo || mb >= mb_hi) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = 32 * (wm * MB + mb) + ch2::quad_row(q, g);   // first logical row of the quad: a window
+      const int w = m >> 2;
+      const int wy = w / WPR, wx = w - wy * WPR;
+      const int y = y0 + 2 * wy, x = x0 + 2 * wx;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = fmaf(acc[mb][4 * q + e], descale, bias_j);
+        if (P.relu) t = fmaxf(t, 0.f);
+        v[e] = t;
+        const int yy = y + (e >> 1), xx = x + (e & 1);
+        if (yy < H && xx < W) {
+          outb[((size_t)yy * W + xx) * Cout] = t;
+          vmax = fmaxf(vmax, fabsf(t));
+        }
+      }
+      if (pb && y + 1 < H && x + 1 < W)
+        pb[((size_t)(y >> 1) * (W >> 1) + (x >> 1)) * Cout] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    }
+  }
+  if (P.out_amax) {  // 64 slots: same-address atomics serialise in L2 (~10 ns each)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    if (lane == 0)
+      atomicMax(reinterpret_cast<unsigned*>(P.out_amax) + (size_t)b * P.amax_stride + ((blockIdx.x * NWAVES + wave) & 63),
+                __float_as_uint(vmax));
+  }
+  CH2W_STAMP(14);
+}
+
+template <int MB, int MWV, int NWV, int WK, int TH, int TW, int OCC>
+static hipError_t conv_h2w_go(ConvH2Dev d, hipStream_t st) {
+  d.tiles_x = (d.W + TW - 1) / TW;
+  d.tiles_y = (d.H + TH - 1) / TH;
+  const int grid = d.B * d.tiles_x * d.tiles_y * (d.Cout / (32 * NWV));
+  hipLaunchKernelGGL((conv_h2w_kernel<MB, MWV, NWV, WK, TH, TW, OCC>), dim3(grid), dim3(64 * MWV * NWV * WK), 0, st, d);
+  return hipGetLastError();
+}
+
+// k-waves of the batched form, by LAYER SHAPE only (the summation order must not depend on the batch): one where
+// M x N of a few images already fills the chip's 1024 SIMDs with 7-block waves, two from the 56-pixel layers on
+int conv_h2w_kwaves(int H, int W, int Cin, int Cout) {
+  (void)Cin;
+  return (long)H * W * Cout > (long)112 * 112 * 64 ? 1 : 2;  // conv1_2, conv2_x: 1; conv3_x, conv4_x: 2
+}
+
+bool conv_h2w_supported(int H, int W, int Cin, int Cout) {
+  return conv_h2_supported(H, W, Cin, Cout) && Cin % 32 == 0 && (long)H * W >= 28 * 28;
+}
+
+// variant: 0 = by shape and batch; 1..5 force <4,2,2,1,8,32>, <7,1,4,1,8,28>, <7,1,2,1,8,28>, <7,1,4,2,8,28>, <7,1,2,2,8,28>
+// (tests: every shape through every variant; 1..3 have one k-wave, 4..5 two -- variants with the same number of
+// k-waves give the same bits)
+hipError_t conv_h2w_launch(ConvH2Dev d, hipStream_t st, int variant) {
+  if (variant == 0) {
+    const int wk = conv_h2w_kwaves(d.H, d.W, d.Cin, d.Cout);
+    if (wk == 1) {
+      if (d.Cout % 128 == 0) variant = 2;
+      else variant = d.W % 32 == 0 ? 1 : 3;
+    } else {
+      // 128-channel workgroups of eight waves (two per SIMD) while they still give >= ~200 workgroups, else 64-channel ones
+      const long wg128 = (long)d.B * ((d.H + 7) / 8) * ((d.W + 27) / 28) * (d.Cout / 128);
+      variant = d.Cout % 128 == 0 && wg128 >= 200 ? 4 : 5;
+    }
+  }
+  switch (variant) {
+    case 1: return conv_h2w_go<4, 2, 2, 1, 8, 32, 2>(d, st);
+    case 2: return conv_h2w_go<7, 1, 4, 1, 8, 28, 2>(d, st);
+    case 3: return conv_h2w_go<7, 1, 2, 1, 8, 28, 2>(d, st);
+    case 4: return conv_h2w_go<7, 1, 4, 2, 8, 28, 1>(d, st);
+    case 5: return conv_h2w_go<7, 1, 2, 2, 8, 28, 1>(d, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace disn

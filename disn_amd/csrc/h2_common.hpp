@@ -29,4 +29,21 @@ __host__ __device__ constexpr int quad_row(int q, int g) {
 }
 }  // namespace ch2
 
+// one 3x3 SAME convolution launch of conv_h2.hip / conv_h2w.hip
+struct ConvH2Dev {
+  const float* in;            // [B][H][W][Cin]
+  const unsigned char* wimg;  // conv_h2_pack image
+  const float* bias;          // [Cout]
+  const float* in_amax;       // 64 floats whose maximum is max |in|
+  float* out;                 // [B][H][W][Cout]
+  float* pool_out;            // [B][H/2][W/2][Cout] or nullptr
+  float* out_amax;            // 64 floats (zeroed by the caller): atomic max |out| spread over the slots, or nullptr
+  int B, H, W, Cin, Cout;
+  int tiles_x, tiles_y;
+  int relu;
+  int amax_stride;            // floats between the slot groups of consecutive images (0: one group for the whole batch)
+  int img_major;              // tile order [image][n-tile][patch] instead of [n-tile][image][patch] (see the launcher)
+  long long* stamps;  // tuning builds: 16 clock stamps per workgroup (nullptr in the product)
+};
+
 }  // namespace disn

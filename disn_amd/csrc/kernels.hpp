@@ -246,7 +246,7 @@ hipError_t amax64_launch(const float* x, size_t n, float* out64, hipStream_t st)
 // images > 1: `images` arrays of n floats back to back, the slots of image i at out64 + i * out_stride
 hipError_t amax64_accumulate_launch(const float* x, size_t n, float* out64, hipStream_t st, int images = 1,
                                     size_t out_stride = 0);
-hipError_t amax_fold_launch(const float* slots64, float* out, hipStream_t st);
+hipError_t amax_fold_launch(const float* slots, float* out, hipStream_t st, int n = 64);  // maximum of n non-negative slots
 // one stream for n points of one image; pts_rot == nullptr: points k0.. of `grid`.  local: gather from
 // pmap + 'sdfprediction_imgfeat', out = (add_in + sum) / out_div; global: 'sdfprediction' with b4 = the
 // folded per-image bias row, out = sum
@@ -269,6 +269,13 @@ bool conv_h2_supported(int H, int W, int Cin, int Cout);  // Cin, Cout multiples
 hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const void* wimg, const float* bias,
                           int Cout, int relu, const float* in_amax, float* out, float* pool_out, float* out_amax,
                           hipStream_t st, int tiling = 0, int amax_stride = 0);  // amax_stride > 0: slot groups PER IMAGE
+
+// ---- conv_h2w.hip: the same convolution for a batch of images (waves own n-blocks, K sequential; see the file) ----
+struct ConvH2Dev;
+bool conv_h2w_supported(int H, int W, int Cin, int Cout);
+int conv_h2w_kwaves(int H, int W, int Cin, int Cout);   // by layer shape only: fixes the summation order
+hipError_t conv_h2w_launch(ConvH2Dev d, hipStream_t st, int variant);  // variant 0: by shape and batch; 1..5 forced
+constexpr int kConvWideMinImages = 4;   // conv_h2_launch(tiling = 0) takes the batched form from this many images on
 
 // conv1_1 (Cin = 3, Cout = 64) as a direct fp32 FMA convolution; w_hwio: the TF tensor [3][3][3][64] as is
 hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu,

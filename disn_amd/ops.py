@@ -140,7 +140,7 @@ def conv3x3_h2(x: torch.Tensor, image: torch.Tensor, bias: torch.Tensor, cout: i
         out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
     pooled = torch.empty((B, H // 2, W // 2, cout), dtype=torch.float32, device=x.device) if pool else None
     amax = torch.zeros(1, dtype=torch.float32, device=x.device) if want_amax else None
-    ws = _ws(lib().disn_conv3x3_h2_workspace_bytes(), x.device)
+    ws = _ws(lib().disn_conv3x3_h2_workspace_bytes(B), x.device)
     check("disn_conv3x3_h2", lib().disn_conv3x3_h2(
         x.data_ptr(), B, H, W, Cin, image.data_ptr(), bias.data_ptr(), cout, int(relu), out.data_ptr(),
         pooled.data_ptr() if pool else None, amax.data_ptr() if want_amax else None, int(tiling), ws.data_ptr(),

@@ -38,7 +38,7 @@ extern "C" {
 #define DISN_E_WS (-3)    /* workspace too small */
 
 /* ABI version of this header; disn_abi_version() returns the library's. */
-#define DISN_ABI_VERSION 6
+#define DISN_ABI_VERSION 7
 int disn_abi_version(void);
 
 /* ---------------------------------------------------------------------- *
@@ -67,9 +67,18 @@ int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w
  * split-K pass.  disn_pack_conv_h2: TF HWIO [3][3][Cin][Cout] -> the weight image (Cin, Cout multiples of 64;
  * `image` holds disn_pack_conv_h2_bytes).  disn_conv3x3_h2: out = act(conv(in) + bias) [B,H,W,Cout]; optional
  * pool_out = its 2x2 max pool [B,H/2,W/2,Cout] (H, W even), optional out_amax = max |out| (the activation scale
- * of a following disn_conv3x3_h2 inside disn_encode*; here the input's own maximum is measured first).
- * tiling: 0 = by shape, 1..4 = force one of the four workgroup tilings (same result up to summation order --
- * none: the K order of a tile does not depend on the tiling).  ws: disn_conv3x3_h2_workspace_bytes(). */
+ * of a following disn_conv3x3_h2 inside disn_encode*; here every image's own maximum is measured first: as inside
+ * disn_encode* the scale of an image, hence its bits, never depend on the other images of the call).
+ * tiling: 0 = by shape and batch, 1..4 = force one of the four single-image workgroup tilings (the K order of an
+ * output element depends on the number of k-waves only: tilings with the same number give the same bits), 5..9 =
+ * force variant 1..5 of the BATCHED form (conv_h2w.hip: waves own 32-channel n-blocks of 128..224-pixel patches and
+ * walk K sequentially; variants 1..3 one k-wave, 4..5 two; H*W >= 784).
+ * SELECTION RULE of tiling 0 (also inside disn_vgg16_* / disn_encode*): calls of B >= 4 images take the batched form
+ * for layers of 28 x 28 pixels and more (one k-wave where H*W*Cout > 112*112*64, else two -- by layer shape only),
+ * everything else the single-image form.  The two forms sum K in different orders: results agree to fp32 rounding
+ * (both within 2e-6 of the layer's scale of the float64 convolution), NOT bit for bit -- an image's bits depend on
+ * which form ran it (B >= 4 or not), never on its companions, its position or the exact B.
+ * ws: disn_conv3x3_h2_workspace_bytes(B). */
 size_t disn_pack_conv_h2_bytes(int Cin, int Cout);
 int disn_pack_conv_h2(const float* w_hwio, int Cin, int Cout, void* image, void* stream);
 /* conv1_1 (3 -> 64 channels; models/CNN/vgg.py:187) as a direct fp32 FMA convolution: w_hwio is the TF tensor
@@ -77,7 +86,7 @@ int disn_pack_conv_h2(const float* w_hwio, int Cin, int Cout, void* image, void*
 size_t disn_conv1_1_workspace_bytes(void);
 int disn_conv1_1(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu, float* out,
                  float* out_amax, void* ws, size_t ws_bytes, void* stream);
-size_t disn_conv3x3_h2_workspace_bytes(void);
+size_t disn_conv3x3_h2_workspace_bytes(int B);
 int disn_conv3x3_h2(const float* in, int B, int H, int W, int Cin, const void* image, const float* bias, int Cout,
                     int relu, float* out, float* pool_out, float* out_amax, int tiling, void* ws, size_t ws_bytes,
                     void* stream);

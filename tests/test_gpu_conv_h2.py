@@ -101,11 +101,12 @@ def test_tilings_agree_bit_for_bit_and_runs_repeat(ops):
         assert np.array_equal(o[0], v)
 
 
-@pytest.mark.parametrize("hw,cin,cout", [(224, 64, 64), (112, 128, 128), (56, 256, 256), (14, 512, 512)])
-def test_multi_round_variants_give_the_single_image_bits(ops, hw, cin, cout):
-    """A launch of several rounds of workgroups (here: four copies of one image) goes through the
-    two-workgroups-per-CU variants (smaller register budget, one-pair weight queue, 16 x 16 layers on half-height
-    patches); k-waves and summation order are the single-image tiling's, so are the bits -- and the pooled copy's."""
+def test_multi_round_variants_give_the_single_image_bits(ops):
+    """14-pixel layers (conv5_x) of a batched call stay on conv_h2.hip: a launch of several rounds of workgroups
+    (here: four copies of one image) goes through its two-workgroups-per-CU variant (smaller register budget,
+    one-pair weight queue); k-waves and summation order are the single-image tiling's, so are the bits -- and the
+    pooled copy's."""
+    hw, cin, cout = 14, 512, 512
     x, w, b = case(1, hw, hw, cin, cout, 77 + hw)
     img = ops.pack_conv_h2(dev(w))
     one, pool1, _ = ops.conv3x3_h2(dev(x), img, dev(b), cout, True, pool=True, want_amax=True)
@@ -113,6 +114,65 @@ def test_multi_round_variants_give_the_single_image_bits(ops, hw, cin, cout):
     for k in range(4):
         assert torch.equal(four[k], one[0]) and torch.equal(pool4[k], pool1[0]), k
     assert float(amax4) == float(one.abs().max())
+
+
+# ---- the batched form (disn_amd/csrc/conv_h2w.hip): tiling 5..9 force its variants 1..5, tiling 0 takes it from
+# four images per call on (28-pixel layers and larger) --------------------------------------------------------------
+WIDE_ONE_KWAVE, WIDE_TWO_KWAVES = (5, 6, 7), (8, 9)
+
+
+@pytest.mark.parametrize("tiling", WIDE_ONE_KWAVE + WIDE_TWO_KWAVES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 30, 44, 64, 128), (1, 36, 62, 128, 128), (3, 28, 28, 192, 128)])
+def test_every_batched_variant_on_ragged_shapes(ops, tiling, B, H, W, Cin, Cout):
+    x, w, b = case(B, H, W, Cin, Cout, 100 * tiling + H, relu_input=False)
+    ref = O.conv2d(x, w, b, "SAME", False, dtype=np.float64)
+    out, pooled, amax = ops.conv3x3_h2(dev(x), ops.pack_conv_h2(dev(w)), dev(b), Cout, False, pool=True,
+                                       want_amax=True, tiling=tiling)
+    got = host(out)
+    report_close("conv3x3_h2 batched variant %d %s" % (tiling - 4, (B, H, W, Cin, Cout)), got, ref, atol=1e-5, rtol=1e-5)
+    assert float(np.abs(got - ref).max()) <= 2e-6 * float(np.abs(ref).max())
+    assert np.array_equal(host(pooled), got.reshape(B, H // 2, 2, W // 2, 2, Cout).max(axis=(2, 4)))
+    assert float(amax) == float(np.abs(got).max())
+
+
+def test_batched_variants_with_the_same_k_waves_agree_bit_for_bit_and_runs_repeat(ops):
+    """the K order of an output element depends on the number of k-waves only (one: k16 blocks ascending, taps inside;
+    two: p0 + p1), not on the patch or the n-waves per workgroup"""
+    x, w, b = case(2, 40, 60, 128, 128, 311)
+    img, xd, bd = ops.pack_conv_h2(dev(w)), dev(x), dev(b)
+    o = {t: host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=t)) for t in WIDE_ONE_KWAVE + WIDE_TWO_KWAVES}
+    assert np.array_equal(o[5], o[6]) and np.array_equal(o[6], o[7])
+    assert np.array_equal(o[8], o[9])
+    assert np.abs(o[5] - o[8]).max() <= 1e-6 * np.abs(o[8]).max()
+    for t in (5, 6, 8, 9):
+        assert np.array_equal(o[t], host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=t)))
+
+
+@pytest.mark.parametrize("hw,cin,cout", [(224, 64, 64), (112, 64, 128), (112, 128, 128), (56, 128, 256), (56, 256, 256),
+                                         (28, 256, 512), (28, 512, 512)])
+def test_batched_form_on_the_vgg_layer_shapes(ops, hw, cin, cout):
+    """tiling 0 with four images per call = the batched form.  Against float64 (first image), against the
+    single-image kernel (every image: another summation order, fp32 rounding only), the fused pool, the maximum,
+    and: an image's bits do not depend on the images it travels with nor on its position in the call."""
+    x, w, b = case(4, hw, hw, cin, cout, hw + cin + 1)
+    x *= np.array([1.0, 0.25, 3.0, 1e-3], np.float32).reshape(4, 1, 1, 1)        # every image its own scale
+    img, bd = ops.pack_conv_h2(dev(w)), dev(b)
+    out, pooled, amax = ops.conv3x3_h2(dev(x), img, bd, cout, True, pool=True, want_amax=True)
+    got = host(out)
+    ref0 = O.conv2d(x[:1], w, b, "SAME", True, dtype=np.float64)
+    sc0 = float(np.abs(ref0).max())
+    err0 = float(np.abs(got[:1] - ref0).max())
+    print("batched hw %d cin %d cout %d: max err %.3g of scale %.3g (%.3g)" % (hw, cin, cout, err0, sc0, err0 / sc0))
+    assert err0 <= 2e-6 * sc0
+    for k in range(4):
+        one = host(ops.conv3x3_h2(dev(x[k:k + 1]), img, bd, cout, True))
+        assert np.abs(got[k] - one[0]).max() <= 2e-6 * np.abs(one).max(), k
+    assert np.array_equal(host(pooled), got.reshape(4, hw // 2, 2, hw // 2, 2, cout).max(axis=(2, 4)))
+    assert float(amax) == float(np.abs(got).max())
+    # other companions, other position, other batch size (5): the same bits
+    x2 = np.concatenate([x[3:4], x[3:4] * 0.5, x[0:1], x[1:2], x[2:3]], axis=0)
+    got2 = host(ops.conv3x3_h2(dev(x2), img, bd, cout, True))
+    assert np.array_equal(got2[2], got[0]) and np.array_equal(got2[0], got[3]) and np.array_equal(got2[4], got[2])
 
 
 def test_zero_input_and_tiny_activations(ops):

@@ -37,7 +37,7 @@ for cin, cout, hw in LAYERS:
     s = stamps.cpu().numpy()
     s = s[s[:, 1] != 0]
     wall = (s[:, 0] - s[:, 0].min()) / 100.0          # wall_clock64: 100 MHz -> us
-    nc = cin // 64
+    nc = cin // int(os.environ.get("STAMP_CK", "64"))   # channels per chunk of the kernel that ran (conv_h2w: 16 or 32)
     idx = [1, 2, 3] + [4 + c for c in range(min(nc - 1, 8))] + [12, 13, 14]
     names = ["setup", "prologue"] + ["chunk%d" % c for c in range(min(nc - 1, 8))] + ["last chunk", "k-reduce", "epilogue"]
     print("B %d cin %d cout %d hw %d: %d workgroups; start skew: median %.2f us, max %.2f us (the launch's rounds show as "
