@@ -184,13 +184,19 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   __syncthreads();
   CH2W_STAMP(3);
 
-  // ---- one chunk: 9 taps x MB blocks = 9 MB sub-steps of three MFMAs from LDS buffer c & 1.  The A pair of
-  // sub-step s + 2 is read while the MFMAs of s run (three rolling register pairs); each tap requests the weight
-  // pair D taps ahead into the queue slot it just freed; MORE: the next chunk's halo is requested at the top and
-  // split into the other buffer one unit at a time between the MFMAs of taps T0..8 ------------------------------
+  // ---- one chunk: 9 taps x MB blocks = 9 MB sub-steps (tap t = s / MB, block s % MB) of three MFMAs from LDS buffer
+  // c & 1, issued as PAIRS of sub-steps: l0 l1 | h0 h1 | h0 h1 -- consecutive MFMAs never wait for each other's
+  // accumulator (what a wave alone on its SIMD cannot hide).  The A fragments of pair p + PD are read while the
+  // MFMAs of pair p run (ring of 2 (PD + 1) register pairs); a tap's weight pair is replaced by the one D taps ahead
+  // as soon as its last sub-step is issued; MORE: the next chunk's halo is requested at the top and split into the
+  // other buffer one unit at a time between the MFMAs of the pairs from tap T0 on -----------------------------------
   constexpr int S = 9 * MB;
+  constexpr int NP = (S + 1) / 2;                // pairs of sub-steps
+  constexpr int PD = OCC * NWAVES >= 8 ? 1 : 2;  // pairs the A reads run ahead (two with one wave per SIMD: 512 registers)
+  constexpr int NB = 2 * (PD + 1);
   constexpr int T0 = 4;
-  constexpr int SLOTS = (9 - T0) * MB;   // sub-steps that may carry a unit of the next halo
+  constexpr int P0 = (T0 * MB + 1) / 2;          // first pair that may carry a unit of the next halo
+  constexpr int SLOTS = NP - P0;
   auto chunk = [&](int c, auto more_c) {
     constexpr bool MORE = decltype(more_c)::value;
     float4 ra[LP];
@@ -199,45 +205,57 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) ab[mb] = arow[mb] + (c & 1) * BUF;
     const unsigned char* wcur = wp + (size_t)c * kChunkStride;
-    ch_h8 ah[3], al[3], bh, bl;
+    ch_h8 ah[NB], al[NB];
     auto rd = [&](int s) {
       const int t = s / MB, mb = s % MB;
       const int off = (t / 3) * ROWB + (t % 3) * KPIX;
-      ah[s % 3] = *reinterpret_cast<const ch_h8*>(&lds[ab[mb] + off]);
-      al[s % 3] = *reinterpret_cast<const ch_h8*>(&lds[ab[mb] + off + CK * 2]);
+      ah[s % NB] = *reinterpret_cast<const ch_h8*>(&lds[ab[mb] + off]);
+      al[s % NB] = *reinterpret_cast<const ch_h8*>(&lds[ab[mb] + off + CK * 2]);
     };
-    rd(0);
-    rd(1);
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const int t = s / MB, mb = s % MB;
-      if (mb == 0) {
-        bh = qh[t % D];
-        bl = ql[t % D];
-        if (MORE || t + D < 9) {  // the pair D taps ahead: this chunk's or the next one's
+    for (int s = 0; s < 2 * PD; ++s) rd(s);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int s0 = 2 * p, s1 = 2 * p + 1;
+      const int t0 = s0 / MB, m0 = s0 % MB, t1 = s1 / MB, m1 = s1 % MB;
+      if (s0 + 2 * PD < S) rd(s0 + 2 * PD);
+      if (s1 + 2 * PD < S) rd(s1 + 2 * PD);
+      __builtin_amdgcn_sched_barrier(0);  // the reads above are ISSUED here, not sunk next to their uses
+      if (s1 < S) {
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s0 % NB], qh[t0 % D], acc[m0], 0, 0, 0);
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s1 % NB], qh[t1 % D], acc[m1], 0, 0, 0);
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s0 % NB], ql[t0 % D], acc[m0], 0, 0, 0);
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s1 % NB], ql[t1 % D], acc[m1], 0, 0, 0);
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s0 % NB], qh[t0 % D], acc[m0], 0, 0, 0);
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s1 % NB], qh[t1 % D], acc[m1], 0, 0, 0);
+      } else {
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s0 % NB], qh[t0 % D], acc[m0], 0, 0, 0);
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s0 % NB], ql[t0 % D], acc[m0], 0, 0, 0);
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s0 % NB], qh[t0 % D], acc[m0], 0, 0, 0);
+      }
+      bool any = false;
+      if (MORE && p >= P0) {  // unit k rides on pair P0 + k SLOTS / LP (LP <= SLOTS)
+#pragma unroll
+        for (int k = 0; k < LP; ++k)
+          if ((k * SLOTS) / LP == p - P0) { store_unit((c + 1) & 1, ra, k); any = true; }
+      }
+      if (any) {
+#pragma unroll
+        for (int m6 = 0; m6 < (s1 < S ? 6 : 3); ++m6) {  // one MFMA, then a share of the split's VALU instructions
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the taps whose last sub-step was just issued hand their queue slot to the pair D taps ahead
+#pragma unroll
+      for (int t = t0; t <= (s1 < S ? t1 : t0); ++t) {
+        const int last = (t + 1) * MB - 1;
+        if ((last == s0 || (last == s1 && s1 < S)) && (MORE || t + D < 9)) {
           const unsigned char* wa = wcur + ((t + D) / 9) * kChunkStride + (size_t)((t + D) % 9) * 2048;
           qh[t % D] = *reinterpret_cast<const ch_h8*>(wa);
           ql[t % D] = *reinterpret_cast<const ch_h8*>(wa + 1024);
-        }
-      }
-      if (s + 2 < S) rd(s + 2);
-      __builtin_amdgcn_sched_barrier(0);  // the loads above are ISSUED here, not sunk next to their uses
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % 3], bh, acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 3], bl, acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 3], bh, acc[mb], 0, 0, 0);
-      if (MORE && t >= T0) {  // unit k rides on sub-step T0 MB + k SLOTS / LP (LP <= SLOTS)
-        const int i = s - T0 * MB;
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < LP; ++k)
-          if ((k * SLOTS) / LP == i) { store_unit((c + 1) & 1, ra, k); any = true; }
-        if (any) {
-#pragma unroll
-          for (int m3 = 0; m3 < 3; ++m3) {  // one MFMA, then up to 12 VALU instructions of the split
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -285,34 +303,48 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   CH2W_STAMP(13);
 
   // ---- epilogue: bias, ReLU, fp32 NHWC store (32 lanes = 128 contiguous bytes of one pixel), 2x2 max pool of the
-  // lane's window, maximum of |out| for the next layer's scale ------------------------------------------------------
+  // lane's window, maximum of |out| for the next layer's scale.  Addresses: four wave-uniform bases (the window's
+  // four pixels) + one 32-bit lane offset per window, picked between the two lane halves' compile-time window
+  // positions -- no per-store 64-bit arithmetic; tiles inside the image take the branch without predicates ---------
   const float bias_j = P.bias[n0 + j];
-  float* outb = P.out + (size_t)b * H * W * Cout + n0 + j;
-  float* pb = P.pool_out ? P.pool_out + (size_t)b * (H >> 1) * (W >> 1) * Cout + n0 + j : nullptr;
+  const int WC = W * Cout;
+  float* o00 = P.out + ((size_t)b * H * W + (size_t)y0 * W + x0) * Cout + n0;
+  float* o01 = o00 + Cout;
+  float* o10 = o00 + WC;
+  float* o11 = o10 + Cout;
+  const int Wp = W >> 1;
+  float* pb = P.pool_out ? P.pool_out + ((size_t)b * (H >> 1) * Wp + (size_t)(y0 >> 1) * Wp + (x0 >> 1)) * Cout + n0 : nullptr;
+  const bool full = y0 + TH <= H && x0 + TW <= W;
   float vmax = 0.f;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     if (mb < mb_lo || mb >= mb_hi) continue;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int m = 32 * (wm * MB + mb) + ch2::quad_row(q, g);   // first logical row of the quad: a window
-      const int w = m >> 2;
-      const int wy = w / WPR, wx = w - wy * WPR;
-      const int y = y0 + 2 * wy, x = x0 + 2 * wx;
+      // the window of this quad for lane half 0 / 1 (compile-time but for wm: MWV == 1 in all but one variant)
+      const int wA = (32 * (wm * MB + mb) + ch2::quad_row(q, 0)) >> 2, wB = (32 * (wm * MB + mb) + ch2::quad_row(q, 1)) >> 2;
+      const int wyA = wA / WPR, wxA = wA - wyA * WPR, wyB = wB / WPR, wxB = wB - wyB * WPR;
+      const int wy = g ? wyB : wyA, wx = g ? wxB : wxA;
+      const int off = (g ? 2 * wyB * WC + 2 * wxB * Cout : 2 * wyA * WC + 2 * wxA * Cout) + j;
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = fmaf(acc[mb][4 * q + e], descale, bias_j);
-        if (P.relu) t = fmaxf(t, 0.f);
-        v[e] = t;
-        const int yy = y + (e >> 1), xx = x + (e & 1);
-        if (yy < H && xx < W) {
-          outb[((size_t)yy * W + xx) * Cout] = t;
-          vmax = fmaxf(vmax, fabsf(t));
-        }
+        v[e] = P.relu ? fmaxf(t, 0.f) : t;
       }
-      if (pb && y + 1 < H && x + 1 < W)
-        pb[((size_t)(y >> 1) * (W >> 1) + (x >> 1)) * Cout] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+      const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+      if (full) {
+        o00[off] = v[0]; o01[off] = v[1]; o10[off] = v[2]; o11[off] = v[3];
+        vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        if (pb) pb[(wy * Wp + wx) * Cout + j] = m4;
+      } else {
+        const int y = y0 + 2 * wy, x = x0 + 2 * wx;
+        if (y < H && x < W) { o00[off] = v[0]; vmax = fmaxf(vmax, fabsf(v[0])); }
+        if (y < H && x + 1 < W) { o01[off] = v[1]; vmax = fmaxf(vmax, fabsf(v[1])); }
+        if (y + 1 < H && x < W) { o10[off] = v[2]; vmax = fmaxf(vmax, fabsf(v[2])); }
+        if (y + 1 < H && x + 1 < W) { o11[off] = v[3]; vmax = fmaxf(vmax, fabsf(v[3])); }
+        if (pb && y + 1 < H && x + 1 < W) pb[(wy * Wp + wx) * Cout + j] = m4;
+      }
     }
   }
   if (P.out_amax) {  // 64 slots: same-address atomics serialise in L2 (~10 ns each)

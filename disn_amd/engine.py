@@ -390,7 +390,7 @@ class StepPipeline:
         except Exception:  # interpreter shutdown
             pass
 
-    def run(self, jobs, keep_encoded: bool = False, chained: Optional[bool] = None):
+    def run(self, jobs, keep_encoded: bool = False, chained: Optional[bool] = None, balance: bool = False):
         """jobs: sequence of (imgs, pts, trans_mat[, pts_rot]) -> list of pred_sdf (or (Encoded, pred_sdf)) in
         job order.  Job k runs on engine context k % in_flight.  Returns with the work enqueued, not finished:
         synchronise the device (or the returned tensors' use on the current stream) as usual.
@@ -406,7 +406,7 @@ class StepPipeline:
         if chained is None:
             chained = False
         if self.batch > 1:
-            return self._run_batched(jobs, keep_encoded)
+            return self._run_batched(jobs, keep_encoded, balance)
         out = [None] * len(jobs)
         cur = torch.cuda.current_stream(self.device)
         if chained:
@@ -443,10 +443,32 @@ class StepPipeline:
             cur.wait_stream(st)                            # results are ordered before later work on the caller's stream
         return out
 
-    def _run_batched(self, jobs, keep_encoded):
-        """groups of ``batch`` consecutive jobs -> one call each; group g runs on context g % in_flight"""
+    @staticmethod
+    def call_sizes(njobs: int, batch: int, in_flight: int, balance: bool):
+        """how many consecutive jobs go into each call.  Default: full calls of ``batch`` + a shorter last one.
+        ``balance``: the same number of calls rounded up to a multiple of ``in_flight`` (every context gets the same
+        number), all of (nearly) equal size -- never below four jobs per call while full calls would have had four (the
+        batched kernels' threshold), never above ``batch``: a short run (bench.py --steps 20) then ends with every
+        context busy instead of one draining a short last call alone."""
+        if njobs <= 0:
+            return []
+        n = -(-njobs // batch)
+        if not balance:
+            return [batch] * (njobs // batch) + ([njobs % batch] if njobs % batch else [])
+        n = -(-n // in_flight) * in_flight
+        while n > 1 and njobs // n < min(4, batch):
+            n -= 1
+        n = max(n, -(-njobs // batch))
+        base, extra = divmod(njobs, n)
+        return [base + (1 if i < extra else 0) for i in range(n)]
+
+    def _run_batched(self, jobs, keep_encoded, balance=False):
+        """groups of up to ``batch`` consecutive jobs -> one call each; group g runs on context g % in_flight"""
         S, Bn = len(self.engines), self.batch
-        groups = [list(range(i, min(i + Bn, len(jobs)))) for i in range(0, len(jobs), Bn)]
+        groups, o = [], 0
+        for n in self.call_sizes(len(jobs), Bn, S, balance):
+            groups.append(list(range(o, o + n)))
+            o += n
         out = [None] * len(jobs)
         cur = torch.cuda.current_stream(self.device)
 

@@ -143,7 +143,7 @@ def test_batched_variants_with_the_same_k_waves_agree_bit_for_bit_and_runs_repea
     o = {t: host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=t)) for t in WIDE_ONE_KWAVE + WIDE_TWO_KWAVES}
     assert np.array_equal(o[5], o[6]) and np.array_equal(o[6], o[7])
     assert np.array_equal(o[8], o[9])
-    assert np.abs(o[5] - o[8]).max() <= 1e-6 * np.abs(o[8]).max()
+    assert np.abs(o[5] - o[8]).max() <= 2e-6 * np.abs(o[8]).max()      # two fp32 summation orders
     for t in (5, 6, 8, 9):
         assert np.array_equal(o[t], host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=t)))
 
