@@ -35,6 +35,7 @@ SOURCES = {
     "conv_h2.hip": [],
     "conv_h2w.hip": [],
     "dense_h2.hip": [],
+    "dense_h2w.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],
     "marching_cubes.hip": ["-ffp-contract=off"],
     "api.hip": [],

@@ -250,6 +250,14 @@ hipError_t dense_h2_launch(const DenseH2Prob* probs, int nprob, hipStream_t st) 
   }
   d.nprob = nprob;
   const DenseH2Prob& p = d.p[0];
+  // Rows of >= kConvWideMinImages images (a batched call): the batched form of dense_h2w.hip (another K summation
+  // order: fp32 rounding apart from the tiles below, not bit for bit; the rule looks at the call's image count and
+  // the rows per image only, so an image's bits never depend on its companions)
+  if (p.amax_rows > 0 && p.amax_rows % 128 == 0 && p.M / p.amax_rows >= tune::conv_wide_min) {
+    bool ok = true;
+    for (int i = 0; i < nprob; ++i) ok = ok && dense_h2w_supported(d.p[i]) && d.p[i].amax_rows == p.amax_rows;
+    if (ok) return dense_h2w_go(d, st);
+  }
   // Tile rows BM = 32 MB.  Neither the tile shape nor the chunk width changes a result bit (a k-wave adds its k16
   // blocks in ascending order and the four partial tiles are summed in one fixed order whatever the tiling):
   //   64 rows when that gives ~200 workgroups, else 32 (a single image's 2048 rows: latency-bound); 128 rows
@@ -306,35 +314,36 @@ int disn_pack_dense_h2(const float* w_kn, int K, int N, void* image, void* strea
   return e == hipSuccess ? 0 : (int)e;
 }
 
-size_t disn_dense_h2_workspace_bytes(void) { return 1024; }
+size_t disn_dense_h2_workspace_bytes(int images) { return (size_t)(images > 0 ? images : 1) * 1024; }
 
 int disn_dense_h2(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, const float* in_bias, int M,
-                  const void* image, const float* bias, int N, int relu, float* out, float* out_amax, void* ws,
-                  size_t ws_bytes, void* stream) {
-  if (!a1 || !image || !bias || !out || !ws || M <= 0 || k1 <= 0 || k2 < 0 || (k2 > 0 && !a2)) return DISN_E_ARG;
+                  int rows_per_image, const void* image, const float* bias, int N, int relu, float* out, float* out_amax,
+                  void* ws, size_t ws_bytes, void* stream) {
+  if (!a1 || !image || !bias || !out || !ws || M <= 0 || k1 <= 0 || k2 < 0 || (k2 > 0 && !a2) || rows_per_image < 0)
+    return DISN_E_ARG;
   const int K = k1 + k2;
-  if (!disn::dense_h2_supported(M, K, N, k1) || lda1 < k1 || (k2 > 0 && lda2 < k2) || lda1 % 4 || (k2 > 0 && lda2 % 4))
-    return DISN_E_SHAPE;
-  if (ws_bytes < 1024) return DISN_E_WS;
+  if (!disn::dense_h2_supported(M, K, N, k1) || lda1 != k1 || (k2 > 0 && lda2 != k2)) return DISN_E_SHAPE;
+  if (rows_per_image > 0 && (M % rows_per_image || rows_per_image % 64)) return DISN_E_SHAPE;
+  const int imgs = rows_per_image > 0 ? M / rows_per_image : 1;
+  const size_t rows = rows_per_image > 0 ? rows_per_image : M;
+  if (ws_bytes < (size_t)imgs * 1024) return DISN_E_WS;
   hipStream_t st = (hipStream_t)stream;
-  float* s1 = static_cast<float*>(ws);  // 64 slots max |a1|, 64 slots max |a2|, 64 slots max |out|
-  hipError_t e = hipSuccess;
-  // the rows' maxima: whole rows of a1 / a2 are measured (lda == k columns in every use; a wider lda would only
-  // loosen the scale)
-  if (lda1 == k1) e = disn::amax64_launch(a1, (size_t)M * k1, s1, st);
-  else return DISN_E_SHAPE;
-  if (e == hipSuccess && k2 > 0) {
-    if (lda2 != k2) return DISN_E_SHAPE;
-    e = disn::amax64_launch(a2, (size_t)M * k2, s1 + 64, st);
-  }
-  if (e == hipSuccess && out_amax) e = hipMemsetAsync(s1 + 128, 0, 256, st);
+  // per image (256 floats apart): 64 slots max |a1|, 64 slots max |a2|, 64 slots max |out|
+  float* s1 = static_cast<float*>(ws);
+  hipError_t e = hipMemsetAsync(s1, 0, (size_t)imgs * 1024, st);
+  if (e == hipSuccess) e = disn::amax64_accumulate_launch(a1, rows * k1, s1, st, imgs, 256);
+  if (e == hipSuccess && k2 > 0) e = disn::amax64_accumulate_launch(a2, rows * k2, s1 + 64, st, imgs, 256);
   if (e != hipSuccess) return (int)e;
   disn::DenseH2Prob p{};
   p.a = a1; p.lda = lda1; p.k1 = k1; p.a2 = k2 > 0 ? a2 : nullptr; p.lda2 = lda2; p.in_bias = in_bias;
   p.wimg = static_cast<const unsigned char*>(image); p.bias = bias; p.in_amax = s1; p.in_amax2 = k2 > 0 ? s1 + 64 : nullptr;
   p.out = out; p.ldc = N; p.out_amax = out_amax ? s1 + 128 : nullptr; p.M = M; p.N = N; p.K = K; p.relu = relu;
+  if (rows_per_image > 0) {
+    p.amax_rows = rows_per_image; p.amax_stride = 256;
+    if (in_bias) p.in_bias_rows = rows_per_image;
+  }
   e = disn::dense_h2_launch(&p, 1, st);
-  if (e == hipSuccess && out_amax) e = disn::amax_fold_launch(s1 + 128, out_amax, st);
+  if (e == hipSuccess && out_amax) e = disn::amax_fold_launch(s1 + 128, out_amax, st, 64, imgs, 256);
   return e == hipSuccess ? 0 : (int)e;
 }
 

@@ -246,7 +246,8 @@ hipError_t amax64_launch(const float* x, size_t n, float* out64, hipStream_t st)
 // images > 1: `images` arrays of n floats back to back, the slots of image i at out64 + i * out_stride
 hipError_t amax64_accumulate_launch(const float* x, size_t n, float* out64, hipStream_t st, int images = 1,
                                     size_t out_stride = 0);
-hipError_t amax_fold_launch(const float* slots, float* out, hipStream_t st, int n = 64);  // maximum of n non-negative slots
+// maximum of n non-negative slots; groups > 1: `groups` runs of n slots, `stride` floats apart
+hipError_t amax_fold_launch(const float* slots, float* out, hipStream_t st, int n = 64, int groups = 1, int stride = 0);
 // one stream for n points of one image; pts_rot == nullptr: points k0.. of `grid`.  local: gather from
 // pmap + 'sdfprediction_imgfeat', out = (add_in + sum) / out_div; global: 'sdfprediction' with b4 = the
 // folded per-image bias row, out = sum
@@ -309,6 +310,11 @@ struct DenseH2Dev {
 bool dense_h2_supported(int M, int K, int N, int k1);  // K, N multiples of 64; k1 a multiple of the chunk (256 when K % 256 == 0, else 64)
 // one or two problems of ONE shape in one launch (the same layer of the global and the local stream)
 hipError_t dense_h2_launch(const DenseH2Prob* probs, int nprob, hipStream_t st);
+// dense_h2w.hip: the batched form (128 x 256 tiles, n-waves, K sequential).  dense_h2_launch takes it when the rows
+// belong to >= kConvWideMinImages images (amax_rows > 0, M / amax_rows images) of a multiple of 128 rows each and the
+// shape allows (N % 256 == 0, K and k1 multiples of 128): by the call's image count, never by the other images
+bool dense_h2w_supported(const DenseH2Prob& p);
+hipError_t dense_h2w_go(DenseH2Dev d, hipStream_t st);
 
 // ---- mlp_small.hip ---------------------------------------------------------
 // relu(p . W1 + b1) for both streams: pts [M][3] -> out_g [M][64], out_l [M][64]

@@ -207,15 +207,16 @@ hipError_t amax64_accumulate_launch(const float* x, size_t n, float* out64, hipS
   return amax_go(x, n, out64, 64, st, false, images, out_stride);
 }
 
-__global__ void amax_fold_kernel(const float* __restrict__ slots, int n, float* __restrict__ out) {
+__global__ void amax_fold_kernel(const float* __restrict__ slots, int n, int groups, int stride, float* __restrict__ out) {
   float m = 0.f;
-  for (int i = threadIdx.x; i < n; i += 64) m = fmaxf(m, slots[i]);
+  for (int gi = 0; gi < groups; ++gi)
+    for (int i = threadIdx.x; i < n; i += 64) m = fmaxf(m, slots[(size_t)gi * stride + i]);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
   if (threadIdx.x == 0) out[0] = m;
 }
-hipError_t amax_fold_launch(const float* slots, float* out, hipStream_t st, int n) {
-  hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(64), 0, st, slots, n, out);
+hipError_t amax_fold_launch(const float* slots, float* out, hipStream_t st, int n, int groups, int stride) {
+  hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(64), 0, st, slots, n, groups, stride, out);
   return hipGetLastError();
 }
 

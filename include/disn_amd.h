@@ -179,13 +179,21 @@ int disn_fc_t(const float* x, int B, int K, const float* wt_nk, const float* bia
  * f = relu(. + in_bias[k]) when in_bias != NULL (the deferred bias + ReLU of a layer whose product was formed before
  * its bias existed), else the identity; lda1 == k1, lda2 == k2 (the rows' maxima are measured over the whole
  * buffers); k1 a multiple of 256 when K = k1 + k2 is, else of 64.  Optional out_amax = max |out|.
- * ws: disn_dense_h2_workspace_bytes(). */
+ * rows_per_image: 0 = the M rows are one set (one activation scale per source); > 0 (a multiple of 64 dividing M):
+ * rows image-major, every image its own maxima / scales -- as inside disn_encode_query -- and in_bias is
+ * [M / rows_per_image][K], one row per image.
+ * SELECTION RULE (also inside disn_encode_query): rows of >= 4 images with rows_per_image % 128 == 0, N % 256 == 0,
+ * K and k1 multiples of 128 take the BATCHED form (dense_h2w.hip: 128 x 256 tiles, eight n-waves, K summed in one
+ * accumulator in ascending order), everything else the four-k-wave tiles of dense_h2.hip.  The two forms agree to
+ * fp32 rounding (both within 2e-6 of the output scale of the float64 product), not bit for bit; which form runs
+ * depends on the call's image count and rows per image only, never on the other images' data.
+ * ws: disn_dense_h2_workspace_bytes(images). */
 size_t disn_pack_dense_h2_bytes(int K, int N);
 int disn_pack_dense_h2(const float* w_kn, int K, int N, void* image, void* stream);
-size_t disn_dense_h2_workspace_bytes(void);
+size_t disn_dense_h2_workspace_bytes(int images);
 int disn_dense_h2(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, const float* in_bias, int M,
-                  const void* image, const float* bias, int N, int relu, float* out, float* out_amax, void* ws,
-                  size_t ws_bytes, void* stream);
+                  int rows_per_image, const void* image, const float* bias, int N, int relu, float* out,
+                  float* out_amax, void* ws, size_t ws_bytes, void* stream);
 
 /* Row K: the scalars of get_loss (models/model_normalization.py:273-299, regression branch) in one launch:
  * out5 = {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}; pred [M] = pred_sdf

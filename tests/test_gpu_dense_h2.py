@@ -92,3 +92,71 @@ def test_argument_checks(ops):
     with pytest.raises(_lib.DisnError) as e:       # k1 = 32 is not a multiple of the 64-column chunk
         ops.dense_h2(dev(a[:, :32]), img, dev(b), 64, True, a2=dev(a[:, 32:]))
     assert e.value.status == -2
+
+
+# ---- the batched form (disn_amd/csrc/dense_h2w.hip): rows of >= 4 images, a multiple of 128 rows each ----------------
+def _ref(a, w, b, relu, in_bias=None, rows=0):
+    a = a.astype(np.float64)
+    if in_bias is not None:
+        a = np.maximum(a + np.repeat(in_bias.astype(np.float64), rows, axis=0), 0)
+    r = a @ w.astype(np.float64) + b
+    return np.maximum(r, 0) if relu else r
+
+
+@pytest.mark.parametrize("imgs,rows,K,N,relu", [(4, 2048, 256, 512, True), (8, 2048, 512, 512, False),
+                                                (8, 2048, 512, 256, True), (5, 384, 1024, 256, True), (4, 128, 128, 512, True)])
+def test_batched_form_vs_float64_and_the_single_image_form(ops, imgs, rows, K, N, relu):
+    a, w, b = case(imgs * rows, K, N, imgs + rows + K + N)
+    a = a.reshape(imgs, rows, K) * (0.5 + np.arange(imgs, dtype=np.float32)).reshape(imgs, 1, 1)   # every image its own scale
+    a = np.ascontiguousarray(a.reshape(imgs * rows, K))
+    ref = _ref(a, w, b, relu)
+    img = ops.pack_dense_h2(dev(w))
+    out, amax = ops.dense_h2(dev(a), img, dev(b), N, relu, want_amax=True, rows_per_image=rows)
+    got = host(out)
+    for i in range(imgs):
+        sl = slice(i * rows, (i + 1) * rows)
+        sc = float(np.abs(ref[sl]).max())
+        assert np.abs(got[sl] - ref[sl]).max() <= 2e-6 * sc, i
+        one = host(ops.dense_h2(dev(a[sl]), img, dev(b), N, relu))            # the four-k-wave tiles
+        assert np.abs(got[sl] - one).max() <= 2e-6 * sc, i
+    assert float(amax) == float(np.abs(got).max())
+    assert np.array_equal(got, host(ops.dense_h2(dev(a), img, dev(b), N, relu, rows_per_image=rows)))
+    # other companions, another position, another image count: the same bits
+    perm = [imgs - 1, 0] + list(range(1, imgs - 1)) + [0]
+    a2 = np.concatenate([a[p * rows:(p + 1) * rows] for p in perm])
+    got2 = host(ops.dense_h2(dev(a2), img, dev(b), N, relu, rows_per_image=rows))
+    assert np.array_equal(got2[rows:2 * rows], got[:rows]) and np.array_equal(got2[:rows], got[(imgs - 1) * rows:])
+    assert np.array_equal(got2[-rows:], got[:rows])
+
+
+def test_batched_form_two_sources_and_deferred_bias(ops):
+    """the local fold2/conv1 ([point 512 | feat 1536 zero-padded] . W, per-image scales of both sources) and the global
+    fold2/conv2 (relu(pre + bias[image]) . W) of an eight-step call"""
+    imgs, rows = 8, 2048
+    M = imgs * rows
+    a, w, b = case(M, 2048, 512, 901)
+    a1, a2 = np.ascontiguousarray(a[:, :512]), np.ascontiguousarray(a[:, 512:]) * 4.0
+    a2[:, 1472:] = 0
+    ref = _ref(np.concatenate([a1, a2], axis=1), w, b, True)
+    got = host(ops.dense_h2(dev(a1), ops.pack_dense_h2(dev(w)), dev(b), 512, True, a2=dev(a2), rows_per_image=rows))
+    sc = float(np.abs(ref).max())
+    print("batched two sources: max err %.3g of scale %.3g" % (np.abs(got - ref).max(), sc))
+    assert np.abs(got - ref).max() <= 2e-6 * sc
+    pre, w, b = case(M, 512, 256, 902, positive=False)
+    ib = (np.random.default_rng(903).standard_normal((imgs, 512)) * 0.7).astype(np.float32)
+    ref = _ref(pre, w, b, True, in_bias=ib, rows=rows)
+    got = host(ops.dense_h2(dev(pre), ops.pack_dense_h2(dev(w)), dev(b), 256, True, in_bias=dev(ib), rows_per_image=rows))
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_per_image_scales_below_the_batched_threshold(ops):
+    """three images (or rows not a multiple of 128): the four-k-wave tiles with per-image scales -- every image bit for
+    bit what it gets alone"""
+    rows, K, N = 192, 256, 512
+    a, w, b = case(3 * rows, K, N, 77)
+    a[rows:2 * rows] *= 8.0
+    img = ops.pack_dense_h2(dev(w))
+    got = host(ops.dense_h2(dev(a), img, dev(b), N, True, rows_per_image=rows))
+    for i in range(3):
+        one = host(ops.dense_h2(dev(a[i * rows:(i + 1) * rows]), img, dev(b), N, True))
+        assert np.array_equal(got[i * rows:(i + 1) * rows], one), i

@@ -471,7 +471,7 @@ def _pipeline_jobs(njobs, npts, seed0=60):
     jobs = []
     for k in range(njobs):
         d = O.synth_inputs(seed0 + k, 1, npts)
-        d["imgs"] *= np.float32(0.25 + 0.25 * k)          # different brightness: different activation maxima
+        d["imgs"] *= np.float32(0.25 + 0.25 * (k % 4))    # different brightness (pixels stay in [0, 1]): different activation maxima
         jobs.append((torch.from_numpy(d["imgs"]).cuda(), torch.from_numpy(d["sample_pc"]).cuda(),
                      torch.from_numpy(d["trans_mat"]).cuda()))
     return jobs
