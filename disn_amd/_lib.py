@@ -98,7 +98,7 @@ SIGNATURES = {
     "disn_pack_dense_h2_bytes": (Z, [I, I]),
     "disn_pack_dense_h2": (I, [P, I, I, P, P]),
     "disn_dense_h2_workspace_bytes": (Z, [I]),
-    "disn_dense_h2": (I, [P, I, I, P, I, I, P, I, I, P, P, I, I, P, P, P, Z, P]),
+    "disn_dense_h2": (I, [P, I, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, P, P, Z, P]),
     "disn_get_loss": (I, [P, P, L, F, F, P, P]),
     "disn_fc_t": (I, [P, I, I, P, P, I, I, P, P]),
     "disn_dense_workspace_bytes": (Z, [I, I, I]),

@@ -254,6 +254,42 @@ int mlp_phase1_h2(const disn_mlp_weights_t* w, int n, const float* feat, int fea
   return 0;
 }
 
+// The local fold2/conv1 of a BATCHED call (>= kConvWideMinImages images, dense_h2w.hip) in two K ranges of the one packed
+// matrix l_d4 (rows: 512 point features | 1472 feature columns | 64 zero rows):
+//   part A -- [h512a | feat columns 0..895] . W[0..1408): everything whose inputs exist once conv4_3 is done (the gather
+//             of taps 0..3 = feature columns 0..959 runs behind conv4_3, under conv5): no bias, no ReLU -> pre;
+//   part B -- feat columns 896..1535 (the rest of tap 3, tap 4, the zero padding) . W[1408..2048) + pre + bias, ReLU:
+//             the only part of the layer behind conv5_3 (640 of 2048 columns), then fold2/conv2.
+// Operand scales: an image's maxima of h512a, of the early gather's columns and of the late gather's columns (the
+// per-workgroup entries both gathers leave in the slot set's tail); part B's scale takes both gathers' maxima (its
+// first 64 columns come from the early one).
+constexpr int kFeatSplit = 896;      // feature columns of part A (512 + 896 = 1408 = 11 x 128)
+constexpr int kFeatMaxSlotB = 800;   // entries of the late gather: floats 800 .. 1023 of a set (the early one's: 576 .. 799)
+
+int mlp_l4a_h2(const disn_mlp_weights_t* w, int n, const float* feat, int feat_ld, const MlpWs& s, int imgs, hipStream_t st) {
+  float* A = h2_slots(s, 0);
+  DenseH2Prob p = h2_prob(s.h512a, 512 + kFeatSplit, w->l_d4, s.zero512, 512, 0, A + 320, s.h512b, nullptr, n);
+  p.lda = 512; p.k1 = 512; p.a2 = feat; p.lda2 = feat_ld; p.Kimg = 2048; p.k_begin = 0;
+  p.in_amax2 = A + kFeatMaxSlot; p.in_amax2_n = project_gather_taps_amax_blocks(n, feat_ld, 0, 4);
+  p = h2_batched(p, imgs, n);
+  DISN_TRY(dense_h2_launch(&p, 1, st));
+  return 0;
+}
+
+int mlp_l4b_l5_h2(const disn_mlp_weights_t* w, int n, const float* feat, int feat_ld, const MlpWs& s, int imgs, hipStream_t st) {
+  float* A = h2_slots(s, 0);
+  const int KB = feat_ld - kFeatSplit;   // 640
+  DenseH2Prob p = h2_prob(feat + kFeatSplit, KB, w->l_d4, w->l_b4, 512, 1, A + kFeatMaxSlot, s.h512b, A + 512, n);
+  p.lda = feat_ld; p.Kimg = 2048; p.k_begin = 512 + kFeatSplit; p.add_in = s.h512b;
+  p.in_amax_n = project_gather_taps_amax_blocks(n, feat_ld, 0, 4);
+  p.in_amax2 = A + kFeatMaxSlotB; p.in_amax2_n = project_gather_taps_amax_blocks(n, feat_ld, 4, 5);
+  p = h2_batched(p, imgs, n);
+  DISN_TRY(dense_h2_launch(&p, 1, st));
+  const DenseH2Prob p5 = h2_batched(h2_prob(s.h512b, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5, nullptr, n), imgs, n);
+  DISN_TRY(dense_h2_launch(&p5, 1, st));
+  return 0;
+}
+
 // global fold2/conv2 on relu(pre + the image's bias row): the deferred bias + ReLU
 int mlp_g5_h2(const disn_mlp_weights_t* w, int n, const float* pre, const float* gbias_b, const MlpWs& s, int b, size_t o,
               int imgs, hipStream_t st) {
@@ -650,7 +686,9 @@ int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* re
 // (models/CNN/vgg.py:198-214; dropout inactive: is_training=False, model_normalization.py:76)
 int fc_layer(const float* x, int B, int K, const float* w_kn, const float* wt_nk, const float* bias, int N, int relu,
              float* out, float* ws, hipStream_t st) {
-  if (wt_nk) DISN_TRY(gemv_rows_launch(x, B, K, wt_nk, bias, N, relu, out, st));
+  // the one-launch row form re-reads x (B x K floats) once per wave: right for one to three rows (launch-latency bound
+  // layers), 4x the weight bytes in L2 traffic at eight -- a batched call takes the split-K stream kernel for every layer
+  if (wt_nk && B < kConvWideMinImages) DISN_TRY(gemv_rows_launch(x, B, K, wt_nk, bias, N, relu, out, st));
   else DISN_TRY(gemv_launch(x, B, K, w_kn, bias, N, relu, out, ws, st));
   return 0;
 }
@@ -852,6 +890,9 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   const bool h2 = two && B <= kH2Imgs && mlp_h2(mw, N);   // small point sets: the dense_h2 layers, image by image
   const int feat_ld = h2 && !featmap ? kFeatPad : DISN_FEAT_DIM;
   const int hb = h2 && N % 64 == 0 ? B : 1;   // images per h2 launch
+  // a batched call (the form of conv_h2w.hip / dense_h2w.hip): the local fold2/conv1 in two K ranges, the first one and
+  // the gather of taps 0..3 behind conv4_3 (see mlp_l4a_h2)
+  const bool split_l4 = h2 && hb == B && B >= tune::conv_wide_min && N % 128 == 0 && !featmap && feat_ld == kFeatPad;
   if (two) {
     DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (orders aux behind the caller's inputs)
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
@@ -872,15 +913,32 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
       if ((rc = mlp_g4_pre(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws2, ctx->aux))) return rc;
     }
     DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
-    rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 2, 13);
+    if (split_l4) {
+      // conv2_1 .. conv4_3, then -- on the auxiliary stream, under conv5 -- the gather of taps 0..3 (feature columns
+      // 0..959; its per-workgroup maxima into the slot set's tail, cleared by pt_embed on that stream) and part A of
+      // the local fold2/conv1
+      rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 2, 10);
+      if (rc) return rc;
+      DISN_TRY(hipEventRecord(ctx->ev[5], st));
+      DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[5], 0));
+      DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 4, e.q.feat, ctx->aux, feat_ld,
+                                          h2_slots(e.q.mlp, 0) + kFeatMaxSlot, 1024));
+      if ((rc = mlp_l4a_h2(mw, N, e.q.feat, feat_ld, e.q.mlp, B, ctx->aux))) return rc;
+      rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 10, 13);
+    } else {
+      rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 2, 13);
+    }
     if (rc) return rc;
     // the gather from the taps on the caller's stream, BEFORE the fc head: alone it takes 14 us, under fc6's HBM
     // stream 65-70 us (r02q trace) -- and the local fold2 layers behind it are the critical path of the tail
     // The kernel also leaves max |feat| per image in the slots the local fold2/conv1 reads its scale from (cleared
     // by pt_embed on the auxiliary stream, hence the ev[8] wait first -- recorded a whole convolution stack ago).
     gather_on_st = h2 && !featmap;
-    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));
-    if (gather_on_st)
+    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));   // (recorded behind g4_pre: not behind part A of a batched call)
+    if (split_l4)   // tap 4 only (feature columns 960..1471 + the zero padding): the slot set's entries 800.. are its own
+      DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 4, 5, e.q.feat, st, feat_ld,
+                                          h2_slots(e.q.mlp, 0) + kFeatMaxSlotB, 1024));
+    else if (gather_on_st)
       DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, st, feat_ld,
                                           h2_slots(e.q.mlp, 0) + kFeatMaxSlot, 1024));
     if (ctx->pipe_record) DISN_TRY(hipEventRecord(ctx->pipe_record, st));  // the next step's convolutions may start
@@ -904,7 +962,9 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   } else {  // no map: up-sample the taps at the touched pixels (bit-identical), all images in one launch
     DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, ms, feat_ld));
   }
-  if (h2) {
+  if (split_l4) {
+    if ((rc = mlp_l4b_l5_h2(mw, N, e.q.feat, feat_ld, e.q.mlp, B, ms))) return rc;
+  } else if (h2) {
     for (int b = 0; b < B; b += hb) {
       const size_t o = (size_t)b * N;
       if ((rc = mlp_phase1_h2(mw, N, e.q.feat + o * feat_ld, feat_ld, e.q.mlp, b, o, hb, ms, gather_on_st))) return rc;

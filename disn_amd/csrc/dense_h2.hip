@@ -258,6 +258,8 @@ hipError_t dense_h2_launch(const DenseH2Prob* probs, int nprob, hipStream_t st) 
     for (int i = 0; i < nprob; ++i) ok = ok && dense_h2w_supported(d.p[i]) && d.p[i].amax_rows == p.amax_rows;
     if (ok) return dense_h2w_go(d, st);
   }
+  for (int i = 0; i < nprob; ++i)
+    if (d.p[i].k_begin || d.p[i].add_in || d.p[i].in_amax_n) return hipErrorInvalidValue;  // the batched form's extras
   // Tile rows BM = 32 MB.  Neither the tile shape nor the chunk width changes a result bit (a k-wave adds its k16
   // blocks in ascending order and the four partial tiles are summed in one fixed order whatever the tiling):
   //   64 rows when that gives ~200 workgroups, else 32 (a single image's 2048 rows: latency-bound); 128 rows
@@ -317,12 +319,13 @@ int disn_pack_dense_h2(const float* w_kn, int K, int N, void* image, void* strea
 size_t disn_dense_h2_workspace_bytes(int images) { return (size_t)(images > 0 ? images : 1) * 1024; }
 
 int disn_dense_h2(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, const float* in_bias, int M,
-                  int rows_per_image, const void* image, const float* bias, int N, int relu, float* out, float* out_amax,
-                  void* ws, size_t ws_bytes, void* stream) {
+                  int rows_per_image, const void* image, int image_k, int k_begin, const float* add_in, const float* bias,
+                  int N, int relu, float* out, float* out_amax, void* ws, size_t ws_bytes, void* stream) {
   if (!a1 || !image || !bias || !out || !ws || M <= 0 || k1 <= 0 || k2 < 0 || (k2 > 0 && !a2) || rows_per_image < 0)
     return DISN_E_ARG;
   const int K = k1 + k2;
   if (!disn::dense_h2_supported(M, K, N, k1) || lda1 != k1 || (k2 > 0 && lda2 != k2)) return DISN_E_SHAPE;
+  if (image_k < 0 || k_begin < 0 || k_begin % 16 || (image_k > 0 && k_begin + K > image_k) || (image_k == 0 && k_begin)) return DISN_E_SHAPE;
   if (rows_per_image > 0 && (M % rows_per_image || rows_per_image % 64)) return DISN_E_SHAPE;
   const int imgs = rows_per_image > 0 ? M / rows_per_image : 1;
   const size_t rows = rows_per_image > 0 ? rows_per_image : M;
@@ -338,11 +341,13 @@ int disn_dense_h2(const float* a1, int lda1, int k1, const float* a2, int lda2, 
   p.a = a1; p.lda = lda1; p.k1 = k1; p.a2 = k2 > 0 ? a2 : nullptr; p.lda2 = lda2; p.in_bias = in_bias;
   p.wimg = static_cast<const unsigned char*>(image); p.bias = bias; p.in_amax = s1; p.in_amax2 = k2 > 0 ? s1 + 64 : nullptr;
   p.out = out; p.ldc = N; p.out_amax = out_amax ? s1 + 128 : nullptr; p.M = M; p.N = N; p.K = K; p.relu = relu;
+  p.Kimg = image_k; p.k_begin = k_begin; p.add_in = add_in;
   if (rows_per_image > 0) {
     p.amax_rows = rows_per_image; p.amax_stride = 256;
     if (in_bias) p.in_bias_rows = rows_per_image;
   }
   e = disn::dense_h2_launch(&p, 1, st);
+  if (e == hipErrorInvalidValue) return DISN_E_SHAPE;   // k_begin / add_in outside the batched form
   if (e == hipSuccess && out_amax) e = disn::amax_fold_launch(s1 + 128, out_amax, st, 64, imgs, 256);
   return e == hipSuccess ? 0 : (int)e;
 }

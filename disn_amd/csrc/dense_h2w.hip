@@ -109,7 +109,11 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dense_h2w_kernel(const Dens
   const int Kimg = P.Kimg > 0 ? P.Kimg : K;
   const float* meta = reinterpret_cast<const float*>(P.wimg + (size_t)Kimg * N * 4);
   const size_t aoff = P.amax_rows > 0 ? (size_t)(m0 / P.amax_rows) * P.amax_stride : 0;  // this tile's image
-  float amax_lane = P.in_amax[aoff + lane];
+  float amax_lane = 0.f;
+  {
+    const int n1 = P.in_amax_n > 0 ? P.in_amax_n : 64;
+    for (int i = lane; i < n1; i += 64) amax_lane = fmaxf(amax_lane, P.in_amax[aoff + i]);
+  }
   if (P.in_amax2) {
     const int n2 = P.in_amax2_n > 0 ? P.in_amax2_n : 64;
     for (int i = lane; i < n2; i += 64) amax_lane = fmaxf(amax_lane, P.in_amax2[aoff + i]);
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dense_h2w_kernel(const Dens
   // (slot kb % DQ): a pair is replaced by the one DQ blocks ahead as soon as its last MFMA is issued
   constexpr int DQ = 4;
   static_assert(KC % DQ == 0, "queue depth");
-  const unsigned char* wp = P.wimg + ((size_t)(n0 >> 5) * (Kimg >> 4)) * 2048 + lane * 16;
+  const unsigned char* wp = P.wimg + ((size_t)(n0 >> 5) * (Kimg >> 4) + (P.k_begin >> 4)) * 2048 + lane * 16;
   ch_h8 qh[DQ], ql[DQ];
 #pragma unroll
   for (int t = 0; t < DQ; ++t) {
@@ -226,6 +230,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dense_h2w_kernel(const Dens
   // ---- epilogue: bias, ReLU, row-major store (32 lanes = 128 contiguous bytes of a row), maximum of |out| ----------
   const float bias_j = P.bias[n0 + j];
   float* outb = P.out + (size_t)m0 * P.ldc + n0 + j;
+  const float* addb = P.add_in ? P.add_in + (size_t)m0 * P.ldc + n0 + j : nullptr;
   float vmax = 0.f;
   const bool full = m0 + BM <= M;
 #pragma unroll
@@ -235,9 +240,11 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dense_h2w_kernel(const Dens
       const int r0 = mb * 32 + ch2::quad_row(q, g);   // four consecutive rows
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        const bool live = full || m0 + r0 + e < M;
         float v = fmaf(acc[mb][4 * q + e], descale, bias_j);
+        if (addb && live) v += addb[(r0 + e) * P.ldc];
         if (P.relu) v = fmaxf(v, 0.f);
-        if (full || m0 + r0 + e < M) {
+        if (live) {
           outb[(r0 + e) * P.ldc] = v;
           vmax = fmaxf(vmax, fabsf(v));
         }
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dense_h2w_kernel(const Dens
 }
 
 bool dense_h2w_supported(const DenseH2Prob& p) {
-  return p.M >= 128 && p.N % 256 == 0 && p.K % 128 == 0 && (p.k1 == p.K || p.k1 % 128 == 0) &&
+  return p.M >= 128 && p.N % 256 == 0 && p.K % 128 == 0 && (p.k1 == p.K || p.k1 % 128 == 0) && p.k_begin % 16 == 0 &&
          (p.amax_rows == 0 || p.amax_rows % 128 == 0) && (size_t)p.M * (p.ldc > p.lda ? p.ldc : p.lda) < ((size_t)1 << 31);
 }
 

@@ -402,11 +402,18 @@ __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
   }
 }
 
-// workgroups per image of the launch with maxima (1024 threads each) -- the count of entries the consumer reads
-int project_gather_taps_amax_blocks(int n, int feat_ld) {
-  const size_t per_img = (size_t)n * (feat_ld > DISN_FEAT ? feat_ld / 4 : DISN_FEAT4);
+// workgroups per image of the launch with maxima (1024 threads each) -- the count of entries the consumer reads.
+// All five taps: up to 448 entries (the free tail of an image's slot set, api.hip); a tap RANGE (the two gathers of a
+// batched call: taps 0..3 behind conv4_3, tap 4 behind conv5_3): up to 224, the two launches' entries side by side.
+static int gather_c4_count(int tap_begin, int tap_end, int feat_ld) {
+  static const int c4_off[6] = {0, 16, 48, 112, 240, DISN_FEAT4};
+  return (tap_end == 5 && feat_ld > DISN_FEAT ? feat_ld / 4 : c4_off[tap_end]) - c4_off[tap_begin];
+}
+int project_gather_taps_amax_blocks(int n, int feat_ld, int tap_begin, int tap_end) {
+  const size_t per_img = (size_t)n * gather_c4_count(tap_begin, tap_end, feat_ld > 0 ? feat_ld : DISN_FEAT);
   const size_t g = (per_img + 1023) / 1024;
-  return (int)(g < 1 ? 1 : (g > 448 ? 448 : g));
+  const size_t cap = tap_begin == 0 && tap_end == 5 ? 448 : 224;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
 hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
@@ -426,8 +433,7 @@ hipError_t project_gather_taps_launch(const float* const taps[5], const float* t
   const int c4_count = (tap_end == 5 && feat_ld > DISN_FEAT ? feat_ld / 4 : c4_off[tap_end]) - c4_begin;
   const size_t total = (size_t)B * n * c4_count;
   if (amax) {
-    if (tap_begin != 0 || tap_end != 5) return hipErrorInvalidValue;
-    const int G = project_gather_taps_amax_blocks(n, feat_ld);
+    const int G = project_gather_taps_amax_blocks(n, feat_ld, tap_begin, tap_end);
     hipLaunchKernelGGL(project_gather_taps_kernel, dim3((unsigned)(B * G)), dim3(1024), 0, st, t, trans_mat, pts, B, n,
                        c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
     return hipGetLastError();

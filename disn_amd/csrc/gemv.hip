@@ -139,9 +139,14 @@ hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, co
   return hipSuccess;
 }
 
-int gemv_splits(int K, int N) {
+// K splits.  One to three batch rows (a step at a time): 2048 workgroups = every wave slot of the chip, what a lone
+// latency-bound stream wants (r01).  Four rows and more (a batched call): 512 -- each workgroup already carries B
+// accumulator sets, the partial slabs (S x B x N floats written and re-read) shrink 4x and the reduce pass with them
+// (fc6 of an eight-step call: 16.8 MB of partials, a 45 us reduce).  By the batch size only: the summation order of a
+// row never depends on the other rows' data.
+int gemv_splits(int K, int N, int B) {
   const int colblocks = N / 256;
-  const int wgs = tune::gemv_wgs > 0 ? tune::gemv_wgs : 2048;
+  const int wgs = tune::gemv_wgs > 0 ? tune::gemv_wgs : (B >= kConvWideMinImages ? 512 : 2048);
   int s = (wgs + colblocks - 1) / colblocks;
   const int smax = K / 32 > 0 ? K / 32 : 1;
   if (s > smax) s = smax;
@@ -150,12 +155,12 @@ int gemv_splits(int K, int N) {
 }
 
 size_t gemv_ws_bytes(int B, int K, int N) {
-  return (size_t)gemv_splits(K, N) * B * N * sizeof(float);
+  return (size_t)gemv_splits(K, N, B) * B * N * sizeof(float);
 }
 
 hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const float* bias, int N,
                        int relu, float* out, float* ws, hipStream_t st) {
-  const int S = gemv_splits(K, N);
+  const int S = gemv_splits(K, N, B);
   dim3 grid(N / 256, S);
   for (int b0 = 0; b0 < B; b0 += 8) {
     const int nb = (B - b0) < 8 ? (B - b0) : 8;

@@ -99,7 +99,7 @@ hipError_t gemm_bf16_launch(const GemmParams& p, GemmMode mode, const void* bpk,
                             bool* pooled = nullptr);
 
 // ---- gemv.hip ------------------------------------------------------------
-int gemv_splits(int K, int N);
+int gemv_splits(int K, int N, int B = 1);
 size_t gemv_ws_bytes(int B, int K, int N);
 // out[b][n] = act(sum_k x[b][k] W[k][n] + bias[n]); N % 256 == 0
 hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const float* bias, int N,
@@ -131,7 +131,7 @@ hipError_t project_gather_taps_launch(const float* const taps[5], const float* t
                                       float* feat, hipStream_t st, int feat_ld = 0, float* amax = nullptr,
                                       size_t amax_stride = 0);
 // amax != nullptr (all five taps): max |feat| per workgroup at amax[b * amax_stride + (0 .. blocks - 1)]
-int project_gather_taps_amax_blocks(int n, int feat_ld);  // feat_ld > 1472: zero-padded rows
+int project_gather_taps_amax_blocks(int n, int feat_ld, int tap_begin = 0, int tap_end = 5);  // feat_ld > 1472: zero-padded rows
 // folded local fold2/conv1 (disn_fold_local): h = relu(pre + resample(pmap_b)(pts) + bias), [n,512]
 hipError_t gather_fold_launch(const float* pmap_b, const float* trans_mat_b, const float* pts, int n,
                               const float* pre, const float* bias, float* h, hipStream_t st);
@@ -301,7 +301,10 @@ struct DenseH2Prob {     // out[M][N] = act(f(A) . W + bias), A = [a (k1 columns
   float* out_amax;       // 64 slots (zeroed by the caller) or nullptr
   int M, N, K, relu;
   int amax_rows;         // > 0: rows per image (a multiple of 64): the maxima of the tile's image are read / written at
-  int amax_stride;       //      in_amax / in_amax2 / out_amax + image * amax_stride
+  int amax_stride;       //      in_amax / in_amax2 / out_amax + image * amax_stride  // dense_h2w.hip only (dense_h2_launch rejects them for the four-k-wave tiles):
+  int k_begin;           // first row of the packed matrix this product uses (a multiple of 16): W[k_begin .. k_begin + K)
+  const float* add_in;   // [M][ldc] addend (a partial product formed earlier) or nullptr: out = act(A . W + bias + add_in); may alias out
+  int in_amax_n;         // > 0: in_amax has this many entries instead of 64
 };
 struct DenseH2Dev {
   DenseH2Prob p[2];

@@ -183,20 +183,23 @@ def pack_dense_h2(w_kn: torch.Tensor) -> torch.Tensor:
 
 def dense_h2(a1: torch.Tensor, image: torch.Tensor, bias: torch.Tensor, n_out: int, relu: bool = True,
              a2: Optional[torch.Tensor] = None, in_bias: Optional[torch.Tensor] = None, want_amax: bool = False,
-             rows_per_image: int = 0):
+             rows_per_image: int = 0, image_k: int = 0, k_begin: int = 0, add_in: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None):
     """disn_dense_h2: act(f([a1 | a2]) @ W + b), f = relu(. + in_bias) when in_bias is given.  rows_per_image > 0:
     rows image-major, one activation scale per image, in_bias [images, K]; four images and more (of a multiple of
     128 rows each) run the batched form (dense_h2w.hip)"""
     a1 = _chk(a1, "a1")
     M, k1 = a1.shape
     k2 = 0 if a2 is None else _chk(a2, "a2").shape[1]
-    out = torch.empty((M, n_out), dtype=torch.float32, device=a1.device)
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float32, device=a1.device)
     amax = torch.zeros(1, dtype=torch.float32, device=a1.device) if want_amax else None
     imgs = M // rows_per_image if rows_per_image > 0 else 1
     ws = _ws(lib().disn_dense_h2_workspace_bytes(imgs), a1.device)
     check("disn_dense_h2", lib().disn_dense_h2(
         a1.data_ptr(), k1, k1, a2.data_ptr() if a2 is not None else None, k2, k2,
-        in_bias.data_ptr() if in_bias is not None else None, M, int(rows_per_image), image.data_ptr(), bias.data_ptr(),
+        in_bias.data_ptr() if in_bias is not None else None, M, int(rows_per_image), image.data_ptr(), int(image_k),
+        int(k_begin), add_in.data_ptr() if add_in is not None else None, bias.data_ptr(),
         n_out, int(relu), out.data_ptr(), amax.data_ptr() if want_amax else None, ws.data_ptr(), ws.numel(), _stream()))
     return (out, amax) if want_amax else out
 

@@ -187,13 +187,19 @@ int disn_fc_t(const float* x, int B, int K, const float* wt_nk, const float* bia
  * accumulator in ascending order), everything else the four-k-wave tiles of dense_h2.hip.  The two forms agree to
  * fp32 rounding (both within 2e-6 of the output scale of the float64 product), not bit for bit; which form runs
  * depends on the call's image count and rows per image only, never on the other images' data.
+ * Batched form only (DISN_E_SHAPE otherwise): image_k > K = the image was packed from a matrix of image_k rows and
+ * this product uses its rows k_begin .. k_begin + K (multiples of 16) -- a K range of a layer; add_in [M][N] != NULL =
+ * a partial product formed earlier: out = act([a1 | a2] . W[k_begin..] + bias + add_in), may alias out.  (How
+ * disn_encode_query cuts the 1984-deep local fold2/conv1 into the part whose inputs exist before conv5 and the rest.)
+ * image_k = 0: the image has exactly K rows.
  * ws: disn_dense_h2_workspace_bytes(images). */
 size_t disn_pack_dense_h2_bytes(int K, int N);
 int disn_pack_dense_h2(const float* w_kn, int K, int N, void* image, void* stream);
 size_t disn_dense_h2_workspace_bytes(int images);
 int disn_dense_h2(const float* a1, int lda1, int k1, const float* a2, int lda2, int k2, const float* in_bias, int M,
-                  int rows_per_image, const void* image, const float* bias, int N, int relu, float* out,
-                  float* out_amax, void* ws, size_t ws_bytes, void* stream);
+                  int rows_per_image, const void* image, int image_k, int k_begin, const float* add_in,
+                  const float* bias, int N, int relu, float* out, float* out_amax, void* ws, size_t ws_bytes,
+                  void* stream);
 
 /* Row K: the scalars of get_loss (models/model_normalization.py:273-299, regression branch) in one launch:
  * out5 = {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}; pred [M] = pred_sdf

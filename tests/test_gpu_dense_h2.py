@@ -160,3 +160,30 @@ def test_per_image_scales_below_the_batched_threshold(ops):
     for i in range(3):
         one = host(ops.dense_h2(dev(a[i * rows:(i + 1) * rows]), img, dev(b), N, True))
         assert np.array_equal(got[i * rows:(i + 1) * rows], one), i
+
+
+def test_batched_form_k_range_with_addend_equals_the_layer_in_one_piece(ops):
+    """how disn_encode_query cuts the local fold2/conv1 of a batched call: rows [0, 1408) of the packed matrix on
+    [point | first 896 feature columns] -> pre; rows [1408, 2048) on the remaining 640 columns + pre + bias, ReLU
+    (in place).  Against float64 and against the layer run in one piece (another summation order: fp32 rounding)."""
+    imgs, rows = 4, 256
+    M = imgs * rows
+    a, w, b = case(M, 2048, 512, 1234)
+    a[:, 1984:] = 0
+    point, feat = np.ascontiguousarray(a[:, :512]), np.ascontiguousarray(a[:, 512:])
+    img = ops.pack_dense_h2(dev(w))
+    zero = dev(np.zeros(512, np.float32))
+    pre = ops.dense_h2(dev(point), img, zero, 512, False, a2=dev(np.ascontiguousarray(feat[:, :896])), rows_per_image=rows,
+                       image_k=2048, k_begin=0)
+    out = ops.dense_h2(dev(np.ascontiguousarray(feat[:, 896:])), img, dev(b), 512, True, rows_per_image=rows, image_k=2048,
+                       k_begin=1408, add_in=pre, out=pre)
+    got = host(out)
+    ref = _ref(a, w, b, True)
+    sc = float(np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 2e-6 * sc
+    whole = host(ops.dense_h2(dev(point), img, dev(b), 512, True, a2=dev(feat), rows_per_image=rows))
+    assert np.abs(got - whole).max() <= 2e-6 * sc
+    from disn_amd import _lib
+    with pytest.raises(_lib.DisnError) as e:       # a K range needs the batched form (>= 4 images)
+        ops.dense_h2(dev(feat[:rows, 896:]), img, dev(b), 512, True, image_k=2048, k_begin=1408)
+    assert e.value.status == -2
