@@ -254,39 +254,57 @@ int mlp_phase1_h2(const disn_mlp_weights_t* w, int n, const float* feat, int fea
   return 0;
 }
 
-// The local fold2/conv1 of a BATCHED call (>= kConvWideMinImages images, dense_h2w.hip) in two K ranges of the one packed
-// matrix l_d4 (rows: 512 point features | 1472 feature columns | 64 zero rows):
-//   part A -- [h512a | feat columns 0..895] . W[0..1408): everything whose inputs exist once conv4_3 is done (the gather
-//             of taps 0..3 = feature columns 0..959 runs behind conv4_3, under conv5): no bias, no ReLU -> pre;
-//   part B -- feat columns 896..1535 (the rest of tap 3, tap 4, the zero padding) . W[1408..2048) + pre + bias, ReLU:
-//             the only part of the layer behind conv5_3 (640 of 2048 columns), then fold2/conv2.
-// Operand scales: an image's maxima of h512a, of the early gather's columns and of the late gather's columns (the
-// per-workgroup entries both gathers leave in the slot set's tail); part B's scale takes both gathers' maxima (its
-// first 64 columns come from the early one).
-constexpr int kFeatSplit = 896;      // feature columns of part A (512 + 896 = 1408 = 11 x 128)
-constexpr int kFeatMaxSlotB = 800;   // entries of the late gather: floats 800 .. 1023 of a set (the early one's: 576 .. 799)
+// The local fold2/conv1 of a BATCHED call (>= kConvWideMinImages images, dense_h2w.hip) in three K ranges of the one
+// packed matrix l_d4 (rows: 512 point features | 1472 feature columns | 64 zero rows), each started as soon as its
+// inputs exist -- on the auxiliary stream, under the convolutions still to come:
+//   range 0 -- [h512a | feat columns 0..383]   . W[0..896)     behind conv3_3 (gather of taps 0..2 = columns 0..447);
+//   range 1 -- feat columns 384..895           . W[896..1408)  behind conv4_3 (gather of tap 3 = columns 448..959);
+//   range 2 -- feat columns 896..1535          . W[1408..2048) behind conv5_3 (gather of tap 4 + the zero padding),
+//              + bias, ReLU, then fold2/conv2.
+// Ranges 0 and 1 leave / add to the fp32 partial product `pre` (no bias, no ReLU); 640 of the 2048 columns are all
+// that is left behind conv5_3.  Operand scales: an image's maxima of h512a and of each gather's columns (the
+// per-workgroup entries the three gathers leave in the slot set's tail, kGatherSlots apart); a range that reads
+// columns of two gathers takes both maxima.
+constexpr int kL4Cut[4] = {0, 384, 896, 1536};       // feature-column cuts of the three ranges (512 + 384 = 7 x 128 ...)
+constexpr int kGatherTapCut[4] = {0, 3, 4, 5};       // taps of the three gathers
+constexpr int kGatherSlots = 144;                    // entries per gather: floats 576 + 144 r .. of a slot set
 
-int mlp_l4a_h2(const disn_mlp_weights_t* w, int n, const float* feat, int feat_ld, const MlpWs& s, int imgs, hipStream_t st) {
-  float* A = h2_slots(s, 0);
-  DenseH2Prob p = h2_prob(s.h512a, 512 + kFeatSplit, w->l_d4, s.zero512, 512, 0, A + 320, s.h512b, nullptr, n);
-  p.lda = 512; p.k1 = 512; p.a2 = feat; p.lda2 = feat_ld; p.Kimg = 2048; p.k_begin = 0;
-  p.in_amax2 = A + kFeatMaxSlot; p.in_amax2_n = project_gather_taps_amax_blocks(n, feat_ld, 0, 4);
-  p = h2_batched(p, imgs, n);
-  DISN_TRY(dense_h2_launch(&p, 1, st));
+int gather_entries(int n, int feat_ld, int r) {
+  const int g = project_gather_taps_amax_blocks(n, feat_ld, kGatherTapCut[r], kGatherTapCut[r + 1]);
+  return g < kGatherSlots ? g : kGatherSlots;
+}
+
+int mlp_l4_gather(float* const taps[5], const float* trans_mat, const float* pts, int B, int n, float* feat, int feat_ld,
+                  const MlpWs& s, int r, hipStream_t st) {
+  DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, n, kGatherTapCut[r], kGatherTapCut[r + 1], feat, st, feat_ld,
+                                      h2_slots(s, 0) + kFeatMaxSlot + kGatherSlots * r, 1024, kGatherSlots));
   return 0;
 }
 
-int mlp_l4b_l5_h2(const disn_mlp_weights_t* w, int n, const float* feat, int feat_ld, const MlpWs& s, int imgs, hipStream_t st) {
+int mlp_l4_range_h2(const disn_mlp_weights_t* w, int n, const float* feat, int feat_ld, const MlpWs& s, int imgs, int r,
+                    hipStream_t st) {
   float* A = h2_slots(s, 0);
-  const int KB = feat_ld - kFeatSplit;   // 640
-  DenseH2Prob p = h2_prob(feat + kFeatSplit, KB, w->l_d4, w->l_b4, 512, 1, A + kFeatMaxSlot, s.h512b, A + 512, n);
-  p.lda = feat_ld; p.Kimg = 2048; p.k_begin = 512 + kFeatSplit; p.add_in = s.h512b;
-  p.in_amax_n = project_gather_taps_amax_blocks(n, feat_ld, 0, 4);
-  p.in_amax2 = A + kFeatMaxSlotB; p.in_amax2_n = project_gather_taps_amax_blocks(n, feat_ld, 4, 5);
+  const int kf = kL4Cut[r + 1] - kL4Cut[r];          // feature columns of this range
+  const bool last = r == 2;
+  DenseH2Prob p{};
+  if (r == 0) {
+    p = h2_prob(s.h512a, 512 + kf, w->l_d4, s.zero512, 512, 0, A + 320, s.h512b, nullptr, n);
+    p.lda = 512; p.k1 = 512; p.a2 = feat; p.lda2 = feat_ld;
+    p.in_amax2 = A + kFeatMaxSlot; p.in_amax2_n = gather_entries(n, feat_ld, 0);
+  } else {
+    p = h2_prob(feat + kL4Cut[r], kf, w->l_d4, last ? w->l_b4 : s.zero512, 512, last ? 1 : 0,
+                A + kFeatMaxSlot + kGatherSlots * (r - 1), s.h512b, last ? A + 512 : nullptr, n);
+    p.lda = feat_ld; p.add_in = s.h512b; p.k_begin = 512 + kL4Cut[r];
+    p.in_amax_n = gather_entries(n, feat_ld, r - 1);
+    p.in_amax2 = A + kFeatMaxSlot + kGatherSlots * r; p.in_amax2_n = gather_entries(n, feat_ld, r);
+  }
+  p.Kimg = 2048;
   p = h2_batched(p, imgs, n);
   DISN_TRY(dense_h2_launch(&p, 1, st));
-  const DenseH2Prob p5 = h2_batched(h2_prob(s.h512b, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5, nullptr, n), imgs, n);
-  DISN_TRY(dense_h2_launch(&p5, 1, st));
+  if (last) {
+    const DenseH2Prob p5 = h2_batched(h2_prob(s.h512b, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5, nullptr, n), imgs, n);
+    DISN_TRY(dense_h2_launch(&p5, 1, st));
+  }
   return 0;
 }
 
@@ -891,7 +909,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   const int feat_ld = h2 && !featmap ? kFeatPad : DISN_FEAT_DIM;
   const int hb = h2 && N % 64 == 0 ? B : 1;   // images per h2 launch
   // a batched call (the form of conv_h2w.hip / dense_h2w.hip): the local fold2/conv1 in two K ranges, the first one and
-  // the gather of taps 0..3 behind conv4_3 (see mlp_l4a_h2)
+  // ranges and the taps' gathers started behind conv3_3 / conv4_3 / conv5_3 (see mlp_l4_range_h2)
   const bool split_l4 = h2 && hb == B && B >= tune::conv_wide_min && N % 128 == 0 && !featmap && feat_ld == kFeatPad;
   if (two) {
     DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (orders aux behind the caller's inputs)
@@ -914,17 +932,20 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     }
     DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
     if (split_l4) {
-      // conv2_1 .. conv4_3, then -- on the auxiliary stream, under conv5 -- the gather of taps 0..3 (feature columns
-      // 0..959; its per-workgroup maxima into the slot set's tail, cleared by pt_embed on that stream) and part A of
-      // the local fold2/conv1
-      rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 2, 10);
-      if (rc) return rc;
-      DISN_TRY(hipEventRecord(ctx->ev[5], st));
-      DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[5], 0));
-      DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 4, e.q.feat, ctx->aux, feat_ld,
-                                          h2_slots(e.q.mlp, 0) + kFeatMaxSlot, 1024));
-      if ((rc = mlp_l4a_h2(mw, N, e.q.feat, feat_ld, e.q.mlp, B, ctx->aux))) return rc;
-      rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 10, 13);
+      // the convolutions in three legs; behind each leg the auxiliary stream gathers the taps that leg finished and
+      // runs the matching K range of the local fold2/conv1 (mlp_l4_range_h2) under the next leg
+      static const int leg_end[3] = {7, 10, 13};   // conv3_3, conv4_3, conv5_3 done
+      static const int leg_ev[3] = {5, 9, 7};
+      int i0 = 2;
+      for (int r = 0; r < 3; ++r) {
+        rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, i0, leg_end[r]);
+        if (rc) return rc;
+        i0 = leg_end[r];
+        DISN_TRY(hipEventRecord(ctx->ev[leg_ev[r]], st));
+        DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[leg_ev[r]], 0));
+        if ((rc = mlp_l4_gather(taps, trans_mat, pts, B, N, e.q.feat, feat_ld, e.q.mlp, r, ctx->aux))) return rc;
+        if ((rc = mlp_l4_range_h2(mw, N, e.q.feat, feat_ld, e.q.mlp, B, r, ctx->aux))) return rc;
+      }
     } else {
       rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 2, 13);
     }
@@ -933,17 +954,16 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     // stream 65-70 us (r02q trace) -- and the local fold2 layers behind it are the critical path of the tail
     // The kernel also leaves max |feat| per image in the slots the local fold2/conv1 reads its scale from (cleared
     // by pt_embed on the auxiliary stream, hence the ev[8] wait first -- recorded a whole convolution stack ago).
-    gather_on_st = h2 && !featmap;
-    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));   // (recorded behind g4_pre: not behind part A of a batched call)
-    if (split_l4)   // tap 4 only (feature columns 960..1471 + the zero padding): the slot set's entries 800.. are its own
-      DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 4, 5, e.q.feat, st, feat_ld,
-                                          h2_slots(e.q.mlp, 0) + kFeatMaxSlotB, 1024));
-    else if (gather_on_st)
+    gather_on_st = h2 && !featmap && !split_l4;
+    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));   // (recorded behind g4_pre, a whole convolution stack ago)
+    if (gather_on_st)
       DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, st, feat_ld,
                                           h2_slots(e.q.mlp, 0) + kFeatMaxSlot, 1024));
     if (ctx->pipe_record) DISN_TRY(hipEventRecord(ctx->pipe_record, st));  // the next step's convolutions may start
-    DISN_TRY(hipEventRecord(ctx->ev[7], st));
-    DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
+    if (!split_l4) {
+      DISN_TRY(hipEventRecord(ctx->ev[7], st));
+      DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
+    }
     if (!h2 && (rc = mlp_fold1_local(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws, ctx->aux))) return rc;
   } else {
     rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st);
@@ -951,7 +971,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     if ((rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, st))) return rc;
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
-  if (gather_on_st) {
+  if (gather_on_st || split_l4) {
     // done above
   } else if (featmap) {
     const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
@@ -963,7 +983,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, ms, feat_ld));
   }
   if (split_l4) {
-    if ((rc = mlp_l4b_l5_h2(mw, N, e.q.feat, feat_ld, e.q.mlp, B, ms))) return rc;
+    // done above: gathers and the three K ranges are on the auxiliary stream
   } else if (h2) {
     for (int b = 0; b < B; b += hb) {
       const size_t o = (size_t)b * N;

@@ -419,7 +419,7 @@ int project_gather_taps_amax_blocks(int n, int feat_ld, int tap_begin, int tap_e
 hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
                                       const float* pts, int B, int n, int tap_begin, int tap_end,
                                       float* feat, hipStream_t st, int feat_ld, float* amax,
-                                      size_t amax_stride) {
+                                      size_t amax_stride, int amax_cap) {
   static const int c4_off[6] = {0, 16, 48, 112, 240, DISN_FEAT4};
   static const int ch[5] = {64, 128, 256, 512, 512};
   TapSet t;
@@ -433,7 +433,8 @@ hipError_t project_gather_taps_launch(const float* const taps[5], const float* t
   const int c4_count = (tap_end == 5 && feat_ld > DISN_FEAT ? feat_ld / 4 : c4_off[tap_end]) - c4_begin;
   const size_t total = (size_t)B * n * c4_count;
   if (amax) {
-    const int G = project_gather_taps_amax_blocks(n, feat_ld, tap_begin, tap_end);
+    int G = project_gather_taps_amax_blocks(n, feat_ld, tap_begin, tap_end);
+    if (amax_cap > 0 && G > amax_cap) G = amax_cap;   // entries the caller has room for
     hipLaunchKernelGGL(project_gather_taps_kernel, dim3((unsigned)(B * G)), dim3(1024), 0, st, t, trans_mat, pts, B, n,
                        c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
     return hipGetLastError();

@@ -140,13 +140,14 @@ hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, co
 }
 
 // K splits.  One to three batch rows (a step at a time): 2048 workgroups = every wave slot of the chip, what a lone
-// latency-bound stream wants (r01).  Four rows and more (a batched call): 512 -- each workgroup already carries B
-// accumulator sets, the partial slabs (S x B x N floats written and re-read) shrink 4x and the reduce pass with them
+// latency-bound stream wants (r01).  Four rows and more (a batched call): 1024 -- each workgroup already carries B
+// accumulator sets, the partial slabs (S x B x N floats written and re-read) shrink 2x and the reduce pass with them
+// (512: fc6 beside the point-MLP layers of the call's tail 84 -> 191 us, too few waves for its share of HBM; r03e)
 // (fc6 of an eight-step call: 16.8 MB of partials, a 45 us reduce).  By the batch size only: the summation order of a
 // row never depends on the other rows' data.
 int gemv_splits(int K, int N, int B) {
   const int colblocks = N / 256;
-  const int wgs = tune::gemv_wgs > 0 ? tune::gemv_wgs : (B >= kConvWideMinImages ? 512 : 2048);
+  const int wgs = tune::gemv_wgs > 0 ? tune::gemv_wgs : (B >= kConvWideMinImages ? 1024 : 2048);
   int s = (wgs + colblocks - 1) / colblocks;
   const int smax = K / 32 > 0 ? K / 32 : 1;
   if (s > smax) s = smax;

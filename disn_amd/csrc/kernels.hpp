@@ -129,7 +129,7 @@ hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_
 hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
                                       const float* pts, int B, int n, int tap_begin, int tap_end,
                                       float* feat, hipStream_t st, int feat_ld = 0, float* amax = nullptr,
-                                      size_t amax_stride = 0);
+                                      size_t amax_stride = 0, int amax_cap = 0);
 // amax != nullptr (all five taps): max |feat| per workgroup at amax[b * amax_stride + (0 .. blocks - 1)]
 int project_gather_taps_amax_blocks(int n, int feat_ld, int tap_begin = 0, int tap_end = 5);  // feat_ld > 1472: zero-padded rows
 // folded local fold2/conv1 (disn_fold_local): h = relu(pre + resample(pmap_b)(pts) + bias), [n,512]

@@ -367,7 +367,7 @@ def test_bench_contract_on_gpu():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 1e5 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 1e5 and d["dtype"].startswith("f32") and d["vs_baseline"] is None
     assert "workload" in d["config"]
 
 

@@ -6,7 +6,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout 900 python -m pytest tests/test_gpu_dense_h2.py -q --no-header -p no:cacheprovider -x > $OUT/pytest_dense_h2.log 2>&1; echo "dense tests exit $?"; tail -5 $OUT/pytest_dense_h2.log
 timeout 300 python tools/dense_h2w_time.py 2>&1 | grep -v amdgpu.ids | tee $OUT/dense_h2w_time.txt
-timeout 2400 python -m pytest tests -m gpu -q -rA --no-header -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; grep -v "^PASSED" $OUT/pytest_gpu.log | tail -30
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_kernels.py -q --no-header -p no:cacheprovider -s > $OUT/pytest_model.log 2>&1; echo "model tests exit $?"; grep "job \|passed\|failed\|^E " $OUT/pytest_model.log | tail -12
 (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/profb8_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 24 --warmup 8 --no-extras --in-flight 1 --batch 8 --spinup-s 0 > /tmp/profb8_$TAG.log 2>&1; echo "rocprof b8 exit $?")
 python tools/trace_step.py $(find /tmp/profb8_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null | grep -v "at::native\|rocclr_copy" > $OUT/infer_call_b8_trace.txt; cat $OUT/infer_call_b8_trace.txt
 for v in "--steps 20 --warmup 5" "--steps 240 --warmup 24" "--steps 240 --warmup 24 --batch 8 --in-flight 1" "--steps 240 --warmup 24 --batch 16 --in-flight 2"; do
