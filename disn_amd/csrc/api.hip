@@ -265,18 +265,22 @@ int mlp_phase1_h2(const disn_mlp_weights_t* w, int n, const float* feat, int fea
 // that is left behind conv5_3.  Operand scales: an image's maxima of h512a and of each gather's columns (the
 // per-workgroup entries the three gathers leave in the slot set's tail, kGatherSlots apart); a range that reads
 // columns of two gathers takes both maxima.
-constexpr int kL4Cut[4] = {0, 384, 896, 1536};       // feature-column cuts of the three ranges (512 + 384 = 7 x 128 ...)
-constexpr int kGatherTapCut[4] = {0, 3, 4, 5};       // taps of the three gathers
+struct L4Plan { int n; int cut[4]; int tap[4]; int leg_end[3]; };   // n ranges; feature-column cuts; tap cuts; last conv layer + 1 of each leg
+constexpr L4Plan kL4Plan3 = {3, {0, 384, 896, 1536}, {0, 3, 4, 5}, {7, 10, 13}};
+constexpr L4Plan kL4Plan2 = {2, {0, 896, 1536, 0}, {0, 4, 5, 0}, {10, 13, 0}};   // conv4_3 / conv5_3 only (measured beside it, r03)
+inline const L4Plan& l4_plan() { return tune::l4_ranges == 2 ? kL4Plan2 : kL4Plan3; }
 constexpr int kGatherSlots = 144;                    // entries per gather: floats 576 + 144 r .. of a slot set
 
 int gather_entries(int n, int feat_ld, int r) {
-  const int g = project_gather_taps_amax_blocks(n, feat_ld, kGatherTapCut[r], kGatherTapCut[r + 1]);
+  const L4Plan& P = l4_plan();
+  const int g = project_gather_taps_amax_blocks(n, feat_ld, P.tap[r], P.tap[r + 1]);
   return g < kGatherSlots ? g : kGatherSlots;
 }
 
 int mlp_l4_gather(float* const taps[5], const float* trans_mat, const float* pts, int B, int n, float* feat, int feat_ld,
                   const MlpWs& s, int r, hipStream_t st) {
-  DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, n, kGatherTapCut[r], kGatherTapCut[r + 1], feat, st, feat_ld,
+  const L4Plan& P = l4_plan();
+  DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, n, P.tap[r], P.tap[r + 1], feat, st, feat_ld,
                                       h2_slots(s, 0) + kFeatMaxSlot + kGatherSlots * r, 1024, kGatherSlots));
   return 0;
 }
@@ -284,17 +288,18 @@ int mlp_l4_gather(float* const taps[5], const float* trans_mat, const float* pts
 int mlp_l4_range_h2(const disn_mlp_weights_t* w, int n, const float* feat, int feat_ld, const MlpWs& s, int imgs, int r,
                     hipStream_t st) {
   float* A = h2_slots(s, 0);
-  const int kf = kL4Cut[r + 1] - kL4Cut[r];          // feature columns of this range
-  const bool last = r == 2;
+  const L4Plan& P = l4_plan();
+  const int kf = P.cut[r + 1] - P.cut[r];             // feature columns of this range
+  const bool last = r == P.n - 1;
   DenseH2Prob p{};
   if (r == 0) {
     p = h2_prob(s.h512a, 512 + kf, w->l_d4, s.zero512, 512, 0, A + 320, s.h512b, nullptr, n);
     p.lda = 512; p.k1 = 512; p.a2 = feat; p.lda2 = feat_ld;
     p.in_amax2 = A + kFeatMaxSlot; p.in_amax2_n = gather_entries(n, feat_ld, 0);
   } else {
-    p = h2_prob(feat + kL4Cut[r], kf, w->l_d4, last ? w->l_b4 : s.zero512, 512, last ? 1 : 0,
+    p = h2_prob(feat + P.cut[r], kf, w->l_d4, last ? w->l_b4 : s.zero512, 512, last ? 1 : 0,
                 A + kFeatMaxSlot + kGatherSlots * (r - 1), s.h512b, last ? A + 512 : nullptr, n);
-    p.lda = feat_ld; p.add_in = s.h512b; p.k_begin = 512 + kL4Cut[r];
+    p.lda = feat_ld; p.add_in = s.h512b; p.k_begin = 512 + P.cut[r];
     p.in_amax_n = gather_entries(n, feat_ld, r - 1);
     p.in_amax2 = A + kFeatMaxSlot + kGatherSlots * r; p.in_amax2_n = gather_entries(n, feat_ld, r);
   }
@@ -910,7 +915,8 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   const int hb = h2 && N % 64 == 0 ? B : 1;   // images per h2 launch
   // a batched call (the form of conv_h2w.hip / dense_h2w.hip): the local fold2/conv1 in two K ranges, the first one and
   // ranges and the taps' gathers started behind conv3_3 / conv4_3 / conv5_3 (see mlp_l4_range_h2)
-  const bool split_l4 = h2 && hb == B && B >= tune::conv_wide_min && N % 128 == 0 && !featmap && feat_ld == kFeatPad;
+  const bool split_l4 = h2 && hb == B && B >= tune::conv_wide_min && N % 128 == 0 && !featmap && feat_ld == kFeatPad &&
+                        tune::l4_ranges >= 2;
   if (two) {
     DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (orders aux behind the caller's inputs)
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
@@ -934,15 +940,16 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     if (split_l4) {
       // the convolutions in three legs; behind each leg the auxiliary stream gathers the taps that leg finished and
       // runs the matching K range of the local fold2/conv1 (mlp_l4_range_h2) under the next leg
-      static const int leg_end[3] = {7, 10, 13};   // conv3_3, conv4_3, conv5_3 done
       static const int leg_ev[3] = {5, 9, 7};
+      const L4Plan& P = l4_plan();
       int i0 = 2;
-      for (int r = 0; r < 3; ++r) {
-        rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, i0, leg_end[r]);
+      for (int r = 0; r < P.n; ++r) {
+        const int ev = r == P.n - 1 ? 7 : leg_ev[r];
+        rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, i0, P.leg_end[r]);
         if (rc) return rc;
-        i0 = leg_end[r];
-        DISN_TRY(hipEventRecord(ctx->ev[leg_ev[r]], st));
-        DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[leg_ev[r]], 0));
+        i0 = P.leg_end[r];
+        DISN_TRY(hipEventRecord(ctx->ev[ev], st));
+        DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[ev], 0));
         if ((rc = mlp_l4_gather(taps, trans_mat, pts, B, N, e.q.feat, feat_ld, e.q.mlp, r, ctx->aux))) return rc;
         if ((rc = mlp_l4_range_h2(mw, N, e.q.feat, feat_ld, e.q.mlp, B, r, ctx->aux))) return rc;
       }
@@ -1402,6 +1409,7 @@ int conv_occ = 0, conv_occ_mask = 7, conv_occ_min = 384;
 int aux_cu_mode = 0;
 int conv_img_major = -1;
 int conv_wide_min = 4;
+int l4_ranges = 3;
 long long* ch2_stamps = nullptr;
 }
 }  // namespace disn
@@ -1411,15 +1419,15 @@ extern "C" int disn_tuning_set_ptr(int key, void* p) {
   return 0;
 }
 // tuning builds only (build.py --tuning -> libdisn_amd_tuning.so): 0 x3, 1 overlap, 2 bf_splits, 3 skip_pack,
-// 4 fused_safe, 5-7 gemm_force, 8 gemv_wgs, 9 dense_mb, 10 dense_nw, 11 dense_kpw, 12 conv_occ, 13 conv_occ_mask, 14 conv_occ_min, 15 aux_cu_mode, 16 conv_img_major, 17 conv_wide_min
+// 4 fused_safe, 5-7 gemm_force, 8 gemv_wgs, 9 dense_mb, 10 dense_nw, 11 dense_kpw, 12 conv_occ, 13 conv_occ_mask, 14 conv_occ_min, 15 aux_cu_mode, 16 conv_img_major, 17 conv_wide_min, 18 l4_ranges
 extern "C" int disn_tuning_set(int key, int value) {
-  int* k[18] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
+  int* k[19] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
                 &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
                 &disn::tune::gemm_force[2], &disn::tune::gemv_wgs, &disn::tune::dense_mb,
                 &disn::tune::dense_nw, &disn::tune::dense_kpw, &disn::tune::conv_occ, &disn::tune::conv_occ_mask,
                 &disn::tune::conv_occ_min, &disn::tune::aux_cu_mode,
-                &disn::tune::conv_img_major, &disn::tune::conv_wide_min};
-  if (key < 0 || key > 17) return DISN_E_ARG;
+                &disn::tune::conv_img_major, &disn::tune::conv_wide_min, &disn::tune::l4_ranges};
+  if (key < 0 || key > 18) return DISN_E_ARG;
   *k[key] = value;
   return 0;
 }

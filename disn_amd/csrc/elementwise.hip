@@ -355,7 +355,11 @@ __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
     const int cl = c - (k == 0 ? 0 : (k == 1 ? 64 : (k == 2 ? 192 : (k == 3 ? 448 : 960))));
     const float* tap = t.p[k] + (size_t)b * t.stride[k];
     const float s = t.s[k];
-    // the resampler of sample4, its four map reads replaced by tap_pixel
+    // the resampler of sample4, its four map reads replaced by the up-sampled tap pixels (tap_pixel's expression).
+    // The four map pixels are {ify, icy} x {ifx, icx}, so their 16 tap pixels are a 4 x 4 grid {ylo, yhi of both map
+    // rows} x {xlo, xhi of both map columns}: all 16 loads are issued before any is used (one memory round trip per
+    // output instead of four; addresses of out-of-map pixels are clamped, their values replaced by the resampler's
+    // zeros afterwards -- no branch around a load).
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool ok = x > -1.0f && y > -1.0f && x < (float)DISN_IMG && y < (float)DISN_IMG;
     if (ok) {
@@ -369,21 +373,47 @@ __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
       const float w_cf = (1.0f - dx) * dy;
       const bool xf = ifx >= 0 && ifx < DISN_IMG, xc = icx >= 0 && icx < DISN_IMG;
       const bool yf = ify >= 0 && ify < DISN_IMG, yc = icy >= 0 && icy < DISN_IMG;
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 v_ff = (xf && yf) ? tap_pixel(tap, hw, ch, s, ify, ifx, cl) : z4;
-      const float4 v_cc = (xc && yc) ? tap_pixel(tap, hw, ch, s, icy, icx, cl) : z4;
-      const float4 v_fc = (xf && yc) ? tap_pixel(tap, hw, ch, s, icy, ifx, cl) : z4;
-      const float4 v_cf = (xc && yf) ? tap_pixel(tap, hw, ch, s, ify, icx, cl) : z4;
-#define DISN_ACC(f)          \
-  {                          \
-    float v = w_ff * v_ff.f; \
-    v = v + w_cc * v_cc.f;   \
-    v = v + w_fc * v_fc.f;   \
-    v = v + w_cf * v_cf.f;   \
-    o.f = v;                 \
+      int roff[4], coff[4];
+      float yl[2], xl[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int oy = min(max(h ? icy : ify, 0), DISN_IMG - 1), ox = min(max(h ? icx : ifx, 0), DISN_IMG - 1);
+        const float ty = (float)oy * s, tx = (float)ox * s;
+        const int ylo = (int)floorf(ty), xlo = (int)floorf(tx);
+        const int yhi = min(ylo + 1, hw - 1), xhi = min(xlo + 1, hw - 1);
+        yl[h] = ty - (float)ylo;
+        xl[h] = tx - (float)xlo;
+        roff[2 * h] = ylo * hw * ch;
+        roff[2 * h + 1] = yhi * hw * ch;
+        coff[2 * h] = xlo * ch;
+        coff[2 * h + 1] = xhi * ch;
+      }
+      const float* base = tap + cl;
+      float4 T[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T[r][q] = *reinterpret_cast<const float4*>(base + roff[r] + coff[q]);
+      // map pixel (row half hy, column half hx): tl, tr, bl, br = T[2 hy][2 hx], T[2 hy][2 hx + 1], T[2 hy + 1][..]
+#define DISN_LERP(hy, hx, f) \
+  ((T[2 * hy][2 * hx].f + (T[2 * hy][2 * hx + 1].f - T[2 * hy][2 * hx].f) * xl[hx]) + \
+   ((T[2 * hy + 1][2 * hx].f + (T[2 * hy + 1][2 * hx + 1].f - T[2 * hy + 1][2 * hx].f) * xl[hx]) - \
+    (T[2 * hy][2 * hx].f + (T[2 * hy][2 * hx + 1].f - T[2 * hy][2 * hx].f) * xl[hx])) * yl[hy])
+#define DISN_ACC(f)                                         \
+  {                                                         \
+    const float p_ff = (xf && yf) ? DISN_LERP(0, 0, f) : 0.f; \
+    const float p_cc = (xc && yc) ? DISN_LERP(1, 1, f) : 0.f; \
+    const float p_fc = (xf && yc) ? DISN_LERP(1, 0, f) : 0.f; \
+    const float p_cf = (xc && yf) ? DISN_LERP(0, 1, f) : 0.f; \
+    float v = w_ff * p_ff;                                  \
+    v = v + w_cc * p_cc;                                    \
+    v = v + w_fc * p_fc;                                    \
+    v = v + w_cf * p_cf;                                    \
+    o.f = v;                                                \
   }
       DISN_ACC(x) DISN_ACC(y) DISN_ACC(z) DISN_ACC(w)
 #undef DISN_ACC
+#undef DISN_LERP
     }
     *reinterpret_cast<float4*>(feat + pt * feat_ld + c) = o;
     vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
