@@ -268,7 +268,11 @@ int mlp_phase1_h2(const disn_mlp_weights_t* w, int n, const float* feat, int fea
 struct L4Plan { int n; int cut[4]; int tap[4]; int leg_end[3]; };   // n ranges; feature-column cuts; tap cuts; last conv layer + 1 of each leg
 constexpr L4Plan kL4Plan3 = {3, {0, 384, 896, 1536}, {0, 3, 4, 5}, {7, 10, 13}};
 constexpr L4Plan kL4Plan2 = {2, {0, 896, 1536, 0}, {0, 4, 5, 0}, {10, 13, 0}};   // conv4_3 / conv5_3 only (measured beside it, r03)
-inline const L4Plan& l4_plan() { return tune::l4_ranges == 2 ? kL4Plan2 : kL4Plan3; }
+// Measured (tools/bench_knobs.py l4_ranges=0/2/3, profiles/r03h_bench_l4.txt; points/s at --steps 20 / steady state /
+// one call at a time): one piece behind conv5_3 9.99 / 12.65 / 11.50 M, two ranges 10.45 / 12.26 / 11.69 M, three
+// 10.13 / 11.84 / 11.65 M -- the gathers running beside the convolutions cost those more than the shorter tail returns
+// once calls overlap anyway; two ranges are the best latency of a call and the default.
+inline const L4Plan& l4_plan() { return tune::l4_ranges == 3 ? kL4Plan3 : kL4Plan2; }
 constexpr int kGatherSlots = 144;                    // entries per gather: floats 576 + 144 r .. of a slot set
 
 int gather_entries(int n, int feat_ld, int r) {
@@ -1409,7 +1413,8 @@ int conv_occ = 0, conv_occ_mask = 7, conv_occ_min = 384;
 int aux_cu_mode = 0;
 int conv_img_major = -1;
 int conv_wide_min = 4;
-int l4_ranges = 3;
+int l4_ranges = 2;
+int gather_l16 = 0;
 long long* ch2_stamps = nullptr;
 }
 }  // namespace disn
@@ -1419,15 +1424,15 @@ extern "C" int disn_tuning_set_ptr(int key, void* p) {
   return 0;
 }
 // tuning builds only (build.py --tuning -> libdisn_amd_tuning.so): 0 x3, 1 overlap, 2 bf_splits, 3 skip_pack,
-// 4 fused_safe, 5-7 gemm_force, 8 gemv_wgs, 9 dense_mb, 10 dense_nw, 11 dense_kpw, 12 conv_occ, 13 conv_occ_mask, 14 conv_occ_min, 15 aux_cu_mode, 16 conv_img_major, 17 conv_wide_min, 18 l4_ranges
+// 4 fused_safe, 5-7 gemm_force, 8 gemv_wgs, 9 dense_mb, 10 dense_nw, 11 dense_kpw, 12 conv_occ, 13 conv_occ_mask, 14 conv_occ_min, 15 aux_cu_mode, 16 conv_img_major, 17 conv_wide_min, 18 l4_ranges, 19 gather_l16
 extern "C" int disn_tuning_set(int key, int value) {
-  int* k[19] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
+  int* k[20] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
                 &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
                 &disn::tune::gemm_force[2], &disn::tune::gemv_wgs, &disn::tune::dense_mb,
                 &disn::tune::dense_nw, &disn::tune::dense_kpw, &disn::tune::conv_occ, &disn::tune::conv_occ_mask,
                 &disn::tune::conv_occ_min, &disn::tune::aux_cu_mode,
-                &disn::tune::conv_img_major, &disn::tune::conv_wide_min, &disn::tune::l4_ranges};
-  if (key < 0 || key > 18) return DISN_E_ARG;
+                &disn::tune::conv_img_major, &disn::tune::conv_wide_min, &disn::tune::l4_ranges, &disn::tune::gather_l16};
+  if (key < 0 || key > 19) return DISN_E_ARG;
   *k[key] = value;
   return 0;
 }

@@ -11,6 +11,7 @@
 //   maxpool2x2       -- slim.max_pool2d                  (models/CNN/vgg.py:188-196)
 //   grid_points      -- linspace/meshgrid grid           (test/create_sdf.py:246-256)
 #include "kernels.hpp"
+#include "tuning.hpp"
 
 namespace disn {
 
@@ -310,6 +311,7 @@ __device__ __forceinline__ float4 tap_pixel(const float* __restrict__ tap, int h
   return o;
 }
 
+template <bool L16>
 __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
                                                                    const float* __restrict__ trans_mat,
                                                                    const float* __restrict__ pts, int B,
@@ -355,12 +357,43 @@ __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
     const int cl = c - (k == 0 ? 0 : (k == 1 ? 64 : (k == 2 ? 192 : (k == 3 ? 448 : 960))));
     const float* tap = t.p[k] + (size_t)b * t.stride[k];
     const float s = t.s[k];
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!L16) {
+    // the resampler of sample4, its four map reads replaced by tap_pixel
+    const bool ok = x > -1.0f && y > -1.0f && x < (float)DISN_IMG && y < (float)DISN_IMG;
+    if (ok) {
+      const float fx = floorf(x), fy = floorf(y);
+      const float cx = fx + 1.0f, cy = fy + 1.0f;
+      const float dx = cx - x, dy = cy - y;
+      const int ifx = (int)fx, ify = (int)fy, icx = (int)cx, icy = (int)cy;
+      const float w_ff = dx * dy;
+      const float w_cc = (1.0f - dx) * (1.0f - dy);
+      const float w_fc = dx * (1.0f - dy);
+      const float w_cf = (1.0f - dx) * dy;
+      const bool xf = ifx >= 0 && ifx < DISN_IMG, xc = icx >= 0 && icx < DISN_IMG;
+      const bool yf = ify >= 0 && ify < DISN_IMG, yc = icy >= 0 && icy < DISN_IMG;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v_ff = (xf && yf) ? tap_pixel(tap, hw, ch, s, ify, ifx, cl) : z4;
+      const float4 v_cc = (xc && yc) ? tap_pixel(tap, hw, ch, s, icy, icx, cl) : z4;
+      const float4 v_fc = (xf && yc) ? tap_pixel(tap, hw, ch, s, icy, ifx, cl) : z4;
+      const float4 v_cf = (xc && yf) ? tap_pixel(tap, hw, ch, s, ify, icx, cl) : z4;
+#define DISN_ACC(f)          \
+  {                          \
+    float v = w_ff * v_ff.f; \
+    v = v + w_cc * v_cc.f;   \
+    v = v + w_fc * v_fc.f;   \
+    v = v + w_cf * v_cf.f;   \
+    o.f = v;                 \
+  }
+      DISN_ACC(x) DISN_ACC(y) DISN_ACC(z) DISN_ACC(w)
+#undef DISN_ACC
+    }
+    } else {
     // the resampler of sample4, its four map reads replaced by the up-sampled tap pixels (tap_pixel's expression).
     // The four map pixels are {ify, icy} x {ifx, icx}, so their 16 tap pixels are a 4 x 4 grid {ylo, yhi of both map
     // rows} x {xlo, xhi of both map columns}: all 16 loads are issued before any is used (one memory round trip per
     // output instead of four; addresses of out-of-map pixels are clamped, their values replaced by the resampler's
     // zeros afterwards -- no branch around a load).
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool ok = x > -1.0f && y > -1.0f && x < (float)DISN_IMG && y < (float)DISN_IMG;
     if (ok) {
       const float fx = floorf(x), fy = floorf(y);
@@ -415,6 +448,7 @@ __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
 #undef DISN_ACC
 #undef DISN_LERP
     }
+    }
     *reinterpret_cast<float4*>(feat + pt * feat_ld + c) = o;
     vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
   }
@@ -465,11 +499,15 @@ hipError_t project_gather_taps_launch(const float* const taps[5], const float* t
   if (amax) {
     int G = project_gather_taps_amax_blocks(n, feat_ld, tap_begin, tap_end);
     if (amax_cap > 0 && G > amax_cap) G = amax_cap;   // entries the caller has room for
-    hipLaunchKernelGGL(project_gather_taps_kernel, dim3((unsigned)(B * G)), dim3(1024), 0, st, t, trans_mat, pts, B, n,
+    if (tune::gather_l16) hipLaunchKernelGGL(project_gather_taps_kernel<true>, dim3((unsigned)(B * G)), dim3(1024), 0, st, t, trans_mat, pts, B, n,
+                       c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
+    else hipLaunchKernelGGL(project_gather_taps_kernel<false>, dim3((unsigned)(B * G)), dim3(1024), 0, st, t, trans_mat, pts, B, n,
                        c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(project_gather_taps_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
+  if (tune::gather_l16) hipLaunchKernelGGL(project_gather_taps_kernel<true>, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
+                     trans_mat, pts, B, n, c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
+  else hipLaunchKernelGGL(project_gather_taps_kernel<false>, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
                      trans_mat, pts, B, n, c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
   return hipGetLastError();
 }

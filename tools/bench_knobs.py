@@ -4,6 +4,8 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+torch.cuda.init(); torch.zeros(1, device="cuda:0")   # the HIP runtime comes up through torch first (as in bench.py)
 import _tuning
 for kv in filter(None, os.environ.get("KNOBS", "").split(",")):
     k, v = kv.split("=")
