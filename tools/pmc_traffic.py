@@ -30,7 +30,7 @@ ids = sorted(fetch)
 
 
 def is_conv(n):
-    return ("conv_h2_kernel" in n or "conv1_1_direct_kernel" in n or ("gemm_bf16_mfma" in n and ", 1, " in n)
+    return ("conv_h2_kernel" in n or "conv_h2w_kernel" in n or "conv1_1_direct_kernel" in n or ("gemm_bf16_mfma" in n and ", 1, " in n)
             or ("gemm_f32_mfma" in n and (", 1, 0>" in n or ", 2, 0>" in n)))
 
 
@@ -55,10 +55,10 @@ cal = 262144 * 5888 / 1024.0 / write[g_big]["v"]
 g_taps = [i for i in ids if "project_gather_taps_kernel" in fetch[i]["name"]]
 g_fold = [i for i in ids if "gather_fold_kernel" in fetch[i]["name"]]
 fused = [i for i in ids if "mlp_fused_kernel" in fetch[i]["name"]]
-build = ""
+build = os.environ.get("PMC_BUILD", "")
 try:
     build = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "disn_amd", "csrc", "build",
-                              "BUILD_ID")).read().strip()
+                              "BUILD_ID")).read().strip() or build
 except Exception:
     pass
 
