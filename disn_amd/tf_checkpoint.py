@@ -18,6 +18,25 @@ byte, shortened index keys included); NOT validated against a file written by Te
 in this environment -- the reference's checkpoints are Dropbox downloads).
 Only what DISN checkpoints contain is supported: uncompressed blocks, one shard, float32/int32/
 int64/float64 tensors, no tensor slices.
+
+V1 checkpoints (``load_checkpoint_v1``; ``load_checkpoint`` / ``list_variables`` detect the format).  The training
+recipe starts from TF-slim's ``vgg_16.ckpt`` (README.md:128; train/train_sdf.py:190-219 lists and restores it through
+``checkpoint_utils`` / ``tf.train.Saver``, which read both formats).  That 2016 file is a SINGLE-FILE V1 checkpoint
+(``tf.train.Saver`` wrote V1 until TF 0.12), i.e. one TF table -- the same table format as the V2 ``.index`` -- written
+by tensorflow/core/util/tensor_slice_writer.cc (``table::Options::compression = kNoCompression``):
+
+    key ""                                 -> SavedTensorSlices { meta = 1: SavedTensorSliceMeta {
+                                                 repeated SavedSliceMeta tensor = 1 { name = 1, shape = 2, type = 3,
+                                                 repeated TensorSliceProto slice = 4 }, versions = 2 } }
+    key OrderedCode(0, name, slice extents) -> SavedTensorSlices { data = 2: SavedSlice { name = 1,
+                                                 TensorSliceProto slice = 2, TensorProto data = 3 } }
+
+with the values in the TensorProto's typed repeated fields (float_val = 5, double_val = 6, int_val = 7,
+int64_val = 10; packed) or tensor_content = 4.  The reader takes name and slice from the VALUE (the ordered-code key is
+only checked for its leading 0), assembles slices of partitioned variables into the full tensor, and is pinned by a file
+assembled by hand from this description (tests/test_tf_checkpoint.py).  STATUS: like the V2 code, not validated against
+a file written by TensorFlow (none here); if slim's file turns out to be compressed (kSnappyCompression) the reader
+says so instead of guessing.
 """
 from __future__ import annotations
 
@@ -265,13 +284,252 @@ def _emit_block(f, block: bytes) -> Tuple[int, int]:
     return off, len(block)
 
 
+# ---------------------------------------------------------------- V1 (single-file, tensor_slice_writer.cc)
+def _table_entries(buf: bytes, verify: bool) -> Iterable[Tuple[bytes, bytes]]:
+    """every (key, value) of a TF table held in ``buf``, in key order"""
+    if len(buf) < FOOTER_LEN or struct.unpack("<Q", buf[-8:])[0] != TABLE_MAGIC:
+        raise ValueError("not a TensorFlow table (bad magic)")
+    footer = buf[-FOOTER_LEN:]
+    pos = 0
+    _mi_off, pos = _get_varint(footer, pos)
+    _mi_size, pos = _get_varint(footer, pos)
+    idx_off, pos = _get_varint(footer, pos)
+    idx_size, pos = _get_varint(footer, pos)
+    for _, handle in _block_entries(_read_block(buf, idx_off, idx_size, verify)):
+        off, p = _get_varint(handle, 0)
+        size, p = _get_varint(handle, p)
+        for kv in _block_entries(_read_block(buf, off, size, verify)):
+            yield kv
+
+
+def _decode_slice(buf: bytes) -> List[Tuple[int, int]]:
+    """TensorSliceProto: repeated Extent extent = 1 { int64 start = 1; oneof { int64 length = 2 } } -> [(start, length)],
+    length -1 = the whole dimension (an Extent without a length)"""
+    out = []
+    for fn, wt, v in _pb_fields(buf):
+        if fn == 1 and wt == 2:
+            start, length = 0, -1
+            for f2, w2, v2 in _pb_fields(v):
+                if f2 == 1:
+                    start = v2
+                elif f2 == 2:
+                    length = v2
+            out.append((start, length))
+    return out
+
+
+def _packed_varints(buf: bytes, signed_bits: int) -> List[int]:
+    out, pos = [], 0
+    while pos < len(buf):
+        v, pos = _get_varint(buf, pos)
+        if v >= 1 << 63:
+            v -= 1 << 64
+        if signed_bits == 32:
+            v = ((v + (1 << 31)) % (1 << 32)) - (1 << 31)
+        out.append(v)
+    return out
+
+
+def _decode_tensor_proto(buf: bytes) -> Tuple[int, Tuple[int, ...], np.ndarray]:
+    """TensorProto (tensor.proto) -> (dtype, shape, flat values): tensor_content, or the typed repeated field"""
+    dtype, shape, content = 0, (), None
+    typed: Dict[int, List] = {5: [], 6: [], 7: [], 10: []}
+    for fn, wt, v in _pb_fields(buf):
+        if fn == 1:
+            dtype = v
+        elif fn == 2:
+            shape = _decode_shape(v)
+        elif fn == 4:
+            content = v
+        elif fn == 5:        # float_val: packed (wire type 2) or one fixed32 per element
+            typed[5].append(np.frombuffer(v, "<f4") if wt == 2 else np.frombuffer(struct.pack("<I", v), "<f4"))
+        elif fn == 6:
+            typed[6].append(np.frombuffer(v, "<f8") if wt == 2 else np.frombuffer(struct.pack("<Q", v), "<f8"))
+        elif fn == 7:
+            typed[7].append(np.asarray(_packed_varints(v, 32) if wt == 2 else [((v + (1 << 31)) % (1 << 32)) - (1 << 31)], np.int32))
+        elif fn == 10:
+            typed[10].append(np.asarray(_packed_varints(v, 64) if wt == 2 else [v - (1 << 64) if v >= 1 << 63 else v], np.int64))
+    if dtype not in DT:
+        raise NotImplementedError("DataType %d" % dtype)
+    dt = np.dtype(DT[dtype])
+    if content is not None:
+        vals = np.frombuffer(content, dtype=dt.newbyteorder("<")).astype(dt)
+    else:
+        field = {1: 5, 2: 6, 3: 7, 9: 10}[dtype]
+        vals = np.concatenate(typed[field]).astype(dt) if typed[field] else np.zeros(0, dt)
+    return dtype, shape, vals
+
+
+def is_v1_checkpoint(path: str) -> bool:
+    """a single FILE that is a TF table (V2 is <prefix>.index + <prefix>.data-*)"""
+    if not os.path.isfile(path):
+        return False
+    with open(path, "rb") as f:
+        f.seek(0, os.SEEK_END)
+        if f.tell() < FOOTER_LEN:
+            return False
+        f.seek(-8, os.SEEK_END)
+        return struct.unpack("<Q", f.read(8))[0] == TABLE_MAGIC
+
+
+def list_variables_v1(path: str, verify: bool = True) -> Dict[str, Dict[str, object]]:
+    """name -> {dtype, shape, slices} from the SavedTensorSliceMeta under key ''"""
+    buf = open(path, "rb").read()
+    out: Dict[str, Dict[str, object]] = {}
+    for k, v in _table_entries(buf, verify):
+        if k != b"":
+            break                               # keys are sorted: '' comes first
+        for fn, wt, meta in _pb_fields(v):      # SavedTensorSlices.meta = 1
+            if fn != 1 or wt != 2:
+                continue
+            for f2, w2, t in _pb_fields(meta):  # SavedTensorSliceMeta.tensor = 1
+                if f2 != 1 or w2 != 2:
+                    continue
+                e = {"dtype": 0, "shape": (), "slices": 0}
+                name = ""
+                for f3, w3, x in _pb_fields(t):
+                    if f3 == 1:
+                        name = x.decode("utf-8")
+                    elif f3 == 2:
+                        e["shape"] = _decode_shape(x)
+                    elif f3 == 3:
+                        e["dtype"] = x
+                    elif f3 == 4:
+                        e["slices"] += 1
+                out[name] = e
+    if not out:
+        raise ValueError("%s: no SavedTensorSliceMeta under key '' (not a V1 checkpoint?)" % path)
+    return out
+
+
+def load_checkpoint_v1(path: str, names: Optional[Iterable[str]] = None, verify: bool = True) -> Dict[str, np.ndarray]:
+    """Read tensors of a single-file V1 checkpoint by variable name (all, or the ``names`` given)."""
+    buf = open(path, "rb").read()
+    want = set(names) if names is not None else None
+    meta = list_variables_v1(path, verify)
+    out: Dict[str, np.ndarray] = {}
+    filled: Dict[str, int] = {}
+    for k, v in _table_entries(buf, verify):
+        if k == b"":
+            continue
+        if k[:1] != b"\x00":                    # OrderedCode::WriteNumIncreasing(0) = one zero byte
+            raise ValueError("V1 checkpoint key does not start with the ordered code of 0")
+        for fn, wt, ss in _pb_fields(v):        # SavedTensorSlices.data = 2: SavedSlice
+            if fn != 2 or wt != 2:
+                continue
+            name, extents, tp = "", [], None
+            for f2, w2, x in _pb_fields(ss):
+                if f2 == 1:
+                    name = x.decode("utf-8")
+                elif f2 == 2:
+                    extents = _decode_slice(x)
+                elif f2 == 3:
+                    tp = x
+            if want is not None and name not in want:
+                continue
+            if name not in meta or tp is None:
+                raise ValueError("V1 checkpoint: slice of unknown tensor %r" % name)
+            dtype, _, vals = _decode_tensor_proto(tp)
+            full = tuple(int(d) for d in meta[name]["shape"])
+            if dtype != meta[name]["dtype"]:
+                raise ValueError("%s: slice dtype %d, meta dtype %d" % (name, dtype, meta[name]["dtype"]))
+            if name not in out:
+                out[name] = np.zeros(full, DT[dtype])
+                filled[name] = 0
+            idx = tuple(slice(None) if ln < 0 else slice(st, st + ln)
+                        for (st, ln) in (extents + [(0, -1)] * (len(full) - len(extents))))
+            target = out[name][idx] if full else out[name]
+            if vals.size != target.size:
+                raise ValueError("%s: slice holds %d values, its extent %d" % (name, vals.size, target.size))
+            if full:
+                out[name][idx] = vals.reshape(target.shape)
+            else:
+                out[name] = vals.reshape(()).astype(DT[dtype])
+            filled[name] += int(vals.size)
+    for name, n in filled.items():
+        size = int(np.prod(meta[name]["shape"], dtype=np.int64)) if meta[name]["shape"] else 1
+        if n != size:
+            raise ValueError("%s: slices cover %d of %d elements" % (name, n, size))
+    if want is not None and want - set(out):
+        pass                                     # absent names are simply not returned (as load_checkpoint)
+    return out
+
+
+def _ordered_string(b: bytes) -> bytes:
+    """OrderedCode::WriteString's escaping: 0x00 -> 00 ff, 0xff -> ff 00 (the terminator 00 01 is added by the caller)"""
+    return b"".join(b"\x00\xff" if c == 0 else (b"\xff\x00" if c == 0xFF else bytes([c])) for c in b)
+
+
+def save_checkpoint_v1(path: str, tensors: Dict[str, np.ndarray], block_bytes: int = 4096) -> None:
+    """Write a single-file V1 checkpoint as tensor_slice_writer.cc does for unpartitioned variables: one full slice per
+    tensor, values in the TensorProto's typed repeated field.  (The reference never writes V1 -- its Saver is V2; this
+    exists so that the V1 reader can be exercised on real weights and a V1 file can be produced for a TF-slim tool.)"""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    field = {1: 5, 2: 6, 3: 7, 9: 10}
+    meta = b""
+    items: List[Tuple[bytes, bytes]] = []
+    for name in sorted(tensors, key=lambda n: n.encode("utf-8")):
+        a = np.asarray(tensors[name])
+        if a.dtype not in DT_INV:
+            raise NotImplementedError("%s: dtype %s" % (name, a.dtype))
+        dt = DT_INV[a.dtype]
+        nm = name.encode("utf-8")
+        shape = _encode_shape(a.shape)
+        slc = b"".join(_pb_bytes(1, b"") for _ in a.shape)                 # one empty Extent per dimension
+        meta += _pb_bytes(1, _pb_bytes(1, nm) + _pb_bytes(2, shape) + _pb_varint(3, dt) + _pb_bytes(4, slc))
+        if dt in (1, 2):
+            payload = np.ascontiguousarray(a).astype(a.dtype.newbyteorder("<")).tobytes()
+        else:
+            payload = b"".join(_put_varint(int(x)) for x in np.ascontiguousarray(a).reshape(-1))
+        tp = _pb_varint(1, dt) + _pb_bytes(2, shape) + _pb_bytes(field[dt], payload)
+        value = _pb_bytes(2, _pb_bytes(1, nm) + _pb_bytes(2, slc) + _pb_bytes(3, tp))
+        nd = len(a.shape)
+        key = b"\x00" + _ordered_string(nm) + b"\x00\x01" + (b"\x00" if nd == 0 else bytes([1, nd])) + b"\x80\x7f" * nd
+        items.append((key, value))
+    items.sort(key=lambda kv: kv[0])
+    items.insert(0, (b"", _pb_bytes(1, meta + _pb_bytes(2, _pb_varint(1, 1)))))     # meta + versions { producer: 1 }
+    with open(path, "wb") as f:
+        index_entries: List[Tuple[bytes, bytes]] = []
+        cur: List[Tuple[bytes, bytes]] = []
+        cur_bytes = 0
+        pending: Optional[Tuple[bytes, bytes]] = None
+
+        def flush():
+            nonlocal cur, cur_bytes, pending
+            if cur:
+                off, size = _emit_block(f, _build_block(cur, 16))
+                pending = (cur[-1][0], _put_varint(off) + _put_varint(size))
+                cur, cur_bytes = [], 0
+
+        for k, v in items:
+            if pending is not None:
+                index_entries.append((_shortest_separator(pending[0], k), pending[1]))
+                pending = None
+            cur.append((k, v))
+            cur_bytes += len(k) + len(v) + 3
+            if cur_bytes >= block_bytes:
+                flush()
+        flush()
+        if pending is not None:
+            index_entries.append((_short_successor(pending[0]), pending[1]))
+        mi_off, mi_size = _emit_block(f, _build_block([], 1))
+        ix_off, ix_size = _emit_block(f, _build_block(index_entries, 1))
+        footer = _put_varint(mi_off) + _put_varint(mi_size) + _put_varint(ix_off) + _put_varint(ix_size)
+        f.write(footer + b"\x00" * (FOOTER_LEN - 8 - len(footer)) + struct.pack("<Q", TABLE_MAGIC))
+
+
 # ---------------------------------------------------------------- public API
 def data_path(prefix: str, shard: int = 0, num_shards: int = 1) -> str:
     return "%s.data-%05d-of-%05d" % (prefix, shard, num_shards)
 
 
 def list_variables(prefix: str, verify: bool = True) -> Dict[str, Dict[str, object]]:
-    """name -> {dtype, shape, shard_id, offset, size, crc32c}; the header is returned under ''."""
+    """name -> {dtype, shape, shard_id, offset, size, crc32c}; the header is returned under ''.
+    A single-file V1 checkpoint (no <prefix>.index, <prefix> itself a table): list_variables_v1 + {'': {'format': 'v1'}}."""
+    if not os.path.exists(prefix + ".index") and is_v1_checkpoint(prefix):
+        d = list_variables_v1(prefix, verify)
+        d[""] = {"format": "v1", "num_shards": 1, "endianness": 0}
+        return d
     buf = open(prefix + ".index", "rb").read()
     if len(buf) < FOOTER_LEN or struct.unpack("<Q", buf[-8:])[0] != TABLE_MAGIC:
         raise ValueError("%s.index is not a TensorFlow table (bad magic)" % prefix)
@@ -305,7 +563,10 @@ def list_variables(prefix: str, verify: bool = True) -> Dict[str, Dict[str, obje
 
 def load_checkpoint(prefix: str, names: Optional[Iterable[str]] = None, verify: bool = True
                     ) -> Dict[str, np.ndarray]:
-    """Read tensors of a V2 bundle by variable name (all, or the ``names`` given)."""
+    """Read tensors of a checkpoint by variable name (all, or the ``names`` given): a V2 bundle
+    (<prefix>.index + .data-*) or, when <prefix> itself is a table file, a single-file V1 checkpoint."""
+    if not os.path.exists(prefix + ".index") and is_v1_checkpoint(prefix):
+        return load_checkpoint_v1(prefix, names, verify)
     entries = list_variables(prefix, verify)
     hdr = entries.pop("")
     want = set(names) if names is not None else None

@@ -211,3 +211,99 @@ def test_writer_produces_the_hand_assembled_bytes(tmp_path):
     tfc.save_checkpoint(prefix, {"a/c": np.asarray(7, np.int32), "a/b": np.asarray([1.0, -2.0], np.float32)})
     assert open(prefix + ".data-00000-of-00001", "rb").read() == data
     assert open(prefix + ".index", "rb").read() == index
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# A single-file V1 checkpoint assembled BY HAND (tensorflow/core/util/tensor_slice_writer.cc, saved_tensor_slice.proto,
+# tensor_slice.proto, tensor.proto, lib/strings/ordered_code.cc): what TF-slim's vgg_16.ckpt is (README.md:128).
+#   key ""                     -> SavedTensorSlices { meta { tensor { name, shape, type, slice } ... } }
+#   key 00 <name> 00 01 <ndims> (<start> <length>)*  (ordered code; small signed numbers are one byte 0x80 + x, the
+#                                 full extent's length -1 is 0x7f)
+#                              -> SavedTensorSlices { data { name, slice, data: TensorProto with float_val / int_val } }
+# ---------------------------------------------------------------------------------------------------------------
+def _pb(fn, payload):              # a length-delimited field (payload < 128 bytes)
+    assert len(payload) < 128
+    return bytes([(fn << 3) | 2, len(payload)]) + payload
+
+
+def _hand_assembled_v1():
+    shape2 = _pb(2, bytes([0x08, 2]))                       # TensorShapeProto { dim { size: 2 } }
+    shape4 = _pb(2, bytes([0x08, 4]))
+    full1 = _pb(1, b"")                                     # TensorSliceProto { extent {} }: the whole dimension
+    meta = b"".join(_pb(1, m) for m in (                    # SavedTensorSliceMeta.tensor = 1
+        _pb(1, b"a/b") + _pb(2, shape2) + bytes([0x18, 1]) + _pb(4, full1),          # float32 [2], one full slice
+        _pb(1, b"a/c") + _pb(2, b"") + bytes([0x18, 3]) + _pb(4, b""),               # int32 scalar
+        _pb(1, b"p") + _pb(2, shape4) + bytes([0x18, 1])                             # float32 [4] in two slices
+        + _pb(4, _pb(1, bytes([0x10, 2]))) + _pb(4, _pb(1, bytes([0x08, 2, 0x10, 2])))))
+    v_meta = _pb(1, meta)                                   # SavedTensorSlices.meta = 1
+    tp_ab = bytes([0x08, 1]) + _pb(2, shape2) + _pb(5, struct.pack("<2f", 1.0, -2.0))          # dtype, shape, packed float_val
+    tp_ac = bytes([0x08, 3]) + _pb(2, b"") + _pb(7, bytes([7]))                                # int_val packed: varint 7
+    tp_p0 = bytes([0x08, 1]) + _pb(2, shape2) + _pb(5, struct.pack("<2f", 10.0, 11.0))
+    tp_p1 = bytes([0x08, 1]) + _pb(2, shape2) + _pb(4, struct.pack("<2f", 12.0, 13.0))         # tensor_content instead
+    v_ab = _pb(2, _pb(1, b"a/b") + _pb(2, full1) + _pb(3, tp_ab))                              # SavedTensorSlices.data = 2
+    v_ac = _pb(2, _pb(1, b"a/c") + _pb(2, b"") + _pb(3, tp_ac))
+    v_p0 = _pb(2, _pb(1, b"p") + _pb(2, _pb(1, bytes([0x10, 2]))) + _pb(3, tp_p0))             # extent { length: 2 } (start 0)
+    v_p1 = _pb(2, _pb(1, b"p") + _pb(2, _pb(1, bytes([0x08, 2, 0x10, 2]))) + _pb(3, tp_p1))    # extent { start: 2 length: 2 }
+    k_ab = b"\x00" + b"a/b" + b"\x00\x01" + b"\x01\x01" + b"\x80\x7f"       # 0, "a/b", 1 dim, start 0, length -1
+    k_ac = b"\x00" + b"a/c" + b"\x00\x01" + b"\x00"                         # 0 dims
+    k_p0 = b"\x00" + b"p" + b"\x00\x01" + b"\x01\x01" + b"\x80\x82"         # start 0, length 2
+    k_p1 = b"\x00" + b"p" + b"\x00\x01" + b"\x01\x01" + b"\x82\x82"         # start 2, length 2
+    entries = [(b"", v_meta), (k_ab, v_ab), (k_ac, v_ac), (k_p0, v_p0), (k_p1, v_p1)]
+    assert [k for k, _ in entries] == sorted(k for k, _ in entries)
+    body = b""
+    for k, v in entries:                                    # no key sharing (shared = 0 is always legal)
+        assert len(k) < 128 and len(v) < 128
+        body += bytes([0, len(k), len(v)]) + k + v
+    body += struct.pack("<II", 0, 1)
+    assert len(body) < 16384
+    data_block = _kat_block(body)
+    meta_block = _kat_block(struct.pack("<II", 0, 1))
+    handle0 = bytes([0]) + bytes([len(body) & 0x7F | 0x80, len(body) >> 7])               # varint of a size >= 128
+    index_body = bytes([0, 1, len(handle0)]) + b"\x01" + handle0 + struct.pack("<II", 0, 1)   # any key >= the last data key
+    index_block = _kat_block(index_body)
+    meta_off = len(data_block)
+    index_off = meta_off + len(meta_block)
+
+    def varint(n):
+        out = b""
+        while n >= 128:
+            out += bytes([n & 0x7F | 0x80])
+            n >>= 7
+        return out + bytes([n])
+    footer = varint(meta_off) + varint(8) + varint(index_off) + varint(len(index_body))
+    footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57)
+    return data_block + meta_block + index_block + footer
+
+
+def test_reader_reads_a_hand_assembled_v1_checkpoint(tmp_path):
+    """the single-file format of TF-slim's vgg_16.ckpt: typed value fields and tensor_content, a scalar, a partitioned
+    variable in two slices; auto-detected by load_checkpoint / list_variables and by the weight store"""
+    path = str(tmp_path / "vgg_like.ckpt")
+    open(path, "wb").write(_hand_assembled_v1())
+    assert tfc.is_v1_checkpoint(path) and not os.path.exists(path + ".index")
+    lv = tfc.list_variables(path)
+    assert lv[""]["format"] == "v1" and lv["a/b"]["shape"] == (2,) and lv["p"]["slices"] == 2 and lv["a/c"]["dtype"] == 3
+    got = tfc.load_checkpoint(path)
+    assert sorted(got) == ["a/b", "a/c", "p"]
+    assert got["a/b"].dtype == np.float32 and got["a/b"].tolist() == [1.0, -2.0]
+    assert got["a/c"].dtype == np.int32 and got["a/c"].shape == () and int(got["a/c"]) == 7
+    assert got["p"].tolist() == [10.0, 11.0, 12.0, 13.0]
+    assert sorted(tfc.load_checkpoint(path, names=["p"])) == ["p"]
+    bad = bytearray(open(path, "rb").read())
+    bad[20] ^= 1
+    open(path, "wb").write(bytes(bad))
+    with pytest.raises(ValueError):
+        tfc.load_checkpoint(path)
+
+
+def test_weight_store_restores_from_a_v1_file(tmp_path):
+    """WeightStore.load_tf on a V1 file written with the module's own table code (same data-block builder as the V2
+    index): the conv1_1 pair of a slim-style vgg_16.ckpt, prefix restore as train/train_sdf.py:196-205"""
+    from disn_amd.weights import WeightStore
+    ws = WeightStore.random_init(5)
+    names = ["vgg_16/conv1/conv1_1/weights", "vgg_16/conv1/conv1_1/biases"]
+    path = str(tmp_path / "vgg_16.ckpt")
+    tfc.save_checkpoint_v1(path, {n: ws[n] for n in names})
+    back = WeightStore.load_tf(path, name_prefix="vgg_16")
+    for n in names:
+        assert np.array_equal(back[n], ws[n])
