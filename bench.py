@@ -167,9 +167,15 @@ def grid_bench(args, torch, dist, dev, world, rank, launched, shared_gpu, backen
     params = [[-1, -1, -1, 1, 1, 1]] * B
     mine = list(range(rank, B, world))
 
+    a2a = args.exchange == "all_to_all"
+
     def step():
-        full = parallel.sharded_create_sdf(eng, imgs, tms, params, R)          # [B, total] on every rank
-        meshes = [iso.marching_cubes(full[b], params[b], R, 0.0) for b in mine]
+        if a2a:    # rank r receives the full grids of ITS images only (1/world of the all_gather's bytes)
+            full, own = parallel.sharded_create_sdf(eng, imgs, tms, params, R, exchange="all_to_all")
+            meshes = [iso.marching_cubes(full[i], params[b], R, 0.0) for i, b in enumerate(own)]
+        else:
+            full = parallel.sharded_create_sdf(eng, imgs, tms, params, R)          # [B, total] on every rank
+            meshes = [iso.marching_cubes(full[b], params[b], R, 0.0) for b in mine]
         return full, meshes
 
     for _ in range(args.warmup):
@@ -214,12 +220,18 @@ def grid_bench(args, torch, dist, dev, world, rank, launched, shared_gpu, backen
         gath = torch.empty((world, B, pad), dtype=torch.float32, device=dev)
 
         def ag():
-            if backend == "nccl":
+            if a2a:
+                order = [b for d in range(world) for b in parallel.owned_images(B, world, d)]
+                send = mine_buf[order].contiguous()
+                recv = torch.empty((world, len(mine), pad), dtype=torch.float32, device=dev)
+                dist.all_to_all_single(recv.view(-1), send.view(-1), output_split_sizes=[len(mine) * pad] * world,
+                                       input_split_sizes=[len(parallel.owned_images(B, world, d)) * pad for d in range(world)])
+            elif backend == "nccl":
                 dist.all_gather_into_tensor(gath.view(-1), mine_buf.view(-1))
             else:
                 dist.all_gather(list(gath.unbind(0)), mine_buf)
         _, t_gather = timed(ag)
-    _, t_mc = timed(lambda: [iso.marching_cubes(full[b], params[b], R, 0.0) for b in mine])
+    _, t_mc = timed(lambda: [iso.marching_cubes(full[i if a2a else b], params[b], R, 0.0) for i, b in enumerate(mine)])
     pts_rank = B * (k1 - k0)
     flop_pt = MLP_FLOP_PER_PT - 2 * 1472 * 512           # executed: local fold2/conv1 folded into the map
     peak = PEAK_FP32_MFMA_TFLOPS if args.unfused else PEAK_F16X2_TFLOPS
@@ -241,8 +253,8 @@ def grid_bench(args, torch, dist, dev, world, rank, launched, shared_gpu, backen
                    "seconds_per_image": dt / args.steps / B,
                    "point_mlp": "layer-by-layer GEMMs (three-term bf16)" if args.unfused else
                                 "fused kernels (two-term fp16, activations in registers)",
-                   "parallelism": "contiguous flat-index slices x%d, redundant encode, one all_gather (%s)%s" % (
-                       world, backend if launched else "none: single process",
+                   "parallelism": "contiguous flat-index slices x%d, redundant encode, one %s (%s)%s" % (
+                       world, args.exchange, backend if launched else "none: single process",
                        "; ranks SHARE GPUs (plumbing run, not a scaling measurement)" if shared_gpu else "")},
         "phases_rank0": {"encode_s": t_enc, "fold_local_s": t_fold, "grid_slice_s": t_grid,
                          "all_gather_s": t_gather, "marching_cubes_s": t_mc,
@@ -256,8 +268,9 @@ def grid_bench(args, torch, dist, dev, world, rank, launched, shared_gpu, backen
                      "note": "executed flops of this rank's grid slices / their wall time (gather from the "
                              "folded map and the final dot included in the time)"},
         "all_gather": None if t_gather is None else {
-            "bytes_received_per_rank": int(world * B * pad * 4), "seconds": t_gather,
-            "GB_per_s": world * B * pad * 4 / t_gather / 1e9, "backend": backend},
+            "exchange": args.exchange,
+            "bytes_received_per_rank": int(world * (len(mine) if a2a else B) * pad * 4), "seconds": t_gather,
+            "GB_per_s": world * (len(mine) if a2a else B) * pad * 4 / t_gather / 1e9, "backend": backend},
         "mesh": {"vertices": nv, "triangles": nf, "images_meshed_on_rank0": len(mine)},
     }
 
@@ -287,6 +300,9 @@ def main():
                          "cubes); train: config-5 training step")
     ap.add_argument("--grid-res", type=int, default=256)
     ap.add_argument("--grid-images", type=int, default=0, help="0: 1 image at N=1 (config 3), 8 at N>1 (config 4)")
+    ap.add_argument("--exchange", choices=("all_to_all", "all_gather"), default="all_to_all",
+                    help="--workload grid, N > 1: all_to_all = rank r receives the full grids of the images it meshes "
+                         "(1/N of the bytes); all_gather = every rank receives every grid")
     ap.add_argument("--unfused", action="store_true",
                     help="dense-grid / large queries through the layer-by-layer GEMM chain instead of the fused kernels")
     ap.add_argument("--dist-backend", choices=("auto", "nccl", "gloo"), default="auto",

@@ -10,8 +10,12 @@ gathers models/model_normalization.py:172-184).  Design:
     slices (z-slab like: the flat order is z-major), rank r evaluates slice r;
   * every rank runs the encoder redundantly (~0.4 ms; cheaper and simpler than broadcasting
     the 110 MB feature map over xGMI) -- no collective on the data path;
-  * ONE exchange step at the end: all_gather of the padded per-rank slices
-    ((R+1)^3/world fp32 per image, 8.5 MB per rank at R=256) into the ``.dist``-ordered buffer.
+  * ONE exchange step at the end.  ``exchange="all_gather"``: every rank ends with every image's full grid
+    (all_gather of the padded per-rank slices; world x B x (R+1)^3 / world floats received per rank -- 543 MB at
+    B = 8, R = 256).  ``exchange="all_to_all"``: rank r ends with the full grids of the images it OWNS (b % world
+    == r: the ones it meshes, test/create_sdf.py:277-289) -- one all_to_all_single, each rank receives only
+    (world - 1) / world of ITS images' points (68 MB per image at R = 256: 1/world of the all_gather's bytes) and
+    nothing is reassembled for images it never touches.
 
 ``query_fn(image_index, k0, k1) -> 1-D tensor`` is injected so the sharding / gather logic is
 testable on CPU with gloo; ``sharded_create_sdf`` binds it to the HIP engine.
@@ -37,22 +41,45 @@ def shard_sizes(total: int, world: int) -> List[int]:
     return [shard_range(total, world, r)[1] - shard_range(total, world, r)[0] for r in range(world)]
 
 
+def owned_images(n_images: int, world: int, rank: int) -> List[int]:
+    """images whose full grid ends on ``rank`` with exchange="all_to_all" (round robin, as bench.py meshes them)"""
+    return list(range(rank, n_images, world))
+
+
 def sharded_grid(query_fn: Callable[[int, int, int], torch.Tensor], n_images: int, total: int,
-                 device, group=None) -> torch.Tensor:
+                 device, group=None, exchange: str = "all_gather"):
     """Evaluate ``n_images`` grids of ``total`` points, sharded over the process group.
-    Returns the full [n_images, total] result on every rank."""
+    exchange="all_gather": returns the full [n_images, total] result on every rank.
+    exchange="all_to_all": returns ([n_owned, total], owned image indices) -- the full grids of this rank's images."""
+    if exchange not in ("all_gather", "all_to_all"):
+        raise ValueError("exchange must be 'all_gather' or 'all_to_all'")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     k0, k1 = shard_range(total, world, rank)
-    pad = (total + world - 1) // world           # all_gather needs equal sizes
+    pad = (total + world - 1) // world           # the collectives need equal sizes
     mine = torch.zeros((n_images, pad), dtype=torch.float32, device=device)
     for b in range(n_images):
         if k1 > k0:
             mine[b, :k1 - k0] = query_fn(b, k0, k1)
+    own = owned_images(n_images, world, rank)
     if world == 1 and not dist.is_initialized():
-        return mine[:, :total]
+        return mine[:, :total] if exchange == "all_gather" else (mine[:, :total], own)
     # (a one-rank process group still goes through the collective: the same RCCL call sequence as
     #  the 8-rank job, which is how the path is exercised on a single-GPU box)
+    if exchange == "all_to_all":
+        # destination d gets this rank's slice of the images d owns: rows reordered owner-major, one
+        # all_to_all_single with per-destination split sizes; from source s arrives s's slice of MY images
+        order = [b for d in range(world) for b in owned_images(n_images, world, d)]
+        send = mine[order].contiguous()
+        in_split = [len(owned_images(n_images, world, d)) * pad for d in range(world)]
+        recv = torch.empty((world, len(own), pad), dtype=torch.float32, device=device)
+        dist.all_to_all_single(recv.view(-1), send.view(-1), output_split_sizes=[len(own) * pad] * world,
+                               input_split_sizes=in_split, group=group)
+        out = torch.empty((len(own), total), dtype=torch.float32, device=device)
+        for r in range(world):
+            a, b_ = shard_range(total, world, r)
+            out[:, a:b_] = recv[r, :, :b_ - a]
+        return out, own
     gathered = torch.empty((world, n_images, pad), dtype=torch.float32, device=device)
     if _supports_flat(group):      # RCCL: one flat collective into the contiguous buffer
         dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
@@ -73,9 +100,10 @@ def _supports_flat(group) -> bool:
 
 
 def sharded_create_sdf(engine, imgs, trans_mats, sdf_params, sdf_res: int, sdf_weight: float = 10.0,
-                       group=None) -> torch.Tensor:
+                       group=None, exchange: str = "all_gather"):
     """BASELINE config 4: every rank encodes the batch, evaluates its slice of every image's
-    grid and the slices are gathered.  Returns [B,(res+1)^3] = pred_sdf / SDF_WEIGHT on every rank."""
+    grid and the slices are exchanged.  Returns [B,(res+1)^3] = pred_sdf / SDF_WEIGHT on every rank
+    (exchange="all_gather"), or ([n_owned,(res+1)^3], owned image indices) with exchange="all_to_all"."""
     import numpy as np
     from .create_sdf import dense_grid_sdf
     enc = engine.encode(imgs)
@@ -86,7 +114,7 @@ def sharded_create_sdf(engine, imgs, trans_mats, sdf_params, sdf_res: int, sdf_w
     def query_fn(b, k0, k1):
         return dense_grid_sdf(engine, enc, b, trans_mats, sp[b], sdf_res, sdf_weight, k_range=(k0, k1))
 
-    return sharded_grid(query_fn, B, total, engine.device, group)
+    return sharded_grid(query_fn, B, total, engine.device, group, exchange)
 
 
 # ---------------------------------------------------------------------------

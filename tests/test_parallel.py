@@ -27,7 +27,7 @@ def test_shard_range_properties():
         par.shard_range(10, 2, 2)
 
 
-def _worker(rank, world, port, total, n_images, q):
+def _worker(rank, world, port, total, n_images, q, exchange="all_gather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,8 +39,11 @@ def _worker(rank, world, port, total, n_images, q):
             k = torch.arange(k0, k1, dtype=torch.float64)
             return (torch.sin(k * 0.37 + b) * 3.0).to(torch.float32)
 
-        out = par.sharded_grid(query_fn, n_images, total, torch.device("cpu"))
-        q.put((rank, out.numpy(), calls))
+        out = par.sharded_grid(query_fn, n_images, total, torch.device("cpu"), exchange=exchange)
+        if exchange == "all_to_all":
+            q.put((rank, out[0].numpy(), calls, out[1]))
+        else:
+            q.put((rank, out.numpy(), calls))
     finally:
         dist.destroy_process_group()
 
@@ -68,6 +71,34 @@ def test_sharded_grid_gloo_world2(total, n_images):
         assert calls == [(b, k0, k1) for b in range(n_images)]   # every rank touched only its slice
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("total,n_images", [(125, 1), (4913, 3), (1000, 4)])
+def test_sharded_grid_all_to_all_gloo_world2(total, n_images):
+    """exchange="all_to_all": rank r ends with the FULL grids of the images it owns (b % world == r) and nothing else;
+    an odd image count gives the ranks different receive sizes"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + total + 333) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, n_images, q, "all_to_all")) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    k = np.arange(total, dtype=np.float64)
+    seen = []
+    for rank, out, calls, own in results:
+        assert own == par.owned_images(n_images, world, rank) and out.shape == (len(own), total)
+        for i, b in enumerate(own):
+            assert np.array_equal(out[i], (np.sin(k * 0.37 + b) * 3.0).astype(np.float32)), (rank, b)
+        k0, k1 = par.shard_range(total, world, rank)
+        assert calls == [(b, k0, k1) for b in range(n_images)]   # every rank still evaluates its slice of EVERY image
+        seen += own
+    assert sorted(seen) == list(range(n_images))
+
+
 def test_single_process_equals_unsharded():
     total = 343
 
@@ -76,6 +107,10 @@ def test_single_process_equals_unsharded():
 
     out = par.sharded_grid(query_fn, 2, total, torch.device("cpu"))
     assert torch.equal(out[1], torch.arange(total, dtype=torch.float32) + 1000)
+    out2, own = par.sharded_grid(query_fn, 2, total, torch.device("cpu"), exchange="all_to_all")
+    assert own == [0, 1] and torch.equal(out2, out)
+    with pytest.raises(ValueError):
+        par.sharded_grid(query_fn, 2, total, torch.device("cpu"), exchange="ring")
 
 
 # ---------------------------------------------------------------- data-parallel training ----------
