@@ -404,29 +404,32 @@ __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) voi
 }
 
 // ---------------------------------------------------------------------------------------------------
-// conv1_1 (models/CNN/vgg.py:187, 3 -> 64 channels, K = 27): 0.17 GFLOP -- not matrix-pipe work.  Direct fp32
-// FMA convolution: a workgroup walks 32-pixel row segments (grid-stride), stages their 3 x 34 x 3 input window in
-// LDS, thread (pixel pair, channel quad) keeps its 27 x 4 weights in registers for the whole walk and stores
-// 16-byte channel quads (16 lanes = one pixel = 256 contiguous bytes); per-workgroup maximum -> the 64 slots
-// the first conv_h2 layer scales by.
+// conv1_1 (models/CNN/vgg.py:187, 3 -> 64 channels, K = 27): 0.17 GFLOP per image -- not matrix-pipe work.  Direct fp32
+// FMA convolution: a workgroup walks tiles of 2 rows x 32 pixels (grid-stride), stages their 4 x 34 x 3 input window in
+// LDS as nine [row][channel] planes of 36 pixels, thread (row, group of 4 pixels, channel quad) keeps its 27 x 4 weights
+// in registers for the whole walk, reads its 6-pixel span of every plane with one 16-byte + one 8-byte LDS read
+// (24 + 12 reads per 432 FMAs; round 2: one 4-byte read per 4 FMAs -- LDS-issue bound, 53 us for eight images) and
+// stores 16-byte channel quads (16 lanes = one pixel = 256 contiguous bytes); per-workgroup maximum -> the 64 slots the
+// first conv_h2 layer scales by.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                              const float* __restrict__ bias, int B, int H, int W,
                                                              int relu, float* __restrict__ out,
                                                              float* __restrict__ out_amax, int amax_stride) {
-  __shared__ float win[2][3 * 34 * 3 + 2];
+  constexpr int PW = 40;                                 // plane pitch in floats (36 used; 160 B keeps 16-byte alignment)
+  __shared__ __attribute__((aligned(16))) float win[2][4 * 3 * PW];   // [buffer][row 0..3][channel][pixel -1 .. 34]
   __shared__ __attribute__((aligned(16))) float wl[27 * 64];
   __shared__ float red[4];
-  const int tid = threadIdx.x, c4 = tid & 15, pp = tid >> 4;  // pixels pp and pp + 16 of the segment
+  const int tid = threadIdx.x, c4 = tid & 15, pg = (tid >> 4) & 7, ry = tid >> 7;   // pixels 4 pg .. 4 pg + 3 of row ry
   for (int i = tid; i < 27 * 16; i += 256)  // the 6.9 KB of weights once per workgroup, then per thread from LDS
     reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(w)[i];
   __syncthreads();
-  float4 wr[27];
+  float4 wr[27];                                         // [r][dx][c] as in the TF tensor [3][3][3][64]
 #pragma unroll
   for (int k = 0; k < 27; ++k) wr[k] = *reinterpret_cast<const float4*>(&wl[k * 64 + 4 * c4]);
   const float4 bv = *reinterpret_cast<const float4*>(bias + 4 * c4);
-  const int segs_x = (W + 31) >> 5;
-  const long nseg = (long)B * H * segs_x;
+  const int segs_x = (W + 31) >> 5, rows2 = (H + 1) >> 1;
+  const long ntile = (long)B * rows2 * segs_x;
   float vmax = 0.f;
   int buf = 0, bcur = -1;
   // the maximum is kept per IMAGE (amax_stride floats between the images' slot groups): a workgroup that walks
@@ -443,36 +446,48 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
     __syncthreads();
     vmax = 0.f;
   };
-  for (long sg = blockIdx.x; sg < nseg; sg += gridDim.x, buf ^= 1) {
-    const int sx = (int)(sg % segs_x);
-    const long by = sg / segs_x;
-    const int y = (int)(by % H), b = (int)(by / H);
+  for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x, buf ^= 1) {
+    const int sx = (int)(tl % segs_x);
+    const long by = tl / segs_x;
+    const int y0 = 2 * (int)(by % rows2), b = (int)(by / rows2);
     if (out_amax && amax_stride && bcur >= 0 && b != bcur) flush(bcur);
     bcur = b;
     const int x0 = sx * 32;
     const float* img = in + (size_t)b * H * W * 3;
-    for (int i = tid; i < 3 * 34 * 3; i += 256) {  // window element (row r, pixel px, channel c)
+    for (int i = tid; i < 4 * 34 * 3; i += 256) {  // window element (row r, pixel px, channel c), read in memory order
       const int r = i / 102, rem = i - r * 102, px = rem / 3, c = rem - px * 3;
-      const int yy = y - 1 + r, xx = x0 - 1 + px;
-      win[buf][i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[((size_t)yy * W + xx) * 3 + c] : 0.f;
+      const int yy = y0 - 1 + r, xx = x0 - 1 + px;
+      win[buf][(r * 3 + c) * PW + px] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[((size_t)yy * W + xx) * 3 + c] : 0.f;
     }
-    __syncthreads();  // one barrier per segment: the other buffer is being read by nobody (everyone passed this point)
+    __syncthreads();  // one barrier per tile: the other buffer is being read by nobody (everyone passed this point)
+    float4 a[4] = {bv, bv, bv, bv};
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int px = pp + 16 * h;
-      float4 a = bv;
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        const float* pl = &win[buf][((ry + r) * 3 + c) * PW + 4 * pg];
+        const float4 v0 = *reinterpret_cast<const float4*>(pl);        // window pixels 4 pg .. 4 pg + 3 (image x0 - 1 + ..)
+        const float2 v1 = *reinterpret_cast<const float2*>(pl + 4);    // 4 pg + 4, 4 pg + 5
+        const float v[6] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y};
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {  // q = dx * 3 + c: nine consecutive floats of the window row
-          const float v = win[buf][r * 102 + px * 3 + q];
-          const float4 ww = wr[r * 9 + q];
-          a.x = fmaf(v, ww.x, a.x); a.y = fmaf(v, ww.y, a.y); a.z = fmaf(v, ww.z, a.z); a.w = fmaf(v, ww.w, a.w);
+        for (int dx = 0; dx < 3; ++dx) {
+          const float4 ww = wr[(r * 3 + dx) * 3 + c];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            a[p].x = fmaf(v[p + dx], ww.x, a[p].x); a[p].y = fmaf(v[p + dx], ww.y, a[p].y);
+            a[p].z = fmaf(v[p + dx], ww.z, a[p].z); a[p].w = fmaf(v[p + dx], ww.w, a[p].w);
+          }
         }
-      if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-      if (x0 + px < W) {
-        *reinterpret_cast<float4*>(out + (((size_t)b * H + y) * W + x0 + px) * 64 + 4 * c4) = a;
-        vmax = fmaxf(fmaxf(fmaxf(vmax, fabsf(a.x)), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+      }
+    const int y = y0 + ry;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float4 o = a[p];
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      const int x = x0 + 4 * pg + p;
+      if (y < H && x < W) {
+        *reinterpret_cast<float4*>(out + (((size_t)b * H + y) * W + x) * 64 + 4 * c4) = o;
+        vmax = fmaxf(fmaxf(fmaxf(vmax, fabsf(o.x)), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
       }
     }
   }
@@ -482,8 +497,8 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
 // w: the TF tensor [3][3][3][64] as is; out_amax: 64 slots (per image when amax_stride > 0) zeroed by the caller, or nullptr
 hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu,
                                  float* out, float* out_amax, hipStream_t st, int amax_stride) {
-  const long nseg = (long)B * H * ((W + 31) / 32);
-  const int grid = (int)(nseg < 512 ? nseg : 512);  // two workgroups per CU, ~3 segments each at 224 x 224
+  const long ntile = (long)B * ((H + 1) / 2) * ((W + 31) / 32);
+  const int grid = (int)(ntile < 512 ? ntile : 512);  // two workgroups per CU (214 registers), ~12 tiles each at eight 224 x 224 images
   hipLaunchKernelGGL(conv1_1_direct_kernel, dim3(grid), dim3(256), 0, st, in, w_hwio, bias, B, H, W, relu, out, out_amax, amax_stride);
   return hipGetLastError();
 }

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dense_h2w_kernel(const Dens
   // chunk's rows are requested at the top and split into the other buffer between the MFMAs of the later pairs --------
   static_assert(MB % 2 == 0, "pairs of row blocks");
   constexpr int S = KC * MB, NP = S / 2, NB = 4;
-  constexpr int P0 = NP / 2;           // first pair that carries a unit of the next chunk
+  constexpr int P0 = NP - LP > NP / 2 ? NP / 2 : NP - LP;   // first pair that carries a unit of the next chunk
   static_assert(LP <= NP - P0, "loader units per thread");
   auto chunk = [&](int c, auto more_c) {
     constexpr bool MORE = decltype(more_c)::value;
@@ -259,16 +259,28 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dense_h2w_kernel(const Dens
 }
 
 bool dense_h2w_supported(const DenseH2Prob& p) {
-  return p.M >= 128 && p.N % 256 == 0 && p.K % 128 == 0 && (p.k1 == p.K || p.k1 % 128 == 0) && p.k_begin % 16 == 0 &&
+  return p.M >= 128 && p.N % 256 == 0 && p.K % 64 == 0 && (p.k1 == p.K || p.k1 % 64 == 0) && p.k_begin % 16 == 0 &&
          (p.amax_rows == 0 || p.amax_rows % 128 == 0) && (size_t)p.M * (p.ldc > p.lda ? p.ldc : p.lda) < ((size_t)1 << 31);
 }
 
-// 1 or 2 problems of ONE shape (validated by dense_h2_launch) through the batched form
+// 1 or 2 problems of ONE shape (validated by dense_h2_launch) through the batched form.  Tile rows and chunk width are
+// speed knobs only (K is summed in ascending order in one accumulator whatever they are): 128-column chunks where K and
+// the source boundary allow, else 64 (fold1/conv2: K = 64); 64-row tiles where 128-row ones would leave half the chip
+// idle (the 256-column layers of an eight-step call: 128 -> 256 workgroups).
 hipError_t dense_h2w_go(DenseH2Dev d, hipStream_t st) {
   const DenseH2Prob& p = d.p[0];
-  d.mtiles = (p.M + 127) / 128;
+  const bool c128 = p.K % 128 == 0 && (p.k1 == p.K || p.k1 % 128 == 0);
+  const long wg128 = (long)((p.M + 127) / 128) * (p.N / 256) * d.nprob;
+  const bool m64 = wg128 < 200;
+  d.mtiles = (p.M + (m64 ? 63 : 127)) / (m64 ? 64 : 128);
   const dim3 grid(d.mtiles * (p.N / 256), d.nprob);
-  hipLaunchKernelGGL((dense_h2w_kernel<4, 8, 8>), grid, dim3(512), 0, st, d);
+  if (m64) {
+    if (c128) hipLaunchKernelGGL((dense_h2w_kernel<2, 8, 8>), grid, dim3(512), 0, st, d);
+    else hipLaunchKernelGGL((dense_h2w_kernel<2, 8, 4>), grid, dim3(512), 0, st, d);
+  } else {
+    if (c128) hipLaunchKernelGGL((dense_h2w_kernel<4, 8, 8>), grid, dim3(512), 0, st, d);
+    else hipLaunchKernelGGL((dense_h2w_kernel<4, 8, 4>), grid, dim3(512), 0, st, d);
+  }
   return hipGetLastError();
 }
 

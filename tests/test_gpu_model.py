@@ -144,6 +144,39 @@ def test_session_loop_like_create_sdf():
     report_close("session loop vs device driver", dev_res, result, 2e-6, 1e-6)
 
 
+def test_cfg1_full_demo_grid_against_golden(kat):
+    """BASELINE config 1 IN FULL (demo/demo.py:263-339: the chair image, the ground-truth camera, sdf_res 64): all
+    274 625 grid points in .dist order plus the pad point of the demo's padded splits, against the float64 oracle run
+    stored in tests/golden/cfg1_full65.npz (tests/golden/make_golden_cfg1.py) -- through (a) the reference's own
+    per-split sess.run loop with its zero padding (demo/demo.py:292-328), (b) the device-side dense-grid driver."""
+    import os
+    from disn_amd import create_sdf as cs
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg1_full65.npz"))["pred64"]
+    R = 64
+    total, split, nsp, pad = cs.split_plan(R)
+    assert total == 65 ** 3 == gold.size - 1 and pad >= 1
+    img = (kat["demo_img"].astype(np.float32) / np.float32(255.0))
+    sess = _session("he")
+    pls, ep = _graph(1, nsp)
+    sdf_params = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    pts = np.concatenate([cs.grid_points_host(sdf_params, R), np.zeros((pad, 3), np.float32)], 0).reshape(split, 1, nsp, 3)
+    acc = np.zeros((split, 1, nsp, 1), np.float32)
+    for sp in range(split):                                   # demo/demo.py:311-326
+        feed = {pls["sample_pc"]: pts[sp], pls["sample_pc_rot"]: pts[sp], pls["imgs"]: img,
+                pls["trans_mat"]: O.DEMO_TRANS_MAT}
+        acc[sp] = sess.run(ep["pred_sdf"], feed_dict=feed)
+    flat = acc.reshape(-1)
+    err = float(np.abs(flat[:total] - gold[:total]).max())
+    err_pad = float(np.abs(flat[total:] - gold[total]).max())   # every pad point is (0, 0, 0)
+    print("cfg1 full grid, session loop: max |gpu - f64| %.3g over %d points (|pred| max %.3g); pad point %.3g" % (
+        err, total, float(np.abs(gold).max()), err_pad))
+    assert err <= PRED_ATOL and err_pad <= PRED_ATOL
+    dev = cs.create_sdf(sess.engine, img, O.DEMO_TRANS_MAT, sdf_params[None], R)[0].cpu().numpy()
+    err_dev = float(np.abs(dev.astype(np.float64) * 10.0 - gold[:total]).max())
+    print("cfg1 full grid, device driver (fused point MLP, pred / 10): max |10 gpu - f64| %.3g" % err_dev)
+    assert err_dev <= PRED_ATOL
+
+
 def test_full_size_grid_properties():
     """BASELINE config 3 size (257^3 = 16 974 593 points): properties that need no oracle run.
     (a) any slice of the full-grid result equals the same slice evaluated alone;

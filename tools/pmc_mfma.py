@@ -1,7 +1,9 @@
 """MFMA utilisation per kernel from one rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass over
 tools/prof_mfma.py.  SQ_VALU_MFMA_BUSY_CYCLES sums, over all 1024 SIMDs, the cycles their matrix pipe was busy (32 per
-v_mfma_f32_32x32x16_f16: MI355X_MICROARCH.md); GRBM_GUI_ACTIVE = the dispatch's duration in shader clocks.
-utilisation = busy / (1024 x GRBM_GUI_ACTIVE); effective clock = GRBM_GUI_ACTIVE / duration.
+v_mfma_f32_32x32x16_f16: MI355X_MICROARCH.md; checked: conv2_2 of eight images = 2 709 504 MFMAs x 32 = the counter to
+the digit); GRBM_GUI_ACTIVE is reported SUMMED OVER THE 8 XCDs (17 "GHz" against the dispatch's duration), so one
+XCD's active shader cycles are GRBM_GUI_ACTIVE / 8.
+utilisation = busy / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); effective clock = GRBM_GUI_ACTIVE / 8 / duration.
 usage: python tools/pmc_mfma.py <counter_collection.csv> > profiles/r03x_pmc_mfma.txt"""
 import collections, csv, sys
 
@@ -24,9 +26,9 @@ print("%-52s %9s %9s %14s %12s %7s %6s" % ("kernel", "grid", "us", "mfma busy cy
 tot = {}
 for (name, grid), e in last.items():
     busy, gui = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), e.get("GRBM_GUI_ACTIVE", 0.0)
-    util = busy / (1024.0 * gui) if gui else 0.0
+    util = busy / (128.0 * gui) if gui else 0.0
     print("%-52s %9d %9.1f %14.0f %12.0f %6.1f%% %6.2f" % (name[:52], grid, e["ns"] / 1e3, busy, gui, 100 * util,
-                                                          gui / e["ns"] if e["ns"] else 0))
+                                                          gui / 8.0 / e["ns"] if e["ns"] else 0))
     fam = "conv (8 images)" if ("conv_h2w" in name or (("conv_h2_kernel" in name) and grid >= 400000)) else \
           "conv (1 image)" if "conv_h2_kernel" in name else "dense_h2w (16384 rows)" if "dense_h2w" in name else \
           "dense_h2 (2048 rows)" if "dense_h2" in name else None
@@ -36,4 +38,4 @@ for (name, grid), e in last.items():
 print("# per family (sums over the rows above)")
 for fam, (busy, gui, ns) in tot.items():
     print("%-28s busy %14.0f  gui active %12.0f  duration %8.1f us  utilisation %5.1f%%" % (fam, busy, gui, ns / 1e3,
-                                                                                         100 * busy / (1024 * gui) if gui else 0))
+                                                                                         100 * busy / (128 * gui) if gui else 0))
