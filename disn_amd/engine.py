@@ -49,7 +49,11 @@ class DeviceWeights:
             w = store["vgg_16/%s/weights" % nm]
             wkn = w.reshape(-1, w.shape[3])
             v.fc_w[i] = dev(wkn).data_ptr()   # [K][N], K=(h,w,c) = NHWC flatten
-            v.fc_w_t[i] = dev(wkn.T).data_ptr()   # [N][K]: one launch per layer, no split-K partials (gemv_rows_kernel)
+            # [N][K]: one launch per layer, no split-K partials (gemv_rows_kernel) -- fc7 / fc8 only: fc6 stays on the
+            # split-K stream kernel (api.hip vgg_head passes no transposed matrix for it), so its 411 MB transpose is
+            # neither built nor uploaded
+            if i > 0:
+                v.fc_w_t[i] = dev(wkn.T).data_ptr()
             v.fc_b[i] = dev(store["vgg_16/%s/biases" % nm]).data_ptr()
         v.num_classes = store.num_classes
         self.vgg = v
@@ -141,7 +145,9 @@ class SdfEngine:
     def __init__(self, store: Optional[WeightStore], device: Optional[torch.device] = None, fused: bool = True,
                  conv_h2: bool = True, weights: Optional[DeviceWeights] = None):
         """``weights``: share the device weights of another engine (``store`` is then ignored): several engine
-        contexts -- each with its own workspaces and auxiliary stream -- over one copy of the 560 MB"""
+        contexts -- each with its own workspaces and auxiliary stream -- over one copy of the ~0.85 GB of device weights
+        (fc6..fc8 as [K][N] 495 MB, fc7 / fc8 transposed 84 MB, the convolutions in three packed forms 206 MB, the
+        point MLPs and their images ~50 MB)"""
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         if not torch.cuda.is_available():

@@ -652,6 +652,14 @@ def write_checkpoint_state(directory: str, model_checkpoint_path: str, all_paths
             f.write('all_model_checkpoint_paths: "%s"\n' % p)
 
 
+def all_checkpoint_paths(directory: str) -> List[str]:
+    """the all_model_checkpoint_paths entries of the directory's state file, oldest first ([] if absent)"""
+    p = os.path.join(directory, "checkpoint")
+    if not os.path.exists(p):
+        return []
+    return re.findall(r'^all_model_checkpoint_paths:\s*"([^"]*)"', open(p).read(), flags=re.M)
+
+
 def get_checkpoint_state(directory: str) -> Optional[str]:
     """tf.train.get_checkpoint_state(dir).model_checkpoint_path (test/create_sdf.py:182-185):
     the prefix of the latest checkpoint, resolved relative to ``directory``; None if absent."""

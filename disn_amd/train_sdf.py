@@ -71,22 +71,34 @@ class FlatParams:
         return out
 
 
-def step_from_checkpoint(arrays: Dict[str, np.ndarray], beta2: float, current: int = 0) -> int:
-    """the global step a restored bundle stands at.  `batch` (the reference's step variable,
-    train/train_sdf.py:232,268) when the bundle has it; otherwise recovered from Adam's beta2_power =
-    beta2^(t+1) while that is a usable float32 (t < ~8e4: it goes denormal near 8.7e4 steps and reaches 0 near
-    1.03e5); a power of exactly 0 means the run is past that point: bias correction is saturated (lr_t == lr, as in
-    TF, which keeps multiplying the zero) and the schedule position is unknown, so the caller's step is kept, but
-    never below the underflow point -- the schedule must not silently restart at 0."""
-    gs = arrays.get("batch")
+def adam_step_from_checkpoint(arrays: Dict[str, np.ndarray], beta2: float, current: int = 0,
+                              underflow_step: Optional[int] = None) -> int:
+    """Adam's timestep t of a restored bundle, from its slot variable beta2_power = beta2^(t+1) -- what a TF restore
+    gives the optimizer back (train/train_sdf.py:285-286 saves every global variable except those named 'lr' / 'batch',
+    so beta1_power / beta2_power ARE in a reference bundle; TF keeps multiplying them and uses
+    lr_t = lr sqrt(1 - beta2_power) / (1 - beta1_power)).  While the power is a usable float32 (t < ~8e4; it goes
+    denormal near 8.7e4 steps and reaches 0 near 1.03e5) t is recovered exactly; a power of exactly 0 means the bias
+    correction is saturated (lr_t == lr in TF as well): ``underflow_step`` is then returned -- an explicit caller choice;
+    None = max(current, 200000), any t at which beta2^t is 0 in the arithmetic of apply_gradients.  No beta2_power in
+    the bundle: ``current``."""
     b2 = arrays.get("beta2_power")
-    if gs is not None and np.asarray(gs).size == 1:
-        return max(int(np.asarray(gs).reshape(())), 0)
     if b2 is not None and 0.0 < float(b2) < 1.0:
         return max(int(round(math.log(float(b2)) / math.log(beta2))) - 1, 0)
     if b2 is not None and float(b2) == 0.0:
-        return max(int(current), 104000)
+        return int(underflow_step) if underflow_step is not None else max(int(current), 200000)
     return int(current)
+
+
+def schedule_step_from_checkpoint(arrays: Dict[str, np.ndarray]) -> int:
+    """the step the learning-rate schedule resumes at.  The reference's Saver leaves `batch` (its global step,
+    train/train_sdf.py:232) OUT of every bundle (:285-286: names containing 'lr' or 'batch' are filtered), so a
+    restored reference run restarts the schedule at step 0 with lr = base_lr -- and so does this function for a
+    reference-written bundle.  A bundle written by Trainer.save(include_step=True) carries `batch` (an extension of
+    this implementation, off by default) and resumes there."""
+    gs = arrays.get("batch")
+    if gs is not None and np.asarray(gs).size == 1:
+        return max(int(np.asarray(gs).reshape(())), 0)
+    return 0
 
 
 class Trainer:
@@ -112,7 +124,8 @@ class Trainer:
         self.grads = self.flat.zeros()
         self.m = self.flat.zeros()
         self.v = self.flat.zeros()
-        self.step_count = 0  # the reference's `batch` variable (global step)
+        self.step_count = 0  # the reference's `batch` variable (global step): drives the learning-rate schedule
+        self.adam_t = 0      # Adam's timestep (TF keeps it as beta1_power / beta2_power): drives the bias correction
         self.batch_size = batch_size  # GLOBAL batch (all ranks), as the LR schedule counts samples
         self.base_lr, self.decay_step, self.decay_rate = base_lr, decay_step, decay_rate
         self.wd, self.sdf_weight, self.mask_weight = wd, sdf_weight, mask_weight
@@ -166,13 +179,14 @@ class Trainer:
 
     def apply_gradients(self) -> float:
         lr = self.learning_rate()
-        t = self.step_count + 1
+        t = self.adam_t + 1
         lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
         with torch.cuda.device(self.params.device):
             self.reducer.finish(self.grads)
             ops.adam_update(self.params, self.grads, self.m, self.v, lr_t, self.beta1, self.beta2, self.eps,
                             1.0 / self.world)
-        self.step_count = t
+        self.adam_t = t
+        self.step_count += 1
         return lr
 
     def step(self, feed: Dict[str, torch.Tensor]):
@@ -182,30 +196,39 @@ class Trainer:
         return pred, {n: losses[i] for i, n in enumerate(LOSS_NAMES)}, lr
 
     # ---- checkpoints --------------------------------------------------------------------
-    def state_arrays(self) -> Dict[str, np.ndarray]:
+    def state_arrays(self, include_step: bool = False) -> Dict[str, np.ndarray]:
+        """what the reference's Saver writes (train/train_sdf.py:285-286): every variable, the Adam slots and the two
+        beta powers -- NOT `batch` / the learning rate.  include_step: also `batch` (int32, as TF creates it), an
+        extension that lets restore() resume the learning-rate schedule (see schedule_step_from_checkpoint)."""
         out = self.flat.to_arrays(self.params)
         out.update(self.flat.to_arrays(self.m, "/Adam"))
         out.update(self.flat.to_arrays(self.v, "/Adam_1"))
-        out["beta1_power"] = np.asarray(self.beta1 ** (self.step_count + 1), np.float32)
-        out["beta2_power"] = np.asarray(self.beta2 ** (self.step_count + 1), np.float32)
-        # the reference's global step (train/train_sdf.py:232 `batch = tf.Variable(0, name='batch')`, :268
-        # minimize(global_step=batch)), int32 as TF creates it: the step is restored from HERE -- beta2_power
-        # underflows float32 after ~1e5 steps
-        out["batch"] = np.asarray(self.step_count, np.int32)
+        out["beta1_power"] = np.asarray(self.beta1 ** (self.adam_t + 1), np.float32)
+        out["beta2_power"] = np.asarray(self.beta2 ** (self.adam_t + 1), np.float32)
+        if include_step:
+            out["batch"] = np.asarray(self.step_count, np.int32)
         return out
 
     def weight_store(self) -> WeightStore:
         return WeightStore(self.flat.to_arrays(self.params))
 
-    def save(self, prefix: str) -> None:
-        """variables + Adam slots + step as a TF Saver-V2 bundle, and the `checkpoint` state file next to it
-        (what saver.save writes, train/train_sdf.py:285-286), so that restore_latest / get_checkpoint_state find it"""
+    def save(self, prefix: str, include_step: bool = False, max_to_keep: int = 5) -> None:
+        """variables + Adam slots + beta powers as a TF Saver-V2 bundle, and the `checkpoint` state file next to it
+        (what saver.save writes, train/train_sdf.py:285-286,322-328), so that restore_latest / get_checkpoint_state
+        find it.  The state file keeps the last ``max_to_keep`` prefixes in all_model_checkpoint_paths, as
+        tf.train.Saver does (older bundles stay on disk here; TF would delete them)."""
         from . import tf_checkpoint as tfc
-        tfc.save_checkpoint(prefix, self.state_arrays())
-        tfc.write_checkpoint_state(os.path.dirname(os.path.abspath(prefix)), os.path.basename(prefix))
+        tfc.save_checkpoint(prefix, self.state_arrays(include_step))
+        d = os.path.dirname(os.path.abspath(prefix))
+        base = os.path.basename(prefix)
+        paths = [p for p in tfc.all_checkpoint_paths(d) if p != base] + [base]
+        tfc.write_checkpoint_state(d, base, paths[-max(1, int(max_to_keep)):])
 
-    def restore(self, prefix: str) -> int:
-        """prefix + exact-shape match, as load_model (train/train_sdf.py:190-219); -> #restored"""
+    def restore(self, prefix: str, underflow_step: Optional[int] = None) -> int:
+        """prefix + exact-shape match, as load_model (train/train_sdf.py:190-219); -> #restored.  Adam's timestep comes
+        back from beta2_power (adam_step_from_checkpoint; ``underflow_step`` for a power that underflowed to 0), the
+        learning-rate schedule restarts at 0 unless the bundle carries `batch` (schedule_step_from_checkpoint) -- the
+        reference's behaviour for its own bundles."""
         from . import tf_checkpoint as tfc
         arrays = tfc.load_checkpoint(prefix)
         n = 0
@@ -215,7 +238,8 @@ class Trainer:
                 if a is not None and tuple(a.shape) == tuple(self.flat.shapes[name]):
                     self.flat.view(buf, name).copy_(torch.from_numpy(np.ascontiguousarray(a, np.float32)))
                     n += 1
-        self.step_count = step_from_checkpoint(arrays, self.beta2, self.step_count)
+        self.adam_t = adam_step_from_checkpoint(arrays, self.beta2, self.adam_t, underflow_step)
+        self.step_count = schedule_step_from_checkpoint(arrays)
         return n
 
 

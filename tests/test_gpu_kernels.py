@@ -291,7 +291,7 @@ def test_external_kat_resize_and_resampler(ops):
     import json
     from conftest import GOLDEN
     k = json.load(open(os.path.join(GOLDEN, "external_kat.json")))
-    for nm in ("resize_up", "resize_down"):
+    for nm in ["resize_up", "resize_down"] + sorted(n for n in k if n.startswith("resize_exact")):
         x = np.asarray(k[nm]["in"], np.float32).reshape(k[nm]["in_shape"])
         oh, ow = k[nm]["out_hw"]
         got = host(ops.resize_bilinear(dev(x), oh, ow)).ravel()

@@ -267,6 +267,7 @@ def test_training_reduces_the_loss():
 
 
 def test_checkpoint_roundtrip_with_adam_slots(tmp_path, small_step):
+    from disn_amd import tf_checkpoint as tfc_mod
     from disn_amd.train_sdf import Trainer
     from disn_amd.weights import WeightStore
     s = small_step
@@ -276,12 +277,21 @@ def test_checkpoint_roundtrip_with_adam_slots(tmp_path, small_step):
     prefix = str(tmp_path / "model.ckpt")
     tr.save(prefix)
     tr2 = Trainer(WeightStore(O.init_weights(99, "he")), batch_size=2)
-    assert tr2.restore(prefix) == 3 * 56 and tr2.step_count == 2
+    assert tr2.restore(prefix) == 3 * 56
+    # as a restored reference run: Adam's timestep back from beta2_power, the learning-rate schedule at step 0
+    # (the reference's Saver leaves `batch` out of the bundle, train/train_sdf.py:285-286)
+    assert tr2.adam_t == 2 and tr2.step_count == 0 and "batch" not in tfc_mod.load_checkpoint(prefix)
     assert torch.equal(tr.params, tr2.params) and torch.equal(tr.m, tr2.m) and torch.equal(tr.v, tr2.v)
     # saver.save also writes the `checkpoint` state file: the latest-checkpoint lookup finds the bundle
     from disn_amd import tf_checkpoint as tfc
     assert tfc.get_checkpoint_state(str(tmp_path)) == prefix
-    assert int(tfc.load_checkpoint(prefix)["batch"]) == 2
+    tr.save(str(tmp_path / "model2.ckpt"), include_step=True)          # the opt-in extension + the state file's history
+    assert int(tfc.load_checkpoint(str(tmp_path / "model2.ckpt"))["batch"]) == 2
+    assert tfc.all_checkpoint_paths(str(tmp_path)) == ["model.ckpt", "model2.ckpt"]
+    tr3 = Trainer(WeightStore(O.init_weights(98, "he")), batch_size=2)
+    tr3.restore(str(tmp_path / "model2.ckpt"))
+    assert tr3.step_count == 2 and tr3.adam_t == 2
+    tr3.close()
     tr.step(feed); tr2.step(feed)
     mlp = slice(int(tr.flat.layout.offset[32]), tr.flat.total)
     assert torch.equal(tr.params[mlp], tr2.params[mlp])

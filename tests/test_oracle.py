@@ -208,7 +208,9 @@ def test_external_kat_tensorflow_resize_vectors():
     """TensorFlow's own unit-test vectors for the legacy bilinear resize (image_ops_test.py,
     ResizeImagesTest): the one pin of the TF-executed arithmetic that does not come from this repo"""
     k = _external_kat()
-    for nm in ("resize_up", "resize_down"):
+    names = ["resize_up", "resize_down"] + sorted(n for n in k if n.startswith("resize_exact"))
+    assert len(names) >= 7          # + the vectors derived with exact rational arithmetic (make_external_resize.py):
+    for nm in names:                # the 137 -> 224, 14 -> 137 and 224 -> 137 rows of the path and two small grids
         x = np.asarray(k[nm]["in"], np.float32).reshape(k[nm]["in_shape"])
         oh, ow = k[nm]["out_hw"]
         assert np.array_equal(O.resize_bilinear_legacy(x, oh, ow).ravel(), np.asarray(k[nm]["out"], np.float32)), nm

@@ -118,21 +118,26 @@ def test_full_model_bundle_roundtrip(tmp_path):
     assert tfc.get_checkpoint_state(os.path.dirname(prefix)) == prefix
 
 
-def test_step_recovery_from_a_bundle():
-    """the step comes from the `batch` variable; beta2_power is only a fallback and an underflowed
-    power never resets the schedule to step 0"""
-    import math
+def test_step_recovery_from_a_bundle(tmp_path):
+    """the reference's Saver leaves `batch` out of its bundles (train/train_sdf.py:285-286), so a restore
+    restarts the learning-rate schedule at 0 and Adam's timestep comes back from beta2_power; `batch` in a bundle is
+    this implementation's opt-in extension; an underflowed power gives the caller's explicit step"""
     import pytest
     pytest.importorskip("torch")
-    from disn_amd.train_sdf import step_from_checkpoint
+    from disn_amd.train_sdf import adam_step_from_checkpoint, schedule_step_from_checkpoint
     b2 = 0.999
-    assert step_from_checkpoint({"batch": np.asarray(123456, np.int32), "beta2_power": np.float32(0.0)}, b2) == 123456
     for t in (0, 1, 999, 50000):
-        assert step_from_checkpoint({"beta2_power": np.float32(b2 ** (t + 1))}, b2) == t
-    assert step_from_checkpoint({"beta2_power": np.float32(0.0)}, b2, current=0) >= 100000
-    assert step_from_checkpoint({"beta2_power": np.float32(0.0)}, b2, current=250000) == 250000
-    assert step_from_checkpoint({}, b2, current=7) == 7
+        assert adam_step_from_checkpoint({"beta2_power": np.float32(b2 ** (t + 1))}, b2) == t
+    assert adam_step_from_checkpoint({"beta2_power": np.float32(0.0)}, b2, current=0) >= 200000
+    assert adam_step_from_checkpoint({"beta2_power": np.float32(0.0)}, b2, current=0, underflow_step=123456) == 123456
+    assert adam_step_from_checkpoint({}, b2, current=7) == 7
     assert np.float32(b2 ** 104000) == 0.0 and np.float32(b2 ** 99000) > 0   # where float32 gives up
+    assert schedule_step_from_checkpoint({"beta2_power": np.float32(0.5)}) == 0          # a reference bundle
+    assert schedule_step_from_checkpoint({"batch": np.asarray(123456, np.int32)}) == 123456
+    # the state file keeps a history (tf.train.Saver's all_model_checkpoint_paths)
+    d = str(tmp_path)
+    tfc.write_checkpoint_state(d, "m-2", ["m-1", "m-2"])
+    assert tfc.all_checkpoint_paths(d) == ["m-1", "m-2"] and tfc.get_checkpoint_state(d) == os.path.join(d, "m-2")
 
 
 # ---------------------------------------------------------------------------------------------------------------
