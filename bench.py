@@ -284,16 +284,19 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2,
                     help="--workload query: independent submissions in flight on this GPU (disn_amd.engine.StepPipeline: "
                          "one HIP stream + host thread per context); 1 = one at a time")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=16,
                     help="--workload query: consecutive independent steps (image + 2048 points each) submitted as ONE "
                          "disn_encode_query call (StepPipeline(batch=)); every image keeps its own activation scales, "
                          "so its result is bit for bit the single-step one; 1 = one step per call")
     ap.add_argument("--spinup-s", type=float, default=0.25,
                     help="--workload query: seconds of untimed set-up steps before the --warmup steps (clock ramp, "
                          "allocator pools); 0 = none")
-    ap.add_argument("--balance", type=int, default=1,
+    ap.add_argument("--balance", type=int, default=0,
                     help="--workload query: 1 = the K steps of a run are cut into calls of equal size (a multiple of "
                          "--in-flight calls, none longer than --batch) instead of full calls + a short last one")
+    ap.add_argument("--pack-short", type=int, default=1,
+                    help="--workload query: 1 = a run of fewer than two calls per context puts its full calls back to back "
+                         "on one context and the remainder call beside them (StepPipeline.pack_short_runs); 0 = round robin")
     ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--workload", choices=("query", "grid", "train"), default="query",
                     help="query: BASELINE.json metric (default); grid: configs 3/4 (dense grid + gather + marching "
@@ -373,6 +376,7 @@ def main():
     S = max(1, args.in_flight)
     SB = max(1, args.batch)
     pipe = StepPipeline(store, dev, in_flight=S, batch=SB)
+    pipe.pack_short_runs = bool(args.pack_short)
     eng = pipe.engines[0]
     rng = np.random.default_rng(1000 + rank)
     # every step of a call -- and of the calls in flight beside it -- has its own image, point set and camera:
@@ -398,8 +402,11 @@ def main():
     # timed region), which is what timeit's gc.disable() is for.
     import gc
     t1 = time.perf_counter()
+    # (with the call sizes of the timed run: K steps cut the same way -- a call size seen for the first time inside
+    # the timed region costs allocator work, measured up to 5 ms once: r03n)
+    rehearsal = args.steps if args.steps <= 8 * S * SB else 4 * S * SB
     while time.perf_counter() - t1 < args.spinup_s:
-        run_steps(4 * S * SB)
+        run_steps(rehearsal)
         torch.cuda.synchronize()
     gc.collect()
     gc.freeze()

@@ -111,7 +111,7 @@ int conv3x3_impl(const float* in, int B, int H, int W, int Cin, const float* w_p
 // ---- point MLP ----------------------------------------------------------------
 const int kChunk = 65536;  // points per MLP pass inside disn_query / disn_sdf_mlp
 
-const int kH2Imgs = 16;  // images per call the dense_h2 path keeps maximum slots for
+const int kH2Imgs = 32;  // images per call the dense_h2 path keeps maximum slots for (32 x 2048 points = kChunk)
 
 struct MlpWs {
   // local stream: e1l -> h256 -> h512a -> (with feat) h512b -> l5

@@ -16,7 +16,7 @@ fi
 if has bench; then
   timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err; echo "bench (driver's command) exit $?"; tail -2 $OUT/bench_driver_cmd.err
   timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; tail -3 $OUT/bench.err
-  for v in "--batch 1 --in-flight 1" "--batch 1 --in-flight 3" "--batch 2 --in-flight 2" "--batch 4 --in-flight 1" "--batch 4 --in-flight 2" "--batch 8 --in-flight 1" "--batch 16 --in-flight 2" "--steps 20 --warmup 5"; do
+  for v in "--batch 1 --in-flight 1" "--batch 1 --in-flight 3" "--batch 2 --in-flight 2" "--batch 4 --in-flight 1" "--batch 4 --in-flight 2" "--batch 8 --in-flight 1" "--batch 8 --in-flight 2" "--batch 16 --in-flight 1" "--steps 20 --warmup 5"; do
     echo "variant $v" | tee -a $OUT/bench_variants.txt
     timeout 120 python bench.py $(case "$v" in *--steps*) ;; *) echo --steps 240 --warmup 24;; esac) $v --no-extras 2>/dev/null | tail -1 | cut -c1-260 | tee -a $OUT/bench_variants.txt
   done
@@ -29,8 +29,8 @@ if has prof; then
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profm_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 8 --no-extras > /tmp/profm_$TAG.log 2>&1; echo "rocprof main exit $?")
   for f in $(find /tmp/profm_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/bench_kernel_stats.csv; done
   # (a2) one call of eight steps at a time: the launch sequence of a batched call
-  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/profb4_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 24 --warmup 8 --no-extras --in-flight 1 --batch 8 --spinup-s 0 > /tmp/profb4_$TAG.log 2>&1; echo "rocprof b4 exit $?")
-  python tools/trace_step.py $(find /tmp/profb4_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null | grep -v "at::native\|rocclr_copy" > $OUT/infer_call_b8_trace.txt; tail -2 $OUT/infer_call_b8_trace.txt
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/profb4_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 24 --warmup 8 --no-extras --in-flight 1 --batch 16 --spinup-s 0 > /tmp/profb4_$TAG.log 2>&1; echo "rocprof b4 exit $?")
+  python tools/trace_step.py $(find /tmp/profb4_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null | grep -v "at::native\|rocclr_copy" > $OUT/infer_call_b16_trace.txt; tail -2 $OUT/infer_call_b16_trace.txt
   # (b) one step at a time: the launch sequence of a step
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-extras --in-flight 1 --batch 1 > /tmp/prof_$TAG.log 2>&1; echo "rocprof exit $?")
   for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/bench_single_kernel_stats.csv; done
@@ -38,9 +38,9 @@ if has prof; then
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profc_$TAG -o trace -- python $GRAFT_REPO_ROOT/tools/conv_stack_time.py > /tmp/profc_$TAG.log 2>&1; echo "rocprof conv stack exit $?")
   for f in $(find /tmp/profc_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/conv_stack_kernel_stats.csv; done
   python tools/trace_step.py $(find /tmp/profc_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null > $OUT/conv_stack_trace.txt; tail -2 $OUT/conv_stack_trace.txt
-  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profc4_$TAG -o trace -- python $GRAFT_REPO_ROOT/tools/conv_stack_time.py 8 > /tmp/profc4_$TAG.log 2>&1; echo "rocprof conv stack x8 exit $?")
-  for f in $(find /tmp/profc4_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/conv_stack_b8_kernel_stats.csv; done
-  python tools/trace_step.py $(find /tmp/profc4_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null > $OUT/conv_stack_b8_trace.txt; tail -2 $OUT/conv_stack_b8_trace.txt
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profc4_$TAG -o trace -- python $GRAFT_REPO_ROOT/tools/conv_stack_time.py 16 > /tmp/profc4_$TAG.log 2>&1; echo "rocprof conv stack x8 exit $?")
+  for f in $(find /tmp/profc4_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/conv_stack_b16_kernel_stats.csv; done
+  python tools/trace_step.py $(find /tmp/profc4_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null > $OUT/conv_stack_b16_trace.txt; tail -2 $OUT/conv_stack_b16_trace.txt
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profk_$TAG -o trace -- python $GRAFT_REPO_ROOT/tools/prof_kernels.py > /tmp/profk_$TAG.log 2>&1; echo "rocprof kernels exit $?")
   for f in $(find /tmp/profk_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/kernels_kernel_stats.csv; done
 fi

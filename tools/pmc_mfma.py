@@ -29,9 +29,7 @@ for (name, grid), e in last.items():
     util = busy / (128.0 * gui) if gui else 0.0
     print("%-52s %9d %9.1f %14.0f %12.0f %6.1f%% %6.2f" % (name[:52], grid, e["ns"] / 1e3, busy, gui, 100 * util,
                                                           gui / 8.0 / e["ns"] if e["ns"] else 0))
-    fam = "conv (8 images)" if ("conv_h2w" in name or (("conv_h2_kernel" in name) and grid >= 400000)) else \
-          "conv (1 image)" if "conv_h2_kernel" in name else "dense_h2w (16384 rows)" if "dense_h2w" in name else \
-          "dense_h2 (2048 rows)" if "dense_h2" in name else None
+    fam = None          # (families are not summed: the same (kernel, grid) serves several layers; see the rows)
     if fam:
         t = tot.setdefault(fam, [0.0, 0.0, 0.0])
         t[0] += busy; t[1] += gui; t[2] += e["ns"]

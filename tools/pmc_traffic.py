@@ -47,7 +47,7 @@ for pos, i in enumerate(ids):
 # the LAST 13 conv launches, when there are more than the steps' (prof_kernels.py ends with one PROF_BATCH-image stack)
 all_conv = [i for i in ids if is_conv(fetch[i]["name"])]
 batched = all_conv[-13:] if len(all_conv) >= 39 else []
-batch_images = int(os.environ.get("PROF_BATCH", "8"))
+batch_images = int(os.environ.get("PROF_BATCH", "16"))
 gathers = [i for i in ids if "gather_kernel" in fetch[i]["name"] and "project" not in fetch[i]["name"]]
 g_small = [i for i in gathers if int(fetch[i]["grid"]) < 1_000_000][-1]
 g_big = [i for i in gathers if int(fetch[i]["grid"]) >= 1_000_000][-1]

@@ -2,7 +2,7 @@
 PROF_STEPS x (encode + 2048-point query), one standalone gather at 2048 and 262144 points,
 one 65536-point query through the layer-by-layer chain and through the fused kernels, one single-call step
 (disn_encode_query: no feature map, gather from the taps), and LAST one convolution stack on PROF_BATCH images
-(default 8: the batch bench.py's main line submits per call)."""
+(default 16: the batch bench.py's main line submits per call)."""
 import os, sys
 import numpy as np
 import torch
@@ -33,7 +33,7 @@ for _ in range(2):
     eng.query(enc, p, tm, fused=True)       # mlp_fused_kernel<global>, <local>
 eng.encode_query(img, pts, tm)
 torch.cuda.synchronize()
-PB = int(os.environ.get("PROF_BATCH", "8"))
+PB = int(os.environ.get("PROF_BATCH", "16"))
 if PB > 0:
     imgs = torch.from_numpy(rng.random((PB, 137, 137, 3), dtype=np.float32)).cuda()
     ops.ConvStackRun(eng.weights.vgg, imgs, want_pool5=False).run()

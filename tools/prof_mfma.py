@@ -1,5 +1,5 @@
 """Workload for the MFMA-utilisation PMC pass (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE):
-the convolution stack of ONE image (conv_h2.hip) and of EIGHT images (conv_h2w.hip: what bench.py's roofline times), the
+the convolution stack of ONE image (conv_h2.hip) and of EIGHT / SIXTEEN images (conv_h2w.hip; sixteen = what bench.py's roofline times), the
 point-MLP layer shapes of an eight-step call (dense_h2w.hip, 16384 rows) and of one step (dense_h2.hip, 2048 rows).
 Every variant runs twice after a warm-up; tools/pmc_mfma.py reads the LAST dispatch of each kernel / grid."""
 import os, sys
@@ -13,13 +13,13 @@ torch.cuda.set_device(0)
 dev = torch.device("cuda:0")
 eng = SdfEngine(WeightStore.random_init(0, mode="he"))
 rng = np.random.default_rng(0)
-for B in (1, 8):
+for B in (1, 8, 16):
     imgs = torch.from_numpy(rng.random((B, 137, 137, 3), dtype=np.float32)).cuda()
     r = ops.ConvStackRun(eng.weights.vgg, imgs, want_pool5=False)
     for _ in range(3):
         r.run()
     torch.cuda.synchronize()
-for M, rows in ((2048, 0), (16384, 2048)):
+for M, rows in ((2048, 0), (16384, 2048), (32768, 2048)):
     for k1, k2, N in ((256, 0, 512), (512, 0, 512), (512, 1536, 512), (512, 0, 256)):
         K = k1 + k2
         a1 = torch.rand((M, k1), device=dev)
