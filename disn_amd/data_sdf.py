@@ -35,12 +35,13 @@ def _load(path_h5: str, keys: Sequence[str]) -> Dict[str, np.ndarray]:
     if os.path.exists(npz):
         with np.load(npz) as z:
             return {k: z[k] for k in keys if k in z.files}
-    if os.path.exists(path_h5):
+    if os.path.exists(path_h5):      # the reference's own files (data/data_sdf_h5_queue.py:121-186)
         try:
-            import h5py  # noqa: F401
-        except ImportError as e:
-            raise RuntimeError("%s is HDF5 and h5py is not installed; convert it to .npz with the same "
-                               "dataset names (disn_amd.data_sdf.save_sample / save_view)" % path_h5) from e
+            import h5py
+        except ImportError:
+            from .hdf5_lite import Hdf5File        # the subset of HDF5 those files use, restated in plain Python
+            f = Hdf5File(path_h5)
+            return {k: f[k] for k in keys if k in f}
         with h5py.File(path_h5, "r") as f:
             return {k: f[k][:] for k in keys if k in f.keys()}
     raise FileNotFoundError(path_h5)
