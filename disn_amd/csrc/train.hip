@@ -213,6 +213,10 @@ struct TrainWs {
   // gradients
   float *dpred, *d5, *d4, *d3, *d2, *d1, *dfeat, *dmap, *dgbias, *demb, *dz7, *dz6, *dpool5, *gA, *gB;
   float *col, *fc_ws, *sumsq_ws, *red_aux;
+  // forward convolutions through conv_h2.hip / conv_h2w.hip: two-term f16 weight images (re-packed every step) and
+  // the activation-maximum slots [14][B][64] of the layer chain
+  float* conv_h2img[13];
+  float* amax;
   BwdWs bw;
   size_t total;
 };
@@ -286,6 +290,9 @@ TrainWs train_layout(void* ws, int B, int N) {
   fws = max_sz(fws, gemv_ws_bytes(B, DISN_EMBED_DIM, 512));
   t.fc_ws = b.take(fws / sizeof(float) + 1);
   t.sumsq_ws = b.take(32 * 256);
+  t.conv_h2img[0] = nullptr;
+  for (int i = 1; i < 13; ++i) t.conv_h2img[i] = b.take(conv_h2_image_bytes(kConv[i].cin, kConv[i].cout) / sizeof(float) + 1);
+  t.amax = b.take((size_t)14 * B * 64);
   t.red_aux = b.take(colsum_ws_bytes(B, 4096) / sizeof(float) + 1);
   size_t red = colsum_ws_bytes(M, 512);
   for (int i = 0; i < 13; ++i)  // bias-gradient partials of every conv layer (chunks x Cout)
@@ -440,13 +447,19 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
   const size_t gwb = s.gemm_ws_bytes;
 
   // ---------------- forward ----------------
+  // The 13 convolutions of the forward (models/CNN/vgg.py:187-196) through the inference kernels -- conv1_1 direct,
+  // conv_h2.hip / conv_h2w.hip (two-term f16 split: fp32-accurate, pools fused) -- in the fp32-accurate and the
+  // mixed-precision mode alike: at eight samples 0.8 ms instead of 2.6 (three-term) / ~1.0 ms (bf16 one-term), and the
+  // kept activations are the fp32-accurate ones.  compute_bf16 == 0 (every product on the f32-input MFMA) keeps the
+  // implicit-GEMM forward.  The weight images are re-packed every step (the weights change every step).
+  const bool h2fwd = compute_bf16 != 0;
   // weights in MFMA fragment order (they change every step): fp32, or bf16 in the same storage
   // all 41 re-packs (forward + data-gradient views) in one launch
   {
     PackJobs jobs{};
-    pack_job_add(jobs, P(0), t.conv_p[0], 0, 27, 64, 0);  // conv1_1 (K = 27) stays on the fp32 path
+    if (!h2fwd) pack_job_add(jobs, P(0), t.conv_p[0], 0, 27, 64, 0);  // conv1_1 (K = 27) stays on the fp32 path
     for (int i = 1; i < 13; ++i) {
-      pack_job_add(jobs, P(2 * i), t.conv_p[i], 0, 9 * kConv[i].cin, kConv[i].cout, bf);
+      if (!h2fwd) pack_job_add(jobs, P(2 * i), t.conv_p[i], 0, 9 * kConv[i].cin, kConv[i].cout, bf);
       pack_job_add(jobs, P(2 * i), t.conv_bT[i], 2, kConv[i].cin, kConv[i].cout, bf);
     }
     const float* gw4 = P(V_G + 6);  // rows 0..511 point part, 512..1535 global part
@@ -486,15 +499,28 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
     DISN_TRY(sumsq_launch(params, segs, 0.5f * wd, losses + 3, t.sumsq_ws, as));
   }
 
+  if (h2fwd)
+    for (int i = 1; i < 13; ++i) {
+      float* scratch = t.conv_h2img[i] + (size_t)kConv[i].cin * 9 * kConv[i].cout + 2;   // behind {s_w, 1 / s_w}
+      DISN_TRY(conv_h2_pack_launch(P(2 * i), kConv[i].cin, kConv[i].cout, t.conv_h2img[i], scratch, st));
+    }
   DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, t.resized, DISN_VGG_SIZE,
-                                  DISN_VGG_SIZE, 3, 0, st));
+                                  DISN_VGG_SIZE, 3, 0, st, 0, h2fwd ? t.amax : nullptr, h2fwd ? 14 * B * 64 : 0));
   const float* x = t.resized;
   for (int i = 0; i < 13; ++i) {
     const ConvL& c = kConv[i];
-    DISN_RC(conv_fwd(x, B, c.hw, c.hw, c.cin, t.conv_p[i], P(2 * i + 1), c.cout, 1, t.act[i], gws, gwb, st, bf));
+    if (h2fwd && i == 0) {
+      DISN_TRY(conv1_1_direct_launch(x, B, c.hw, c.hw, P(0), P(1), 1, t.act[0], t.amax + (size_t)B * 64, st, 64));
+    } else if (h2fwd) {
+      DISN_TRY(conv_h2_launch(x, B, c.hw, c.hw, c.cin, t.conv_h2img[i], P(2 * i + 1), c.cout, 1,
+                              t.amax + (size_t)B * 64 * i, t.act[i], c.pool ? t.pooled[i] : nullptr,
+                              t.amax + (size_t)B * 64 * (i + 1), st, 0, 64));
+    } else {
+      DISN_RC(conv_fwd(x, B, c.hw, c.hw, c.cin, t.conv_p[i], P(2 * i + 1), c.cout, 1, t.act[i], gws, gwb, st, bf));
+    }
     x = t.act[i];
     if (c.pool) {
-      DISN_TRY(maxpool2x2_launch(x, B, c.hw, c.hw, c.cout, t.pooled[i], st));
+      if (!h2fwd) DISN_TRY(maxpool2x2_launch(x, B, c.hw, c.hw, c.cout, t.pooled[i], st));
       x = t.pooled[i];
     }
   }

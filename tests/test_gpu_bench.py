@@ -32,12 +32,16 @@ def test_default_line_contract():
     assert "workload" in d["config"]
 
 
-def test_grid_workload_two_ranks_with_a_collective():
-    """config-4 shape on a small grid: 2 ranks, 2 images, 33^3 points each, sharded + all_gather + MC"""
+@pytest.mark.parametrize("exchange", ["all_to_all", "all_gather"])
+def test_grid_workload_two_ranks_with_a_collective(exchange):
+    """config-4 shape on a small grid: 2 ranks, 2 images, 33^3 points each, sharded + one exchange + MC.  all_to_all
+    (default): every rank receives the full grid of the ONE image it meshes; all_gather: both grids"""
     d = _run(["--gpus", "2", "--workload", "grid", "--grid-res", "32", "--grid-images", "2", "--steps", "2",
-              "--warmup", "1"])
+              "--warmup", "1", "--exchange", exchange])
     assert d["n_gpus"] == 2
-    assert d["all_gather"] is not None and d["all_gather"]["bytes_received_per_rank"] >= 2 * 33 ** 3 * 4
+    got = (d["all_gather"] or {}).get("bytes_received_per_rank", 0)
+    want_images = 1 if exchange == "all_to_all" else 2
+    assert d["all_gather"]["exchange"] == exchange and want_images * 33 ** 3 * 4 <= got < (want_images + 0.5) * 33 ** 3 * 4
     assert d["config"]["images"] == 2 and d["value"] > 0
     assert d["mesh"]["images_meshed_on_rank0"] == 1
 
