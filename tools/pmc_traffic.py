@@ -70,7 +70,7 @@ def hbm(idl):
             "hbm_bytes": (2 * f + cal * w) * 1024.0}
 
 
-out = {"build": build, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_kernels.py workload (PROF_STEPS=1)",
+out = {"build": build, "counter_files": os.environ.get("PMC_BUILD", ""), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_kernels.py workload (PROF_STEPS=1)",
        "note": "KB as reported; gfx950: FETCH_SIZE x2 for wide coalesced reads; WRITE_SIZE calibrated on the gather",
        "conv_family_per_step": dict(hbm(conv), kernels=sorted({fetch[i]["name"].split("(")[0] for i in conv}),
                                     algorithmic_bytes_note="conv_h2 build: weights 59 MB (two f16 planes, 4 B/weight) + layer "
