@@ -269,9 +269,13 @@ bool dense_h2w_supported(const DenseH2Prob& p) {
 // idle (the 256-column layers of an eight-step call: 128 -> 256 workgroups).
 hipError_t dense_h2w_go(DenseH2Dev d, hipStream_t st) {
   const DenseH2Prob& p = d.p[0];
-  const bool c128 = p.K % 128 == 0 && (p.k1 == p.K || p.k1 % 128 == 0);
+  // (128-column chunks from K = 1024 on: at K <= 512 the 64-column ones measured 3-5 % faster -- twice the workgroups per
+  //  CU by LDS, a shorter prologue; profiles/r03t_dense_h2w_knobs.txt)
+  bool c128 = p.K >= 1024 && p.K % 128 == 0 && (p.k1 == p.K || p.k1 % 128 == 0);
   const long wg128 = (long)((p.M + 127) / 128) * (p.N / 256) * d.nprob;
-  const bool m64 = wg128 < 200;
+  bool m64 = wg128 < 200;
+  if (tune::densew_m64 >= 0) m64 = tune::densew_m64 != 0;          // tuning builds (tools/dense_h2w_time.py)
+  if (tune::densew_c128 >= 0) c128 = c128 && tune::densew_c128 != 0;
   d.mtiles = (p.M + (m64 ? 63 : 127)) / (m64 ? 64 : 128);
   const dim3 grid(d.mtiles * (p.N / 256), d.nprob);
   if (m64) {

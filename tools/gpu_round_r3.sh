@@ -3,12 +3,15 @@
 # step, conv stack), PMC traffic (FETCH / WRITE passes) and MFMA utilisation (its own pass) of the SAME build
 set -u
 TAG=${1:-r03x}; shift || true
-WHAT=${*:-"tests bench grid prof pmc mfma"}
+WHAT=${*:-"smoke tests bench grid prof pmc mfma"}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 if has test; then
   timeout 300 python -m pytest tests/test_gpu_model.py -q -k "pipeline or standalone_layer_chain or cfg2" --no-header -p no:cacheprovider > $OUT/pytest_quick.log 2>&1; echo "quick tests exit $?"; tail -3 $OUT/pytest_quick.log
+fi
+if has smoke; then
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -1 $OUT/smoke.log
 fi
 if has tests; then
   timeout 1500 python -m pytest tests -m gpu -q -rA --no-header -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log; grep -v "^PASSED" $OUT/pytest_gpu.log | tail -15
@@ -29,7 +32,7 @@ if has prof; then
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profm_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 8 --no-extras > /tmp/profm_$TAG.log 2>&1; echo "rocprof main exit $?")
   for f in $(find /tmp/profm_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/bench_kernel_stats.csv; done
   # (a2) one call of eight steps at a time: the launch sequence of a batched call
-  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/profb4_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 24 --warmup 8 --no-extras --in-flight 1 --batch 16 --spinup-s 0 > /tmp/profb4_$TAG.log 2>&1; echo "rocprof b4 exit $?")
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/profb4_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 16 --no-extras --in-flight 1 --batch 16 --spinup-s 0 > /tmp/profb4_$TAG.log 2>&1; echo "rocprof b4 exit $?")
   python tools/trace_step.py $(find /tmp/profb4_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null | grep -v "at::native\|rocclr_copy" > $OUT/infer_call_b16_trace.txt; tail -2 $OUT/infer_call_b16_trace.txt
   # (b) one step at a time: the launch sequence of a step
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-extras --in-flight 1 --batch 1 > /tmp/prof_$TAG.log 2>&1; echo "rocprof exit $?")
