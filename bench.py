@@ -246,9 +246,9 @@ def grid_bench(args, torch, dist, dev, world, rank, launched, shared_gpu, backen
         "scaling": "strong" if args.grid_images else ("weak" if world == 1 else "strong"),
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config %s: %d image(s) x %d^3 dense grid, query chunks sharded over %d "
-                               "rank(s), one all_gather, marching cubes; img_feat_twostream, fp32, random-init "
+                               "rank(s), one %s, marching cubes; img_feat_twostream, fp32, random-init "
                                "(xavier) weights, nothing cached between steps" % (
-                                   "3" if world == 1 else "4", B, R + 1, world),
+                                   "3" if world == 1 else "4", B, R + 1, world, args.exchange),
                    "images": B, "grid_points_per_image": total, "seconds_per_step": dt / args.steps,
                    "seconds_per_image": dt / args.steps / B,
                    "point_mlp": "layer-by-layer GEMMs (three-term bf16)" if args.unfused else
@@ -294,9 +294,6 @@ def main():
     ap.add_argument("--balance", type=int, default=0,
                     help="--workload query: 1 = the K steps of a run are cut into calls of equal size (a multiple of "
                          "--in-flight calls, none longer than --batch) instead of full calls + a short last one")
-    ap.add_argument("--pack-short", type=int, default=1,
-                    help="--workload query: 1 = a run of fewer than two calls per context puts its full calls back to back "
-                         "on one context and the remainder call beside them (StepPipeline.pack_short_runs); 0 = round robin")
     ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--workload", choices=("query", "grid", "train"), default="query",
                     help="query: BASELINE.json metric (default); grid: configs 3/4 (dense grid + gather + marching "
@@ -376,7 +373,6 @@ def main():
     S = max(1, args.in_flight)
     SB = max(1, args.batch)
     pipe = StepPipeline(store, dev, in_flight=S, batch=SB)
-    pipe.pack_short_runs = bool(args.pack_short)
     eng = pipe.engines[0]
     rng = np.random.default_rng(1000 + rank)
     # every step of a call -- and of the calls in flight beside it -- has its own image, point set and camera:
@@ -543,7 +539,7 @@ def main():
                                                  "traffic": (pmc.get("conv_family_per_step") or {}).get("hbm_bytes"),
                                                  "note": "the same chain on ONE image (a step run alone: conv_h2_kernel, K "
                                                          "parallel inside the workgroup)"},
-                                "per_launch": "profiles/r03*_conv_stack_b8_trace.txt (rocprofv3 kernel trace of the same call)"}
+                                "per_launch": "profiles/r03*_conv_stack_b16_trace.txt (rocprofv3 kernel trace of the same call)"}
         except Exception as e:   # a failing extra must not cost the contract line
             line.setdefault("extras_failed", {})['roofline of the dominant kernel family'] = repr(e)
             print("[bench] extra failed: %s: %r" % ('roofline of the dominant kernel family', e), file=sys.stderr)

@@ -9,8 +9,8 @@
 //    the pace (0.16 - 0.24 of the f16 peak).
 //  * Here a workgroup is 128 rows x 256 columns: eight n-waves, each owning one 32-column n-block for all four row
 //    blocks and walking K sequentially.  The operand chunk (128 rows x 128 columns) is split once per 256 output
-//    columns by 512 threads (4 float4 units each: ~100 VALU per 96 MFMAs), each wave streams its own weight
-//    fragments from L2 (2 KiB per 12 MFMAs), MFMAs are issued as pairs of row blocks (no back-to-back dependence).
+//    columns by 512 threads (8 float4 units each per chunk: ~230 VALU per 96 MFMAs and wave), each wave streams its own
+//    weight fragments from L2 (2 KiB per 12 MFMAs), MFMAs are issued as pairs of row blocks (no back-to-back dependence).
 //  * Everything dense_h2.hip does on load is kept: A = [a | a2] read in place (models/sdfnet.py:180's concat),
 //    relu(A + in_bias[image]) (the deferred bias of the split global fold2/conv1), per-image maxima / scales.
 //

@@ -318,7 +318,6 @@ class StepPipeline:
         import queue
         import threading
         self.batch = max(1, int(batch))
-        self.pack_short_runs = True   # see _run_batched
         self.trace = None      # a list: run() appends (context, call index, time.perf_counter() after enqueueing)
         self._threading = threading
         # Stream / context creation ORDER matters: ROCm hands out its hardware queues (GPU_MAX_HW_QUEUES, default
@@ -483,15 +482,10 @@ class StepPipeline:
             ts = [self.engines[0]._dev(jobs[k][pos]) for k in idx]
             return ts[0] if len(ts) == 1 else torch.cat(ts, dim=0)
 
-        # which context runs which call.  Round robin when every context gets at least two calls (they drift out of
-        # phase and fill each other's gaps).  A SHORT run (fewer calls than that): two calls started together stay in
-        # phase -- convolutions beside convolutions, fc stream beside fc stream -- and gain little from each other
-        # (measured, --steps 20 as 8 + 8 + 4: 3.66 ms of GPU time round robin), so the full calls go back to back on
-        # context 0 and the remainder call runs beside them on context 1.
-        assign = [g % S for g in range(len(groups))]
-        if self.pack_short_runs and S >= 2 and 2 <= len(groups) < 2 * S and len(groups[-1]) < len(groups[0]):
-            assign = [0] * (len(groups) - 1) + [1]
-        mine = [[g for g in range(len(groups)) if assign[g] == i] for i in range(S)]
+        # call g runs on context g % in_flight.  (Tried for short runs -- bench.py --steps 20 = 8 + 8 + 4: the full calls back
+        # to back on one context and the remainder beside them, because two calls started together stay in phase and gain
+        # little from each other; no better, 4.13 vs 4.05-4.13 ms: profiles/r03o_bench_pack20.txt.)
+        mine = [[g for g in range(len(groups)) if g % S == i] for i in range(S)]
 
         def work(i):
             self.streams[i].wait_stream(cur)
