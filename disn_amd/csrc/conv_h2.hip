@@ -498,7 +498,8 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
 hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu,
                                  float* out, float* out_amax, hipStream_t st, int amax_stride) {
   const long ntile = (long)B * ((H + 1) / 2) * ((W + 31) / 32);
-  const int grid = (int)(ntile < 512 ? ntile : 512);  // two workgroups per CU (214 registers), ~12 tiles each at eight 224 x 224 images
+  const long cap = tune::conv11_wgs > 0 ? tune::conv11_wgs : 512;
+  const int grid = (int)(ntile < cap ? ntile : cap);  // two workgroups per CU, ~12 tiles each at eight 224 x 224 images
   hipLaunchKernelGGL(conv1_1_direct_kernel, dim3(grid), dim3(256), 0, st, in, w_hwio, bias, B, H, W, relu, out, out_amax, amax_stride);
   return hipGetLastError();
 }
