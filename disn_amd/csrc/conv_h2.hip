@@ -52,9 +52,11 @@ namespace disn {
 // contiguous 18 KiB -- what one k-wave reads per chunk, whatever the number of k-waves.  Behind the image:
 // {s_w, 1 / s_w}.
 // ---------------------------------------------------------------------------------------------------
+// flip_t: w is the FORWARD tensor [taps][Cout][Cin] of the layer whose data gradient this image serves -- the image is
+// the one of w'[t][ci][co] = w[taps - 1 - t][co][ci] (taps mirrored, channels transposed: dx = conv(dz, w'))
 __global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int taps,
                                                            const float* __restrict__ amax,
-                                                           unsigned char* __restrict__ image) {
+                                                           unsigned char* __restrict__ image, int flip_t) {
   const int KB = Cin >> 4;
   const size_t frags = (size_t)(Cout >> 5) * KB * taps;
   const float s = ch2::pow2_scale(amax[0], 13);
@@ -65,16 +67,23 @@ __global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restri
   }
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < frags * 64; idx += (size_t)gridDim.x * 256) {
     const int lane = (int)(idx & 63);
-    const size_t f = idx >> 6;
-    const int t = (int)(f % taps);
-    const int kb = (int)((f / taps) % KB);
+    size_t f = idx >> 6;
+    int t = (int)(f % taps);
+    int kb = (int)((f / taps) % KB);
     const int nb = (int)(f / ((size_t)taps * KB));
+    if (flip_t) {  // walk the k16 blocks fastest: a lane's reads of consecutive fragments are consecutive 32-byte pieces of
+                   // one row of the forward tensor (whole cache lines per workgroup pass instead of a quarter of each)
+      kb = (int)(f % KB);
+      t = (int)((f / KB) % taps);
+      f = ((size_t)nb * KB + kb) * taps + t;
+    }
     const int j = lane & 31, g = lane >> 5;
     ch_h8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int ci = 16 * kb + 8 * g + e;
-      const float v = w[((size_t)t * Cin + ci) * Cout + 32 * nb + j] * s;
+      const float v = (flip_t ? w[((size_t)(taps - 1 - t) * Cout + 32 * nb + j) * Cin + ci]
+                              : w[((size_t)t * Cin + ci) * Cout + 32 * nb + j]) * s;
       const _Float16 h = (_Float16)v;
       hi[e] = h;
       lo[e] = (_Float16)(v - (float)h);
@@ -87,14 +96,110 @@ __global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restri
 
 size_t conv_h2_image_bytes(int Cin, int Cout) { return (size_t)Cin * 9 * Cout * 4 + 256; }
 
+// ---- the same for a list of 3x3 tensors: one maximum pass, one pack pass (train.hip) ----------------------------
+__global__ __launch_bounds__(256) void conv_h2_wmax_multi_kernel(const ConvH2PackJobs jobs) {
+  // a workgroup reduces 4096 consecutive floats of ONE tensor (tensor sizes are multiples of 36864 = 9 * 4096)
+  __shared__ float red[4];
+  const long base = (long)blockIdx.x * 4096;
+  int s = 0;
+  while (s + 1 < jobs.nslots && jobs.seg_begin[s + 1] <= base) ++s;
+  const float* p = jobs.seg[s] + (base - jobs.seg_begin[s]);
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)(k * 256 + threadIdx.x) * 4);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<unsigned*>(jobs.wmax) + s, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
+__global__ __launch_bounds__(256) void conv_h2_pack_multi_kernel(const ConvH2PackJobs jobs) {
+  // four fragments per workgroup; fragment counts of every job are multiples of four (72 at 64 x 64 channels)
+  const long f0 = (long)blockIdx.x * 4;
+  int ji = 0;
+  {
+    int lo = 0, hi = jobs.n - 1;  // last job with frag_begin <= f0
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs.j[mid].frag_begin <= f0) lo = mid; else hi = mid - 1;
+    }
+    ji = lo;
+  }
+  const ConvH2PackJob& J = jobs.j[ji];
+  const int Cin = J.Cin, Cout = J.Cout, KB = Cin >> 4, taps = 9;
+  const float s = ch2::pow2_scale(jobs.wmax[J.slot], 13);
+  size_t f = (size_t)(f0 - J.frag_begin) + (threadIdx.x >> 6);
+  if (f == 0 && threadIdx.x == 0) {
+    float* meta = reinterpret_cast<float*>(J.image + (size_t)Cin * taps * Cout * 4);
+    meta[0] = s;
+    meta[1] = 1.0f / s;
+  }
+  const int lane = threadIdx.x & 63;
+  int t = (int)(f % taps);
+  int kb = (int)((f / taps) % KB);
+  const int nb = (int)(f / ((size_t)taps * KB));
+  if (J.flip_t) {  // as conv_h2_pack_kernel: k16 blocks fastest
+    kb = (int)(f % KB);
+    t = (int)((f / KB) % taps);
+    f = ((size_t)nb * KB + kb) * taps + t;
+  }
+  const int j = lane & 31, g = lane >> 5;
+  ch_h8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = 16 * kb + 8 * g + e;
+    const float v = (J.flip_t ? J.w[((size_t)(taps - 1 - t) * Cout + 32 * nb + j) * Cin + ci]
+                              : J.w[((size_t)t * Cin + ci) * Cout + 32 * nb + j]) * s;
+    const _Float16 h = (_Float16)v;
+    hi[e] = h;
+    lo[e] = (_Float16)(v - (float)h);
+  }
+  ch_h8* out = reinterpret_cast<ch_h8*>(J.image);
+  out[(f * 2) * 64 + lane] = hi;
+  out[(f * 2 + 1) * 64 + lane] = lo;
+}
+
+void conv_h2_pack_job_add(ConvH2PackJobs& jobs, const float* w_fwd, int Cin_fwd, int Cout_fwd, void* image, int flip_t,
+                          int slot) {
+  ConvH2PackJob& J = jobs.j[jobs.n++];
+  J.w = w_fwd; J.image = static_cast<unsigned char*>(image); J.flip_t = flip_t; J.slot = slot;
+  J.Cin = flip_t ? Cout_fwd : Cin_fwd;
+  J.Cout = flip_t ? Cin_fwd : Cout_fwd;
+  J.frag_begin = jobs.total_frags;
+  jobs.total_frags += (long)(J.Cout >> 5) * (J.Cin >> 4) * 9;
+  if (slot >= jobs.nslots) {   // slots are added in order, one tensor each
+    jobs.seg[slot] = w_fwd;
+    jobs.seg_begin[slot] = slot == 0 ? 0 : jobs.seg_begin[slot];
+    jobs.seg_begin[slot + 1] = jobs.seg_begin[slot] + (long)9 * Cin_fwd * Cout_fwd;
+    jobs.nslots = slot + 1;
+  }
+}
+
+#ifndef CH2_UBENCH
+// jobs.wmax: nslots device floats
+hipError_t conv_h2_pack_multi_launch(const ConvH2PackJobs& jobs, hipStream_t st) {
+  if (jobs.n == 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(jobs.wmax, 0, (size_t)jobs.nslots * sizeof(float), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(conv_h2_wmax_multi_kernel, dim3((unsigned)(jobs.seg_begin[jobs.nslots] / 4096)), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL(conv_h2_pack_multi_kernel, dim3((unsigned)(jobs.total_frags / 4)), dim3(256), 0, st, jobs);
+  return hipGetLastError();
+}
+#endif
+
 #ifndef CH2_UBENCH
 // w: TF HWIO [3][3][Cin][Cout]; scratch: one float (max |w|)
 hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, float* scratch, hipStream_t st,
-                               int taps) {
+                               int taps, int flip_t) {
   hipError_t e = amax_launch(w, (size_t)taps * Cin * Cout, scratch, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(conv_h2_pack_kernel, dim3(1024), dim3(256), 0, st, w, Cin, Cout, taps, scratch,
-                     static_cast<unsigned char*>(image));
+                     static_cast<unsigned char*>(image), flip_t);
   return hipGetLastError();
 }
 

@@ -260,9 +260,31 @@ hipError_t mlp_fused_launch(bool local, const void* image, const float* w1, cons
 // ---- conv_h2.hip: the single-image 3x3 convolution (two-term f16 split, halo in LDS, K parallel inside the workgroup) ----
 size_t conv_h2_image_bytes(int Cin, int Cout);
 // w: TF HWIO [3][3][Cin][Cout] (taps = 9) or a [K = Cin][N = Cout] matrix (taps = 1, dense_h2.hip); scratch: one
-// device float; the image holds taps * Cin * Cout * 4 + 256 bytes
+// device float; the image holds taps * Cin * Cout * 4 + 256 bytes.  flip_t: w is the forward tensor [taps][Cout][Cin]
+// of a layer and the image the one of its data gradient, w'[t][ci][co] = w[taps - 1 - t][co][ci] (train.hip)
 hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, float* scratch, hipStream_t st,
-                               int taps = 9);
+                               int taps = 9, int flip_t = 0);
+// Many 3x3 weight images in TWO launches (train.hip re-packs 12 forward + 12 data-gradient images per step; as 72
+// separate memset / max / pack launches they were 0.46 ms of serial 5-us kernels): one max |w| pass over all tensors
+// (job k's scale from wmax[slot]; images of one tensor share a slot), one pack pass over all fragments.
+struct ConvH2PackJob {
+  const float* w;          // forward tensor [9][Cin_fwd][Cout_fwd]
+  unsigned char* image;
+  int Cin, Cout;           // of the IMAGE (swapped against the tensor's when flip_t)
+  int flip_t, slot;
+  long frag_begin;         // first fragment (of 64 lanes) of this job in the concatenated space
+};
+struct ConvH2PackJobs {
+  int n, nslots;
+  long total_frags;
+  float* wmax;             // [nslots] device floats (scratch)
+  const float* seg[16];    // tensor of slot s
+  long seg_begin[17];      // in floats, multiples of 4096
+  ConvH2PackJob j[32];
+};
+void conv_h2_pack_job_add(ConvH2PackJobs& jobs, const float* w_fwd, int Cin_fwd, int Cout_fwd, void* image, int flip_t,
+                          int slot);
+hipError_t conv_h2_pack_multi_launch(const ConvH2PackJobs& jobs, hipStream_t st);
 bool conv_h2_supported(int H, int W, int Cin, int Cout);  // Cin, Cout multiples of 64
 // in_amax: 64 floats whose maximum is max |in|; out_amax (optional, 64 floats zeroed by the caller): atomic
 // max |out| spread over the slots; pool_out

@@ -168,9 +168,12 @@ int dense_bwd(const float* a, int lda, int K, const float* w_kn, const float* dz
 
 // 3x3 conv backward; dz [B,H,W,Cout] already ReLU-masked; x [B,H,W,Cin]; w raw [3,3,Cin,Cout]
 // col: [B*H*W][64] scratch, only for Cin == 3
+// h2img != nullptr: the data gradient through conv_h2.hip / conv_h2w.hip -- dx = conv(dz, w') with the mirrored,
+// transposed kernel's two-term f16 image (conv_h2_pack_launch(flip_t)), dz split per image against its own maximum
+// (amax: B x 64 slots) -- instead of the implicit-GEMM kernels on `prepacked`
 int conv_bwd(const float* x, int B, int H, int W, int Cin, const float* w, const float* dz, int Cout,
              float wd, float* dx, float* dw, float* col, const BwdWs& s, hipStream_t st,
-             const float* prepacked = nullptr) {
+             const float* prepacked = nullptr, const void* h2img = nullptr, float* amax = nullptr) {
   const long M = (long)B * H * W;
   if (Cin == 3) {
     DISN_TRY(im2col_c3_launch(x, B, H, W, col, st));
@@ -185,7 +188,11 @@ int conv_bwd(const float* x, int B, int H, int W, int Cin, const float* w, const
     t.c = dw; t.ldc = Cout; t.H = H; t.W = W; t.Cin = Cin; t.l2 = wd; t.wcur = w; t.bf16 = s.ns == 1;
     DISN_TRY(gemm_tn_launch(t, s.tn_ws, st));
   }
-  if (dx) {
+  if (dx && h2img) {
+    DISN_TRY(hipMemsetAsync(amax, 0, (size_t)B * 64 * sizeof(float), st));
+    DISN_TRY(amax64_accumulate_launch(dz, (size_t)H * W * Cout, amax, st, B, 64));
+    DISN_TRY(conv_h2_launch(dz, B, H, W, Cout, h2img, s.zero, Cin, 0, amax, dx, nullptr, nullptr, st, 0, 64));
+  } else if (dx) {
     const float* wt = prepacked;
     if (!wt) {
       if (s.ns)
@@ -216,7 +223,10 @@ struct TrainWs {
   // forward convolutions through conv_h2.hip / conv_h2w.hip: two-term f16 weight images (re-packed every step) and
   // the activation-maximum slots [14][B][64] of the layer chain
   float* conv_h2img[13];
+  float* conv_h2bT[13];   // the same for the data gradients (mirrored taps, transposed channels)
   float* amax;
+  float* amax_bwd;        // [B][64]: maxima of the layer gradient being propagated
+  float* wmax;            // [16]: max |w| of the 12 packed convolution tensors
   BwdWs bw;
   size_t total;
 };
@@ -292,7 +302,11 @@ TrainWs train_layout(void* ws, int B, int N) {
   t.sumsq_ws = b.take(32 * 256);
   t.conv_h2img[0] = nullptr;
   for (int i = 1; i < 13; ++i) t.conv_h2img[i] = b.take(conv_h2_image_bytes(kConv[i].cin, kConv[i].cout) / sizeof(float) + 1);
+  t.conv_h2bT[0] = nullptr;
+  for (int i = 1; i < 13; ++i) t.conv_h2bT[i] = b.take(conv_h2_image_bytes(kConv[i].cout, kConv[i].cin) / sizeof(float) + 1);
   t.amax = b.take((size_t)14 * B * 64);
+  t.amax_bwd = b.take((size_t)B * 64);
+  t.wmax = b.take(16);
   t.red_aux = b.take(colsum_ws_bytes(B, 4096) / sizeof(float) + 1);
   size_t red = colsum_ws_bytes(M, 512);
   for (int i = 0; i < 13; ++i)  // bias-gradient partials of every conv layer (chunks x Cout)
@@ -347,6 +361,10 @@ size_t disn_conv3x3_backward_workspace_bytes(int B, int H, int W, int Cin, int C
                             : max_sz(max_sz(gemm_plan(M, Cin, 9 * Cout).ws_bytes,
                                             gemm_bf16_ws_bytes(M, Cin, 9 * Cout)), 256);
   if (Cin == 3) b.take((size_t)M * 64);
+  else {  // the data gradient's two-term f16 image and its B x 64 maxima (compute_bf16 != 0)
+    b.take(conv_h2_image_bytes(Cout, Cin) / sizeof(float) + 1);
+    b.take((size_t)B * 64);
+  }
   return bwd_layout(b, (size_t)9 * (Cin == 3 ? 64 : Cin) * Cout, M, g, colsum_ws_bytes(M, Cout)).total;
 }
 
@@ -360,6 +378,8 @@ int disn_conv3x3_backward(const float* x, int B, int H, int W, int Cin, const fl
   Bump b(ws);
   const int M = B * H * W;
   float* col = Cin == 3 ? b.take((size_t)M * 64) : nullptr;
+  float* h2img = Cin == 3 ? nullptr : b.take(conv_h2_image_bytes(Cout, Cin) / sizeof(float) + 1);
+  float* h2amax = Cin == 3 ? nullptr : b.take((size_t)B * 64);
   const size_t g = Cin == 3 ? 256
                             : max_sz(max_sz(gemm_plan(M, Cin, 9 * Cout).ws_bytes,
                                             gemm_bf16_ws_bytes(M, Cin, 9 * Cout)), 256);
@@ -367,7 +387,13 @@ int disn_conv3x3_backward(const float* x, int B, int H, int W, int Cin, const fl
   s.ns = Cin == 3 ? 0 : (compute_bf16 == 2 ? 3 : (compute_bf16 ? 1 : 0));
   DISN_TRY(hipMemsetAsync(s.zero, 0, 4096 * sizeof(float), st));
   DISN_TRY(relu_bwd_colsum_launch(dy, y, M, Cout, y != nullptr, db, s.red_ws, st));
-  return conv_bwd(x, B, H, W, Cin, w_hwio, dy, Cout, wd, dx, dw, col, s, st);
+  // as in disn_train_step: with compute_bf16 != 0 the data gradient runs through conv_h2.hip / conv_h2w.hip
+  const bool h2 = compute_bf16 != 0 && dx && Cin != 3 && conv_h2_supported(H, W, Cout, Cin);
+  if (h2) {
+    float* scratch = h2img + (size_t)Cin * 9 * Cout + 2;
+    DISN_TRY(conv_h2_pack_launch(w_hwio, Cout, Cin, h2img, scratch, st, 9, 1));
+  }
+  return conv_bwd(x, B, H, W, Cin, w_hwio, dy, Cout, wd, dx, dw, col, s, st, nullptr, h2 ? h2img : nullptr, h2amax);
 }
 
 int disn_maxpool2x2_backward(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
@@ -460,7 +486,7 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
     if (!h2fwd) pack_job_add(jobs, P(0), t.conv_p[0], 0, 27, 64, 0);  // conv1_1 (K = 27) stays on the fp32 path
     for (int i = 1; i < 13; ++i) {
       if (!h2fwd) pack_job_add(jobs, P(2 * i), t.conv_p[i], 0, 9 * kConv[i].cin, kConv[i].cout, bf);
-      pack_job_add(jobs, P(2 * i), t.conv_bT[i], 2, kConv[i].cin, kConv[i].cout, bf);
+      if (!h2fwd) pack_job_add(jobs, P(2 * i), t.conv_bT[i], 2, kConv[i].cin, kConv[i].cout, bf);
     }
     const float* gw4 = P(V_G + 6);  // rows 0..511 point part, 512..1535 global part
     const float* lw4 = P(V_L + 6);  // rows 0..511 point part, 512..1983 image-feature part
@@ -499,11 +525,15 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
     DISN_TRY(sumsq_launch(params, segs, 0.5f * wd, losses + 3, t.sumsq_ws, as));
   }
 
-  if (h2fwd)
+  if (h2fwd) {  // 12 forward + 12 data-gradient images (mirrored taps, transposed channels): three launches in all
+    ConvH2PackJobs cj{};
+    cj.wmax = t.wmax;
     for (int i = 1; i < 13; ++i) {
-      float* scratch = t.conv_h2img[i] + (size_t)kConv[i].cin * 9 * kConv[i].cout + 2;   // behind {s_w, 1 / s_w}
-      DISN_TRY(conv_h2_pack_launch(P(2 * i), kConv[i].cin, kConv[i].cout, t.conv_h2img[i], scratch, st));
+      conv_h2_pack_job_add(cj, P(2 * i), kConv[i].cin, kConv[i].cout, t.conv_h2img[i], 0, i - 1);
+      conv_h2_pack_job_add(cj, P(2 * i), kConv[i].cin, kConv[i].cout, t.conv_h2bT[i], 1, i - 1);
     }
+    DISN_TRY(conv_h2_pack_multi_launch(cj, st));
+  }
   DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, t.resized, DISN_VGG_SIZE,
                                   DISN_VGG_SIZE, 3, 0, st, 0, h2fwd ? t.amax : nullptr, h2fwd ? 14 * B * 64 : 0));
   const float* x = t.resized;
@@ -653,7 +683,7 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
       if (dx == dy) dx = bufs[which ^ 1];
     }
     DISN_RC(conv_bwd(xin, B, c.hw, c.hw, c.cin, P(2 * i), dy, c.cout, wd, dx, G(2 * i), t.col, s, st,
-                     t.conv_bT[i]));
+                     t.conv_bT[i], h2fwd && i > 0 ? t.conv_h2bT[i] : nullptr, t.amax_bwd));
     if (dx) {
       which = (dx == bufs[0]) ? 1 : 0;
       dcur = dx;

@@ -502,12 +502,16 @@ int disn_param_layout(disn_param_layout_t* out);
  * gt [B,N] = the fed 'sdf' (sdf_val - 0.003, train/train_sdf.py:375).
  * pred [B,N] = pred_sdf (un-divided).  losses: 5 device floats =
  * {accuracy, sdf_loss_realvalue, sdf_loss, regularization, overall_loss}.
- * compute_bf16: 0 = every product on the f32-input MFMA; 2 = the same fp32 accuracy, forward and
- *   data-gradient GEMMs as a three-term bf16 split on the bf16 MFMA pipes (faster); 1 = mixed
- *   precision as BASELINE config 5 names it: the forward and data-gradient GEMMs of the convolutions
- *   (conv1_1 excepted) and of the point MLPs multiply in bf16 with fp32 accumulation; parameters,
- *   activations, gradients and the optimizer stay fp32 ("fp32 master"); weight gradients use bf16
- *   where the 128x128 tile applies and the fp32 MFMA otherwise.
+ * compute_bf16: 0 = every product on the f32-input MFMA (implicit-GEMM convolutions).
+ *   2 = the same fp32 accuracy, faster: the convolutions of the forward (conv1_1 excepted: direct fp32) AND their
+ *   data gradients (dx = conv(dz, mirrored transposed kernel)) through the inference kernels conv_h2.hip /
+ *   conv_h2w.hip (two-term f16 split, per-image operand scales; the batched form from four samples on), the
+ *   point-MLP forward / data-gradient GEMMs as a three-term bf16 split on the bf16 MFMA pipes.
+ *   1 = mixed precision as BASELINE config 5 names it: the point-MLP forward / data-gradient GEMMs multiply in bf16
+ *   with fp32 accumulation; the convolutions' forward and data gradients stay on the f16-split kernels of mode 2
+ *   (measured faster than a one-term bf16 implicit GEMM); parameters, activations, gradients and the optimizer
+ *   stay fp32 ("fp32 master"); weight gradients use bf16 where the 128x128 tile applies and the fp32 MFMA
+ *   otherwise.
  * ctx (may be NULL): the HBM-bound side work (weight-norm sum, fc6-fc8 forward and backward) runs on
  *   the context's auxiliary stream under the MFMA-bound GEMMs; the caller still sees one
  *   asynchronous operation on `stream`.
@@ -535,8 +539,9 @@ int disn_adam_update(float* params, const float* grads, float* m, float* v, int6
  *   a [M][lda] (first K columns), w_kn raw [K][N]; K, N multiples of 64.
  * disn_conv3x3_backward: same for a SAME 3x3 conv, x [B,H,W,Cin], w_hwio [3,3,Cin,Cout],
  *   Cin == 3 (dx must be NULL) or a multiple of 64, Cout a multiple of 64.
- * compute_bf16 != 0: both GEMMs of the block multiply in bf16 (fp32 accumulate), as in the
- *   mixed-precision step (ignored for Cin == 3). */
+ * compute_bf16 (as in disn_train_step; ignored for Cin == 3): 1 = the GEMMs of the block multiply in bf16 (fp32
+ *   accumulate), 2 = three-term bf16 split; disn_conv3x3_backward with 1 or 2: dx through conv_h2.hip /
+ *   conv_h2w.hip (two-term f16 split, fp32-accurate) as the step does. */
 size_t disn_dense_backward_workspace_bytes(int M, int K, int N);
 int disn_dense_backward(const float* a, int lda, int K, const float* w_kn, const float* y, float* dy,
                         int M, int N, float wd, int compute_bf16, float* da, float* dw, float* db,

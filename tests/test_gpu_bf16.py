@@ -153,7 +153,13 @@ def test_conv3x3_backward_bf16(ops, B, H, Cin, Cout):
     out = Fnn.conv2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), None, padding=1).permute(0, 2, 3, 1)
     (out * torch.tensor(bf16_round(dz))).sum().backward()
     dx, dw, db = ops.conv3x3_backward(dev(x), dev(w), dev(y), dev(dy), wd=wd, compute_bf16=True)
-    report_close("dx", dx.cpu().numpy(), xt.grad.numpy(), atol=2e-6 * np.abs(xt.grad.numpy()).max())
+    # the data gradient runs through conv_h2.hip / conv_h2w.hip (two-term f16 split: fp32-accurate, and faster than a
+    # one-term bf16 implicit GEMM) in the mixed-precision mode too: reference = float64 on the UNROUNDED operands
+    x64 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    out64 = Fnn.conv2d(x64.permute(0, 3, 1, 2), torch.tensor(w, dtype=torch.float64).permute(3, 2, 0, 1), None,
+                       padding=1).permute(0, 2, 3, 1)
+    (out64 * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    report_close("dx", dx.cpu().numpy(), x64.grad.numpy(), atol=2e-6 * np.abs(x64.grad.numpy()).max())
     ref_dw = wt.grad.numpy() + wd * w.astype(np.float64)
     tol = 2e-6 if ((9 * Cin) % 128 == 0 and Cout % 128 == 0) else 2e-2
     report_close("dw", dw.cpu().numpy(), ref_dw, atol=tol * np.abs(ref_dw).max())

@@ -86,6 +86,33 @@ def test_conv3x3_backward(ops, B, H, Cin, Cout):
     rel_close("db", host(db), bt.grad.numpy(), 2e-6)
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 14, 512, 512), (8, 14, 512, 512), (3, 28, 256, 512), (4, 28, 256, 512),
+                                          (4, 28, 512, 512), (4, 56, 128, 256), (5, 56, 256, 256), (4, 112, 64, 128),
+                                          (4, 112, 128, 128), (4, 224, 64, 64)])
+def test_conv3x3_data_gradient_through_conv_h2(ops, B, H, Cin, Cout):
+    """compute mode 2 (and 1) of the step: dx = conv(dz, mirrored transposed kernel) on the inference kernels -- the
+    single-image form below four samples, the batched form from four on (all VGG layer shapes with a data gradient,
+    channels swapped).  fp32-accurate: 2e-6 of the gradient's scale against float64; sample b's dx does not depend on
+    the other samples (per-sample operand scales): checked by re-running sample 0 with the others zeroed."""
+    rng = np.random.default_rng(B * 1000 + H + Cin + 7)
+    x = rng.standard_normal((B, H, H, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / math.sqrt(9 * Cin)).astype(np.float32)
+    dz = (rng.standard_normal((B, H, H, Cout)) * rng.uniform(0.01, 10.0, (B, 1, 1, 1))).astype(np.float32)
+    dzt = torch.tensor(dz, dtype=torch.float64)
+    wt = torch.tensor(w, dtype=torch.float64)
+    # dx = conv_transpose of dz: the full correlation with the mirrored kernel
+    ref = Fnn.conv_transpose2d(dzt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1).numpy()
+    dx, dw, db = ops.conv3x3_backward(dev(x), dev(w), None, dev(dz), wd=0.0, compute_bf16=2)
+    got = host(dx)
+    for b in range(B):   # per sample: each has its own scale
+        rel_close("dx[%d]" % b, got[b], ref[b], 2e-6)
+    dz0 = dz.copy()
+    dz0[1:] = 0
+    dx0, _, _ = ops.conv3x3_backward(dev(x), dev(w), None, dev(dz0), wd=0.0, compute_bf16=2)
+    assert np.array_equal(host(dx0)[0], got[0])
+    assert not host(dx0)[1:].any()
+
+
 # ------------------------------------------------------------------ pool / resize / gather ------
 def test_maxpool_backward(ops):
     rng = np.random.default_rng(5)
