@@ -17,6 +17,10 @@
 // whole tile is finished in place, any other goes to a slab and tn_fixup sums the slabs of a tile in
 // workgroup order (deterministic, no atomics).
 #include "kernels.hpp"
+#include "tuning.hpp"
+#include "h2_common.hpp"
+
+#include <type_traits>
 
 namespace disn {
 
@@ -27,6 +31,9 @@ struct TnDev {
   float* ws;  // slabs [2*W][BP*BQ]
   int msteps, ptiles, qtiles, W;
   long units;
+  int kt;  // > 0: INTERLEAVED reduction -- workgroup w = tile (w % T), row steps (w / T) + i kt: all workgroups walk the
+           // rows of A and B together, a window of 32 kt rows at a time (L2-resident), instead of each streaming its own
+           // contiguous range; one slab per workgroup, tn_fixup sums a tile's kt slabs in order
 };
 
 __device__ __forceinline__ long tn_unit_begin(long U, int W, int w) { return (U * w) / W; }
@@ -39,8 +46,14 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // consecutive m of one column -- is one conflict-free ds_read_b128.  The transposing LDS write is a
 // ds_write_b32 of the bf16 pair (m, m+1): a thread loads the same float4 column group of two adjacent
 // rows; lanes of a 32-lane write group are 16 row pairs x 2 column groups = 32 distinct banks.
-template <int BP, int BQ, bool CONV, bool BF>
+// MODE 2 (round 3): the fp32-ACCURATE multiply on the f16 pipes -- both operands as two-term f16 splits (h + l of
+// v * 2^k, k from the operand's maximum: TnParams::amax_a / amax_b), l_a h_b + h_a l_b + h_a h_b on
+// v_mfma_f32_32x32x16_f16, as conv_h2.hip does for the forward.  Same transposed staging as the bf16 form with two
+// planes per operand (80 KiB of LDS for the 128 x 128 tile's two stages), and the global loads run TWO row steps
+// ahead (two register sets): the step loop of the bf16 form waits a full memory latency per 8 MFMAs.
+template <int BP, int BQ, bool CONV, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
+  constexpr bool BF = MODE == 1;
   constexpr int LDP = BP + 8, LDQ = BQ + 8;      // padded LDS row strides (words)
   constexpr int BUF = 32 * (LDP + LDQ);          // one stage
   constexpr int TP = BP / 64, TQ = BQ / 64;      // 32x32 accumulators per wave, per dimension
@@ -57,18 +70,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
     w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int MS = d.msteps;
-  const long u0 = tn_unit_begin(d.units, d.W, w), u1 = tn_unit_begin(d.units, d.W, w + 1);
+  const int KT = d.kt;
+  if (KT > 0) w = blockIdx.x;
+  const long u0 = KT > 0 ? 0 : tn_unit_begin(d.units, d.W, w), u1 = KT > 0 ? 1 : tn_unit_begin(d.units, d.W, w + 1);
 
   for (long u = u0; u < u1;) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));  // keep lane-dependent addressing inside the segment loop
     const int lane = tid & 63;
-    const int tile = (int)(u / MS);
-    const int s_begin = (int)(u - (long)tile * MS);
-    const long rest = u1 - (long)tile * MS;
-    const int s_end = rest < MS ? (int)rest : MS;
-    const int slot = (u == u0) ? 2 * w : 2 * w + 1;
-    u += s_end - s_begin;
+    int tile, s_begin, s_end, slot;
+    const int sstep = KT > 0 ? KT : 1;
+    if (KT > 0) {
+      const int T = d.ptiles * d.qtiles;
+      tile = w % T;
+      s_begin = w / T;
+      s_end = MS;
+      slot = w;
+      u = u1;
+    } else {
+      tile = (int)(u / MS);
+      s_begin = (int)(u - (long)tile * MS);
+      const long rest = u1 - (long)tile * MS;
+      s_end = rest < MS ? (int)rest : MS;
+      slot = (u == u0) ? 2 * w : 2 * w + 1;
+      u += s_end - s_begin;
+    }
     const int pt = tile / d.qtiles, qt = tile - pt * d.qtiles;
     const int p0 = pt * BP, q0 = qt * BQ;
     f32x16 acc[TP][TQ];
@@ -78,7 +104,154 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
       for (int j = 0; j < TQ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if constexpr (BF) {
+    float descale = 1.0f;
+    if constexpr (MODE == 2) {
+      // ---------------- two-term f16 path ----------------
+      constexpr int LDT = 40;                          // f16 per transposed row (32 m + pad): 80 bytes
+      constexpr int TBUF = 2 * (BP + BQ) * LDT;        // one stage: A_h, A_l, B_h, B_l
+      constexpr int PA = BP / 64, PB = BQ / 64;
+      _Float16* tl = reinterpret_cast<_Float16*>(lds);
+      const int rp = tid & 15, cg = tid >> 4;
+      float sa, sb;
+      {
+        float ma = 0.f, mb = 0.f;
+        for (int k = lane; k < p.amax_a_n; k += 64) ma = fmaxf(ma, p.amax_a[k]);
+        for (int k = lane; k < p.amax_b_n; k += 64) mb = fmaxf(mb, p.amax_b[k]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          ma = fmaxf(ma, __shfl_xor(ma, off));
+          mb = fmaxf(mb, __shfl_xor(mb, off));
+        }
+        sa = ch2::pow2_scale(ma, 14);
+        sb = ch2::pow2_scale(mb, 14);
+        descale = (1.0f / sa) * (1.0f / sb);
+      }
+      int tdy[PA], tdx[PA], tci[PA];
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        const int col = p0 + 4 * (cg + 16 * q);
+        tdy[q] = 0; tdx[q] = 0; tci[q] = col;
+        if (CONV) {
+          const int tap = col / p.Cin;
+          tci[q] = col - tap * p.Cin;
+          tdy[q] = tap / 3 - 1;
+          tdx[q] = tap - (tap / 3) * 3 - 1;
+        }
+      }
+      float4 xa[2][PA][2], xb[2][PB][2];
+      auto load = [&](int s, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const long m = (long)s * 32 + 2 * rp + h;
+          const bool okm = m < p.M;
+          const long mm = okm ? m : 0;
+          int y = 0, x = 0;
+          if (CONV) {
+            const int hw = p.H * p.W;
+            const int rem = (int)(mm % hw);
+            y = rem / p.W;
+            x = rem - y * p.W;
+          }
+#pragma unroll
+          for (int q = 0; q < PA; ++q) {
+            bool ok = okm;
+            const float* src;
+            if (CONV) {
+              const int yy = y + tdy[q], xx = x + tdx[q];
+              ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+              src = p.a + (size_t)(ok ? mm + tdy[q] * p.W + tdx[q] : 0) * p.Cin + tci[q];
+            } else {
+              src = p.a + (size_t)mm * p.lda + tci[q];
+            }
+            const float4 v = *reinterpret_cast<const float4*>(src);
+            xa[SET][q][h] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int q = 0; q < PB; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(p.b + (size_t)mm * p.ldb + q0 + 4 * (cg + 16 * q));
+            xb[SET][q][h] = okm ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      };
+      typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+      // rows (m, m + 1) of four columns: per column one f16 pair into the h plane, one into the l plane
+      auto put = [&](_Float16* th, _Float16* tlo, int colbase, const float4& lo, const float4& hi, float sc) {
+        const float l4[4] = {lo.x, lo.y, lo.z, lo.w}, h4[4] = {hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v0 = l4[j] * sc, v1 = h4[j] * sc;
+          h2v vh, vl;
+          vh[0] = (_Float16)v0;
+          vh[1] = (_Float16)v1;
+          vl[0] = (_Float16)(v0 - (float)vh[0]);
+          vl[1] = (_Float16)(v1 - (float)vh[1]);
+          *reinterpret_cast<h2v*>(&th[(colbase + j) * LDT + 2 * rp]) = vh;
+          *reinterpret_cast<h2v*>(&tlo[(colbase + j) * LDT + 2 * rp]) = vl;
+        }
+      };
+      auto store = [&](int buf, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+        _Float16* ta = tl + buf * TBUF;
+        _Float16* tb = ta + 2 * BP * LDT;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) put(ta, ta + BP * LDT, 4 * (cg + 16 * q), xa[SET][q][0], xa[SET][q][1], sa);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) put(tb, tb + BQ * LDT, 4 * (cg + 16 * q), xb[SET][q][0], xb[SET][q][1], sb);
+      };
+      auto compute = [&](int cur) {
+        const _Float16* ta = tl + cur * TBUF + (wm * (BP / 2) + (lane & 31)) * LDT + 8 * (lane >> 5);
+        const _Float16* tb = tl + cur * TBUF + 2 * BP * LDT + (wn * (BQ / 2) + (lane & 31)) * LDT + 8 * (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          ch_h8 ah[TP], al[TP], bh[TQ], bl[TQ];
+#pragma unroll
+          for (int i = 0; i < TP; ++i) {
+            ah[i] = *reinterpret_cast<const ch_h8*>(ta + i * 32 * LDT + kk * 16);
+            al[i] = *reinterpret_cast<const ch_h8*>(ta + BP * LDT + i * 32 * LDT + kk * 16);
+          }
+#pragma unroll
+          for (int j = 0; j < TQ; ++j) {
+            bh[j] = *reinterpret_cast<const ch_h8*>(tb + j * 32 * LDT + kk * 16);
+            bl[j] = *reinterpret_cast<const ch_h8*>(tb + BQ * LDT + j * 32 * LDT + kk * 16);
+          }
+#pragma unroll
+          for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+      };
+      const int nsteps = (s_end - s_begin + sstep - 1) / sstep;
+      auto S = [&](int i) { return s_begin + (i < nsteps ? i : nsteps - 1) * sstep; };
+      using std::integral_constant;
+      load(S(0), integral_constant<int, 0>{});
+      load(S(1), integral_constant<int, 1>{});
+      store(0, integral_constant<int, 0>{});
+      __syncthreads();
+      int cur = 0;
+      for (int i = 0; i < nsteps; i += 2) {
+        // step i is in buffer cur, register set 1 holds step i + 1, set 0 is free
+        load(S(i + 2), integral_constant<int, 0>{});
+        compute(cur);
+        store(cur ^ 1, integral_constant<int, 1>{});
+        __syncthreads();
+        cur ^= 1;
+        if (i + 1 >= nsteps) break;
+        load(S(i + 3), integral_constant<int, 1>{});
+        compute(cur);
+        store(cur ^ 1, integral_constant<int, 0>{});
+        __syncthreads();
+        cur ^= 1;
+      }
+    } else if constexpr (BF) {
       // ---------------- bf16 path ----------------
       constexpr int LDT = 40;                          // bf16 per transposed row (32 m + pad)
       constexpr int TBUF = (BP + BQ) * LDT;            // one stage, in bf16
@@ -154,8 +327,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
       store(0);
       __syncthreads();
       int cur = 0;
-      for (int s = s_begin; s < s_end; ++s) {
-        const int sn = (s + 1 < s_end) ? s + 1 : s;
+      for (int s = s_begin; s < s_end; s += sstep) {
+        const int sn = (s + sstep < s_end) ? s + sstep : s;
         load(sn);
         const __bf16* ta = tl + cur * TBUF + (wm * (BP / 2) + (lane & 31)) * LDT + 8 * (lane >> 5);
         const __bf16* tb = tl + cur * TBUF + BP * LDT + (wn * (BQ / 2) + (lane & 31)) * LDT + 8 * (lane >> 5);
@@ -232,8 +405,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
     store(0);
     __syncthreads();
     int cur = 0;
-    for (int s = s_begin; s < s_end; ++s) {
-      const int sn = (s + 1 < s_end) ? s + 1 : s;
+    for (int s = s_begin; s < s_end; s += sstep) {
+      const int sn = (s + sstep < s_end) ? s + sstep : s;
       load(sn);
       const float* la = &lds[cur * BUF] + wm * (BP / 2) + (lane & 31);
       const float* lb = &lds[cur * BUF] + 32 * LDP + wn * (BQ / 2) + (lane & 31);
@@ -259,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
       cur ^= 1;
     }
     }  // fp32 path
-    const bool whole = s_begin == 0 && s_end == MS;
+    const bool whole = s_begin == 0 && s_end == MS && sstep == 1;
     float* slab = d.ws + (size_t)slot * BP * BQ;  // tile-local row-major [BP][BQ]
 #pragma unroll
     for (int i = 0; i < TP; ++i)
@@ -271,11 +444,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_mfma(const TnDev d) {
           const int col = wn * (BQ / 2) + j * 32 + (lane & 31);
           if (whole) {  // the whole reduction of this tile: finish in place (tn_fixup skips it)
             const size_t o = (size_t)(p0 + row) * p.ldc + q0 + col;
-            float v = acc[i][j][r];
+            float v = acc[i][j][r] * descale;
             if (p.l2 != 0.f) v += p.l2 * p.wcur[o];
             p.c[o] = v;
           } else {
-            slab[row * BQ + col] = acc[i][j][r];
+            slab[row * BQ + col] = acc[i][j][r] * descale;
           }
         }
     if (u < u1) __syncthreads();
@@ -287,6 +460,27 @@ template <int BP, int BQ>
 __global__ __launch_bounds__(256) void tn_fixup(const TnDev d) {
   const TnParams& p = d.p;
   const int tile = blockIdx.x;
+  if (d.kt > 0) {  // interleaved reduction: slabs tile + T k, k = 0 .. kt - 1
+    if (d.kt == 1) return;
+    const int T = d.ptiles * d.qtiles;
+    const int idx4 = blockIdx.y * 256 + threadIdx.x;
+    const int lrow = idx4 / (BQ / 4), lcol = (idx4 - lrow * (BQ / 4)) * 4;
+    const float* base = d.ws + (size_t)lrow * BQ + lcol;
+    const size_t slab = (size_t)BP * BQ;
+    float4 v = *reinterpret_cast<const float4*>(base + (size_t)tile * slab);
+    for (int k = 1; k < d.kt; ++k) {
+      const float4 u = *reinterpret_cast<const float4*>(base + (size_t)(tile + T * k) * slab);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int pt = tile / d.qtiles, qt = tile - pt * d.qtiles;
+    const size_t o = (size_t)(pt * BP + lrow) * p.ldc + qt * BQ + lcol;
+    if (p.l2 != 0.f) {
+      const float4 wv = *reinterpret_cast<const float4*>(p.wcur + o);
+      v.x += p.l2 * wv.x; v.y += p.l2 * wv.y; v.z += p.l2 * wv.z; v.w += p.l2 * wv.w;
+    }
+    *reinterpret_cast<float4*>(p.c + o) = v;
+    return;
+  }
   const long MS = d.msteps, tb = (long)tile * MS, te = tb + MS;
   int w = (int)((tb * d.W) / d.units);
   while (w + 1 < d.W && tn_unit_begin(d.units, d.W, w + 1) <= tb) ++w;
@@ -322,9 +516,10 @@ size_t gemm_tn_ws_bytes(long M, int P, int Q) {
   return (size_t)2 * kTnMaxW * 128 * 128 * sizeof(float);
 }
 
-template <int BP, int BQ, bool CONV, bool BF>
+template <int BP, int BQ, bool CONV, int BF>
 static hipError_t tn_launch_kernel(const TnDev& d, hipStream_t st) {
-  const size_t lds_bytes = BF ? (size_t)2 * (BP + BQ) * 40 * 2 : (size_t)2 * 32 * (BP + 8 + BQ + 8) * sizeof(float);
+  const size_t lds_bytes = BF == 2 ? (size_t)4 * (BP + BQ) * 40 * 2
+                                   : (BF ? (size_t)2 * (BP + BQ) * 40 * 2 : (size_t)2 * 32 * (BP + 8 + BQ + 8) * sizeof(float));
   static bool attr_done = false;  // benign race: idempotent attribute
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f32_mfma<BP, BQ, CONV, BF>),
@@ -345,11 +540,30 @@ static hipError_t tn_launch_tile(const TnParams& p, float* ws, hipStream_t st) {
   d.qtiles = p.Q / BQ;
   d.units = (long)d.ptiles * d.qtiles * d.msteps;
   d.W = (int)(d.units < kTnMaxW ? d.units : kTnMaxW);
+  d.kt = 0;
+  // Interleaved row steps for the forms that stage transposed 16-bit operands (bf16, two-term f16), from 18 tiles on:
+  // measured at 8 samples (tools/conv_bwd_time.py, r03aa / r03ab) 56 x 56, 256 -> 256: 222 -> 194 us (bf16), 300 -> 275
+  // (f16 split); 28 x 28, 256 -> 512: 132 -> 105, 177 -> 153; no gain with 9 tiles (112 x 112) and none for the
+  // fp32-MFMA form (MFMA-bound), which keeps the contiguous stream-K ranges.
+  const int T0 = d.ptiles * d.qtiles;
+  const bool inter = tune::tn_interleave < 0 ? (p.bf16 != 0 && T0 >= 18) : tune::tn_interleave != 0;
+  if (inter) {
+    const int T = T0;
+    int kt = tune::tn_interleave > 1 ? tune::tn_interleave : kTnMaxW / T;
+    if (kt > d.msteps) kt = d.msteps;
+    if (kt < 1) kt = 1;
+    if ((long)T * kt <= 2 * kTnMaxW) {
+      d.kt = kt;
+      d.W = T * kt;
+    }
+  }
   hipError_t e;
   if (p.Cin > 0)
-    e = p.bf16 ? tn_launch_kernel<BP, BQ, true, true>(d, st) : tn_launch_kernel<BP, BQ, true, false>(d, st);
+    e = p.bf16 == 2 ? tn_launch_kernel<BP, BQ, true, 2>(d, st)
+                    : (p.bf16 ? tn_launch_kernel<BP, BQ, true, 1>(d, st) : tn_launch_kernel<BP, BQ, true, 0>(d, st));
   else
-    e = p.bf16 ? tn_launch_kernel<BP, BQ, false, true>(d, st) : tn_launch_kernel<BP, BQ, false, false>(d, st);
+    e = p.bf16 == 2 ? tn_launch_kernel<BP, BQ, false, 2>(d, st)
+                    : (p.bf16 ? tn_launch_kernel<BP, BQ, false, 1>(d, st) : tn_launch_kernel<BP, BQ, false, 0>(d, st));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((tn_fixup<BP, BQ>), dim3(d.ptiles * d.qtiles, BP * BQ / 1024), dim3(256), 0, st, d);
   return hipGetLastError();
@@ -360,7 +574,8 @@ hipError_t gemm_tn_launch(const TnParams& pin, float* ws, hipStream_t st) {
   const bool p128 = p.P % 128 == 0, q128 = p.Q % 128 == 0;
   // the bf16 form pays for its transposing stage only with the 128x128 tile (measured: 64-wide
   // tiles 62 TFLOP/s in bf16 against 76 in fp32)
-  if (!(p128 && q128)) p.bf16 = 0;
+  if (p.bf16 == 1 && !(p128 && q128)) p.bf16 = 0;
+  if (p.bf16 == 2 && (!p.amax_a || !p.amax_b || p.amax_a_n <= 0 || p.amax_b_n <= 0)) p.bf16 = 0;  // no operand maxima: fp32 MFMA
   if (p128 && q128) return tn_launch_tile<128, 128>(p, ws, st);
   if (p128) return tn_launch_tile<128, 64>(p, ws, st);
   if (q128) return tn_launch_tile<64, 128>(p, ws, st);

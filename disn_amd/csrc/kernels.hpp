@@ -156,7 +156,11 @@ struct TnParams {
   int H, W, Cin;
   float l2;           // the fix-up adds l2 * wcur (weight-decay gradient); 0: nothing
   const float* wcur;  // same layout as c
-  int bf16;           // multiply on the bf16 MFMA (operands rounded when staged), fp32 accumulate
+  int bf16;           // 1: multiply on the bf16 MFMA (operands rounded when staged), fp32 accumulate;
+                      // 2: fp32-accurate two-term f16 split on the f16 MFMA -- needs the operands' maxima:
+  const float* amax_a = nullptr;  // amax_a_n device floats whose maximum is >= max |a| (e.g. per-image slots)
+  const float* amax_b = nullptr;
+  int amax_a_n = 0, amax_b_n = 0;
 };
 size_t gemm_tn_ws_bytes(long M, int P, int Q);
 hipError_t gemm_tn_launch(const TnParams& p, float* ws, hipStream_t st);

@@ -171,10 +171,17 @@ int dense_bwd(const float* a, int lda, int K, const float* w_kn, const float* dz
 // h2img != nullptr: the data gradient through conv_h2.hip / conv_h2w.hip -- dx = conv(dz, w') with the mirrored,
 // transposed kernel's two-term f16 image (conv_h2_pack_launch(flip_t)), dz split per image against its own maximum
 // (amax: B x 64 slots) -- instead of the implicit-GEMM kernels on `prepacked`
+// amax_x (with amax): B x 64 floats whose maximum bounds |x| -- then the weight gradient of the fp32-accurate mode
+// (s.ns == 3) runs as a two-term f16 split too (gemm_tn_mfma.hip, mode 2) instead of on the fp32 MFMA
 int conv_bwd(const float* x, int B, int H, int W, int Cin, const float* w, const float* dz, int Cout,
              float wd, float* dx, float* dw, float* col, const BwdWs& s, hipStream_t st,
-             const float* prepacked = nullptr, const void* h2img = nullptr, float* amax = nullptr) {
+             const float* prepacked = nullptr, const void* h2img = nullptr, float* amax = nullptr,
+             const float* amax_x = nullptr) {
   const long M = (long)B * H * W;
+  if (amax && Cin != 3) {  // maxima of dz per image: the data gradient's operand scales, the weight gradient's bound
+    DISN_TRY(hipMemsetAsync(amax, 0, (size_t)B * 64 * sizeof(float), st));
+    DISN_TRY(amax64_accumulate_launch(dz, (size_t)H * W * Cout, amax, st, B, 64));
+  }
   if (Cin == 3) {
     DISN_TRY(im2col_c3_launch(x, B, H, W, col, st));
     TnParams t{};
@@ -186,11 +193,14 @@ int conv_bwd(const float* x, int B, int H, int W, int Cin, const float* w, const
     TnParams t{};
     t.a = x; t.lda = Cin; t.b = dz; t.ldb = Cout; t.M = M; t.P = 9 * Cin; t.Q = Cout;
     t.c = dw; t.ldc = Cout; t.H = H; t.W = W; t.Cin = Cin; t.l2 = wd; t.wcur = w; t.bf16 = s.ns == 1;
+    if (s.ns == 3 && amax && amax_x) {
+      t.bf16 = 2;
+      t.amax_a = amax_x; t.amax_a_n = B * 64;
+      t.amax_b = amax; t.amax_b_n = B * 64;
+    }
     DISN_TRY(gemm_tn_launch(t, s.tn_ws, st));
   }
   if (dx && h2img) {
-    DISN_TRY(hipMemsetAsync(amax, 0, (size_t)B * 64 * sizeof(float), st));
-    DISN_TRY(amax64_accumulate_launch(dz, (size_t)H * W * Cout, amax, st, B, 64));
     DISN_TRY(conv_h2_launch(dz, B, H, W, Cout, h2img, s.zero, Cin, 0, amax, dx, nullptr, nullptr, st, 0, 64));
   } else if (dx) {
     const float* wt = prepacked;
@@ -363,7 +373,7 @@ size_t disn_conv3x3_backward_workspace_bytes(int B, int H, int W, int Cin, int C
   if (Cin == 3) b.take((size_t)M * 64);
   else {  // the data gradient's two-term f16 image and its B x 64 maxima (compute_bf16 != 0)
     b.take(conv_h2_image_bytes(Cout, Cin) / sizeof(float) + 1);
-    b.take((size_t)B * 64);
+    b.take((size_t)B * 128);
   }
   return bwd_layout(b, (size_t)9 * (Cin == 3 ? 64 : Cin) * Cout, M, g, colsum_ws_bytes(M, Cout)).total;
 }
@@ -379,7 +389,7 @@ int disn_conv3x3_backward(const float* x, int B, int H, int W, int Cin, const fl
   const int M = B * H * W;
   float* col = Cin == 3 ? b.take((size_t)M * 64) : nullptr;
   float* h2img = Cin == 3 ? nullptr : b.take(conv_h2_image_bytes(Cout, Cin) / sizeof(float) + 1);
-  float* h2amax = Cin == 3 ? nullptr : b.take((size_t)B * 64);
+  float* h2amax = Cin == 3 ? nullptr : b.take((size_t)B * 128);
   const size_t g = Cin == 3 ? 256
                             : max_sz(max_sz(gemm_plan(M, Cin, 9 * Cout).ws_bytes,
                                             gemm_bf16_ws_bytes(M, Cin, 9 * Cout)), 256);
@@ -393,7 +403,13 @@ int disn_conv3x3_backward(const float* x, int B, int H, int W, int Cin, const fl
     float* scratch = h2img + (size_t)Cin * 9 * Cout + 2;
     DISN_TRY(conv_h2_pack_launch(w_hwio, Cout, Cin, h2img, scratch, st, 9, 1));
   }
-  return conv_bwd(x, B, H, W, Cin, w_hwio, dy, Cout, wd, dx, dw, col, s, st, nullptr, h2 ? h2img : nullptr, h2amax);
+  const bool maxima = compute_bf16 != 0 && Cin != 3;   // dz maxima: data gradient and (mode 2) weight gradient
+  if (maxima && compute_bf16 == 2) {
+    DISN_TRY(hipMemsetAsync(h2amax + (size_t)B * 64, 0, (size_t)B * 64 * sizeof(float), st));
+    DISN_TRY(amax64_accumulate_launch(x, (size_t)H * W * Cin, h2amax + (size_t)B * 64, st, B, 64));
+  }
+  return conv_bwd(x, B, H, W, Cin, w_hwio, dy, Cout, wd, dx, dw, col, s, st, nullptr, h2 ? h2img : nullptr,
+                  maxima ? h2amax : nullptr, maxima && compute_bf16 == 2 ? h2amax + (size_t)B * 64 : nullptr);
 }
 
 int disn_maxpool2x2_backward(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
@@ -683,7 +699,8 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
       if (dx == dy) dx = bufs[which ^ 1];
     }
     DISN_RC(conv_bwd(xin, B, c.hw, c.hw, c.cin, P(2 * i), dy, c.cout, wd, dx, G(2 * i), t.col, s, st,
-                     t.conv_bT[i], h2fwd && i > 0 ? t.conv_h2bT[i] : nullptr, t.amax_bwd));
+                     t.conv_bT[i], h2fwd && i > 0 ? t.conv_h2bT[i] : nullptr, h2fwd && i > 0 ? t.amax_bwd : nullptr,
+                     h2fwd && i > 0 ? t.amax + (size_t)B * 64 * i : nullptr));
     if (dx) {
       which = (dx == bufs[0]) ? 1 : 0;
       dcur = dx;

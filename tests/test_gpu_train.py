@@ -102,10 +102,17 @@ def test_conv3x3_data_gradient_through_conv_h2(ops, B, H, Cin, Cout):
     wt = torch.tensor(w, dtype=torch.float64)
     # dx = conv_transpose of dz: the full correlation with the mirrored kernel
     ref = Fnn.conv_transpose2d(dzt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1).numpy()
-    dx, dw, db = ops.conv3x3_backward(dev(x), dev(w), None, dev(dz), wd=0.0, compute_bf16=2)
+    dx, dw, db = ops.conv3x3_backward(dev(x), dev(w), None, dev(dz), wd=1e-3, compute_bf16=2)
     got = host(dx)
     for b in range(B):   # per sample: each has its own scale
         rel_close("dx[%d]" % b, got[b], ref[b], 2e-6)
+    # the weight gradient of the same mode: two-term f16 split of x and dz (one scale per tensor) in the TN GEMM
+    xt = torch.tensor(x, dtype=torch.float64)
+    wt.requires_grad_(True)
+    out = Fnn.conv2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), None, padding=1).permute(0, 2, 3, 1)
+    (out * dzt).sum().backward()
+    rel_close("dw", host(dw), wt.grad.numpy() + 1e-3 * w.astype(np.float64), 2e-6)
+    rel_close("db", host(db), dz.astype(np.float64).sum((0, 1, 2)), 2e-6)
     dz0 = dz.copy()
     dz0[1:] = 0
     dx0, _, _ = ops.conv3x3_backward(dev(x), dev(w), None, dev(dz0), wd=0.0, compute_bf16=2)
