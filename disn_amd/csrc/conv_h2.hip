@@ -647,6 +647,17 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
   // and walk K sequentially, 12 .. 21 MFMAs per weight pair.  Its summation order differs from the k-wave tree
   // below (fp32 rounding; both inside the 1e-5 bar): an image's bits depend on WHICH FORM runs it (fewer than
   // kConvWideMinImages images per call or not), never on the other images of its call.  tiling 5..9: forced variants.
+  // 14 x 14 layers (conv5_x) of a batched call (B >= 4, as for the batched form below): FOUR k-waves, whatever B -- so
+  // their bits, like the other layers', depend on "four images or more per call" only.  Where that fills the chip
+  // (B Cout / 32 >= 200 workgroups: from 13 images on at 512 channels) ONE workgroup per image and n-block takes the
+  // whole image as one patch of seven 32-pixel blocks: the two-row patches give a weight pair three MFMAs (1.03 GB of
+  // fragment reads for conv5_x of 16 images: L2-bound, 32 % MFMA busy, 65 us), the whole image 21 (52 us).  Smaller
+  // calls keep the two-row patches (measured equal to the eight-k-wave tiling at 4 / 8 / 12 images: r03ad).
+  if (cfg == 10) return conv_h2_go<7, 1, 16, 14, 3, 4>(d, st);
+  if (cfg == 0 && tune::conv5_whole && W <= 14 && H <= 14 && B >= tune::conv_wide_min) {
+    if ((long)B * (Cout / 32) >= 200) return conv_h2_go<7, 1, 16, 14, 3, 4>(d, st);
+    return conv_h2_go<1, 1, 16, 14, 3, 4, 2>(d, st);
+  }
   if (cfg >= 5) return conv_h2w_supported(H, W, Cin, Cout) ? conv_h2w_launch(d, st, cfg - 4) : hipErrorInvalidValue;
   if (cfg == 0 && B >= tune::conv_wide_min && conv_h2w_supported(H, W, Cin, Cout)) return conv_h2w_launch(d, st, 0);
   if (cfg == 0) {
@@ -719,9 +730,10 @@ int disn_conv3x3_h2(const float* in, int B, int H, int W, int Cin, const void* i
                     int relu, float* out, float* pool_out, float* out_amax, int tiling, void* ws, size_t ws_bytes,
                     void* stream) {
   if (!in || !image || !bias || !out || !ws || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
-  if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 9 || (pool_out && ((H | W) & 1)))
+  if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 10 || (pool_out && ((H | W) & 1)))
     return DISN_E_SHAPE;
-  if (tiling >= 5 && !disn::conv_h2w_supported(H, W, Cin, Cout)) return DISN_E_SHAPE;
+  if (tiling >= 5 && tiling <= 9 && !disn::conv_h2w_supported(H, W, Cin, Cout)) return DISN_E_SHAPE;
+  if (tiling == 10 && (H > 14 || W > 14)) return DISN_E_SHAPE;
   if (ws_bytes < (size_t)B * 512) return DISN_E_WS;
   hipStream_t st = (hipStream_t)stream;
   // every image its own 64 slots in / 64 slots out, as inside disn_encode*: an image's scale, hence its bits, do

@@ -70,6 +70,31 @@ def test_vgg_layer_shapes_vs_float64(ops, hw, cin, cout):
     assert float(amax) == float(np.abs(got).max())
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 14, 14, 512, 512), (3, 14, 14, 64, 128), (2, 10, 12, 192, 64),
+                                            (5, 14, 14, 512, 512), (16, 14, 14, 512, 512)])
+def test_whole_image_tiling_of_14_pixel_layers(ops, B, H, W, Cin, Cout):
+    """tiling 10: one workgroup per image and n-block, the image as ONE patch (seven 32-pixel blocks), four k-waves --
+    what tiling 0 takes for 14 x 14 layers when B * Cout / 32 >= 200 (conv5_x of a 16-image call).  Against float64;
+    pool and maximum from the same values; an image's bits do not depend on its companions; every call of four images
+    and more (tiling 0) gives these bits: four k-waves, as a whole image or in two-row patches."""
+    x, w, b = case(B, H, W, Cin, Cout, 1000 + B + H + Cin, relu_input=Cin == 512)
+    ref = O.conv2d(x, w, b, "SAME", True, dtype=np.float64)
+    img = ops.pack_conv_h2(dev(w))
+    out, pooled, amax = ops.conv3x3_h2(dev(x), img, dev(b), Cout, True, pool=True, want_amax=True, tiling=10)
+    got = host(out)
+    scale = float(np.abs(ref).max())
+    report_close("conv3x3_h2 whole-image tiling %s" % ((B, H, W, Cin, Cout),), got, ref, atol=2e-6 * scale)
+    assert np.array_equal(host(pooled), got.reshape(B, H // 2, 2, W // 2, 2, Cout).max(axis=(2, 4)))
+    assert float(amax) == float(np.abs(got).max())
+    alone = host(ops.conv3x3_h2(dev(x[B - 1:]), img, dev(b), Cout, True, tiling=10))
+    assert np.array_equal(alone[0], got[B - 1])
+    if B >= 4:
+        assert np.array_equal(host(ops.conv3x3_h2(dev(x), img, dev(b), Cout, True, tiling=0)), got)
+    # four k-waves: the bits of the other four-k-wave tilings
+    if Cin % 128:
+        assert np.array_equal(host(ops.conv3x3_h2(dev(x), img, dev(b), Cout, True, tiling=1)), got)
+
+
 @pytest.mark.parametrize("tiling", [1, 2, 3, 4])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 20, 18, 64, 128), (1, 30, 44, 128, 64), (3, 6, 8, 192, 64)])
 def test_every_tiling_on_ragged_shapes(ops, tiling, B, H, W, Cin, Cout):
@@ -101,19 +126,21 @@ def test_tilings_agree_bit_for_bit_and_runs_repeat(ops):
         assert np.array_equal(o[0], v)
 
 
-def test_multi_round_variants_give_the_single_image_bits(ops):
-    """14-pixel layers (conv5_x) of a batched call stay on conv_h2.hip: a launch of several rounds of workgroups
-    (here: four copies of one image) goes through its two-workgroups-per-CU variant (smaller register budget,
-    one-pair weight queue); k-waves and summation order are the single-image tiling's, so are the bits -- and the
-    pooled copy's."""
+def test_14_pixel_layers_of_a_batched_call_run_with_four_k_waves(ops):
+    """14-pixel layers (conv5_x) stay on conv_h2.hip; in a call of four images and more they run with FOUR k-waves
+    (two-row patches, two workgroups per CU, or the whole-image tiling in large calls): the bits of the four-k-wave
+    order whatever the tiling -- here four copies of one image against that image through tiling 10 -- and within fp32
+    rounding of the single-image call's eight-k-wave tree."""
     hw, cin, cout = 14, 512, 512
     x, w, b = case(1, hw, hw, cin, cout, 77 + hw)
     img = ops.pack_conv_h2(dev(w))
-    one, pool1, _ = ops.conv3x3_h2(dev(x), img, dev(b), cout, True, pool=True, want_amax=True)
+    one, pool1, _ = ops.conv3x3_h2(dev(x), img, dev(b), cout, True, pool=True, want_amax=True, tiling=10)
     four, pool4, amax4 = ops.conv3x3_h2(dev(np.repeat(x, 4, axis=0)), img, dev(b), cout, True, pool=True, want_amax=True)
     for k in range(4):
         assert torch.equal(four[k], one[0]) and torch.equal(pool4[k], pool1[0]), k
     assert float(amax4) == float(one.abs().max())
+    single = ops.conv3x3_h2(dev(x), img, dev(b), cout, True)      # eight k-waves
+    assert float((single - one).abs().max()) <= 2e-6 * float(one.abs().max())
 
 
 # ---- the batched form (disn_amd/csrc/conv_h2w.hip): tiling 5..9 force its variants 1..5, tiling 0 takes it from
