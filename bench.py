@@ -424,7 +424,7 @@ def main():
     gc.enable()
     if pipe.trace:
         print("[bench] enqueue times (ms after t0) per call: " +
-              " ".join("%d:%.2f" % (i, (t - t0) * 1e3) for i, g, t in sorted(pipe.trace, key=lambda x: x[2])) +
+              " ".join("%d[%s]:%.2f" % (i, g, (t - t0) * 1e3) for i, g, t in sorted(pipe.trace, key=lambda x: x[2])) +
               " | done %.2f" % (dt * 1e3), file=sys.stderr)
     out = outs[0]
     # the same job submitted again (another call, another context, possibly the other form of the convolutions when

@@ -172,9 +172,8 @@ void conv_h2_pack_job_add(ConvH2PackJobs& jobs, const float* w_fwd, int Cin_fwd,
   J.Cout = flip_t ? Cin_fwd : Cout_fwd;
   J.frag_begin = jobs.total_frags;
   jobs.total_frags += (long)(J.Cout >> 5) * (J.Cin >> 4) * 9;
-  if (slot >= jobs.nslots) {   // slots are added in order, one tensor each
+  if (slot >= jobs.nslots) {   // slots are added in order (0, 1, ...), one tensor each; seg_begin[0] == 0
     jobs.seg[slot] = w_fwd;
-    jobs.seg_begin[slot] = slot == 0 ? 0 : jobs.seg_begin[slot];
     jobs.seg_begin[slot + 1] = jobs.seg_begin[slot] + (long)9 * Cin_fwd * Cout_fwd;
     jobs.nslots = slot + 1;
   }

@@ -177,6 +177,10 @@ class SdfEngine:
 
     def _dev(self, a) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
+            # (the common case first: a resident fp32 tensor costs one comparison chain, not two dispatcher calls -- a
+            # 16-step call assembles 48 of them on the host before its first launch)
+            if a.dtype is torch.float32 and a.device == self.device and a.is_contiguous():
+                return a
             return a.to(self.device, torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
@@ -488,14 +492,18 @@ class StepPipeline:
         mine = [[g for g in range(len(groups)) if g % S == i] for i in range(S)]
 
         def work(i):
+            if self.trace is not None:           # host-side pacing: this context's host thread is running
+                self.trace.append((i, "start", time.perf_counter()))
             self.streams[i].wait_stream(cur)
             for g in mine[i]:
                 idx = groups[g]
                 if len({tuple(jobs[k][1].shape) for k in idx}) != 1:
                     raise ValueError("jobs of one batch must have point sets of one shape")
                 args = [cat(idx, p) for p in range(len(jobs[idx[0]]))]
+                if self.trace is not None:       # ... the call's inputs are assembled
+                    self.trace.append((i, "call %d" % g, time.perf_counter()))
                 enc, sdf = self.engines[i].encode_query(*args)
-                if self.trace is not None:       # host-side pacing: when this call's launches were all enqueued
+                if self.trace is not None:       # ... its launches are all enqueued
                     self.trace.append((i, g, time.perf_counter()))
                 o = 0
                 for k in idx:
