@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * (BN / 2) + j * 32 + scol;
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (d.S == 1) bv = *reinterpret_cast<const float4*>(p.bias + col);
+      if (d.S == 1 && !p.rows_per_bias) bv = *reinterpret_cast<const float4*>(p.bias + col);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -430,6 +430,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
             if (d.S > 1) {
               *reinterpret_cast<float4*>(d.ws + ((size_t)ks * p.M + row) * p.N + col) = v;
             } else {
+              // rows_per_bias: bias row m / rows_per_bias (the folded per-image term of the global stream's fold2/conv1)
+              if (p.rows_per_bias) bv = *reinterpret_cast<const float4*>(p.bias + (size_t)(row / p.rows_per_bias) * p.N + col);
               v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
               if (p.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_bf16
           if (d.S > 1) {
             d.ws[((size_t)ks * p.M + row) * p.N + col] = acc[i][j][r];
           } else {
-            float v = acc[i][j][r] + bv;
+            float v = acc[i][j][r] + (p.rows_per_bias ? p.bias[(size_t)(row / p.rows_per_bias) * p.N + col] : bv);
             if (p.relu) v = fmaxf(v, 0.f);
             p.out[(size_t)row * p.ldc + col] = v;
           }
@@ -489,7 +491,7 @@ static hipError_t bf_launch_mode(const BfDev& d, GemmMode mode, hipStream_t st) 
   if (d.pool_out)
     return splitk_reduce_pool_launch(d.ws, d.S, d.p.M / (d.p.H * d.p.W), d.p.H, d.p.W, d.p.N, d.p.bias,
                                      d.p.relu, d.p.out, d.pool_out, st);
-  return splitk_reduce_launch(d.ws, d.S, d.p.M, d.p.N, d.p.bias, 0, d.p.relu, d.p.out, d.p.ldc, st);
+  return splitk_reduce_launch(d.ws, d.S, d.p.M, d.p.N, d.p.bias, d.p.rows_per_bias, d.p.relu, d.p.out, d.p.ldc, st);
 }
 
 // split-K factor for a layer with few 64x64 tiles (the 14x14 / 28x28 convolutions, small point

@@ -85,12 +85,13 @@ void build_layout(disn_param_layout_t* L) {
 
 int dense_fwd(const float* a1, int lda1, int k1, const float* a2, int lda2, int K, int M,
               const float* bp, const float* bias, int N, int relu, float* out, float* ws,
-              size_t ws_bytes, hipStream_t st, int ns = 0) {
+              size_t ws_bytes, hipStream_t st, int ns = 0, int rows_per_bias = 0) {
   // ns != 0: bp is a pack_bf16_launch image; 1 = bf16 multiply, 3 = three-term split (fp32-accurate)
+  // rows_per_bias != 0: bias is [M / rows_per_bias][N], one row per image
   GemmParams p{};
   p.a1 = a1; p.lda1 = lda1; p.k1 = k1; p.a2 = a2; p.lda2 = lda2;
   p.M = M; p.N = N; p.K = K;
-  p.bp = bp; p.bias = bias; p.rows_per_bias = 0;
+  p.bp = bp; p.bias = bias; p.rows_per_bias = rows_per_bias;
   p.out = out; p.ldc = N; p.relu = relu;
   if (ns) {
     DISN_TRY(gemm_bf16_launch(p, GEMM_DENSE, bp, ws, ws ? ws_bytes : 0, st, ns));
@@ -599,10 +600,16 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
   DISN_RC(dense_fwd(t.g1, 64, 64, nullptr, 0, 64, (int)M, t.g_p2, P(V_G + 3), 256, 1, t.g2, gws, gwb, st, bf));
   DISN_RC(dense_fwd(t.g2, 256, 256, nullptr, 0, 256, (int)M, t.g_p3, P(V_G + 5), 512, 1, t.g3, gws, gwb, st, bf));
   if (ctx) DISN_TRY(hipStreamWaitEvent(st, ctx->ev[2], 0));  // embedding, gbias, regularization
-  for (int b = 0; b < B; ++b) {
-    const size_t o = (size_t)b * N * 512;
-    DISN_RC(dense_fwd(t.g3 + o, 512, 512, nullptr, 0, 512, N, t.g_p4, t.gbias + (size_t)b * 512, 512, 1,
-                      t.g4 + o, gws, gwb, st, bf));
+  // the folded per-image term is the bias row of the sample: one launch for all samples on the bf16 / three-term kernels
+  // (gemm_bf16_mfma.hip takes a bias row per rows_per_bias rows); the fp32-MFMA GEMM has one bias row: a launch per sample
+  if (bf) {
+    DISN_RC(dense_fwd(t.g3, 512, 512, nullptr, 0, 512, (int)M, t.g_p4, t.gbias, 512, 1, t.g4, gws, gwb, st, bf, N));
+  } else {
+    for (int b = 0; b < B; ++b) {
+      const size_t o = (size_t)b * N * 512;
+      DISN_RC(dense_fwd(t.g3 + o, 512, 512, nullptr, 0, 512, N, t.g_p4, t.gbias + (size_t)b * 512, 512, 1,
+                        t.g4 + o, gws, gwb, st, bf));
+    }
   }
   DISN_RC(dense_fwd(t.g4, 512, 512, nullptr, 0, 512, (int)M, t.g_p5, P(V_G + 9), 256, 1, t.g5, gws, gwb, st, bf));
   DISN_TRY(final_dot_launch(t.g5, t.l5, M, P(V_G + 10), P(V_G + 11), P(V_L + 10), P(V_L + 11), pred,

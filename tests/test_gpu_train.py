@@ -285,6 +285,27 @@ def test_trainer_steps_match_oracle_adam(small_step):
     assert float(losses["overall_loss"]) > 0 and tr.step_count == 1
 
 
+def test_fp32_mfma_mode_tracks_the_default_mode(small_step):
+    """precision="f32_mfma" (compute_bf16 = 0: every product on the f32-input MFMA, implicit-GEMM convolutions, a
+    launch per sample for the global stream's fold2/conv1) against the default fp32-accurate mode (two-term f16 /
+    three-term bf16 kernels): same losses, predictions within 2e-5 of each other, every gradient aligned"""
+    from disn_amd.train_sdf import Trainer
+    from disn_amd.weights import WeightStore
+    s = small_step
+    tr = Trainer(WeightStore(s["weights"]), batch_size=2, precision="f32_mfma")
+    dpred, dl = tr.forward_backward(_dev_feed(s["feed"]))
+    torch.cuda.synchronize()
+    report_close("pred", host(dpred), s["dpred"], atol=2e-5, rtol=1e-5)
+    for i in range(len(s["dl"])):
+        assert abs(float(dl[i]) - float(s["dl"][i])) <= 1e-5 * max(abs(float(s["dl"][i])), 1.0) + 1e-6
+    got, ref = tr.flat.to_arrays(tr.grads), s["tr"].flat.to_arrays(s["tr"].grads)
+    for name in ref:
+        g, r = got[name].astype(np.float64).ravel(), ref[name].astype(np.float64).ravel()
+        cos = float(g @ r / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
+        assert cos > 0.9995, (name, cos)
+    tr.close()
+
+
 def test_training_reduces_the_loss():
     from disn_amd.train_sdf import Trainer
     from disn_amd.weights import WeightStore
