@@ -65,10 +65,14 @@ hipError_t pack_conv_bwd_launch(const float* w, int Cin, int Cout, float* packed
 constexpr int kRowsPerChunk = 256;
 
 // block: 256 threads = CG float4 column groups x RL row lanes; chunk of 256 rows
+// amax != nullptr: also max |masked dy| per image of rpi rows, spread over the image's 64 slots (atomic max of
+// non-negative floats as unsigned: exact, order-free) -- the operand scales of the data gradient that follows
+// (train.hip: saves the separate pass over dy).  A chunk of <= rpc rows touches at most three images (rpi >= rpc / 2).
 __global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__ dy,
                                                              const float* __restrict__ y, long M, int N,
                                                              int relu, int rpc,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, float* __restrict__ amax,
+                                                             long rpi) {
   __shared__ float4 red[256];
   const int cgn = N >> 2;                       // float4 column groups of the matrix
   const int cg_per_block = cgn < 256 ? cgn : 256;
@@ -78,6 +82,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__
   const long r0 = (long)blockIdx.y * rpc;
   const long r1 = r0 + rpc < M ? r0 + rpc : M;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long img0 = amax ? r0 / rpi : 0;
+  const long b1 = (img0 + 1) * rpi, b2 = b1 + rpi;   // rows of image img0 end at b1, of img0 + 1 at b2
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f;
   if (col < N && rl < rl_n) {
     for (long r = r0 + rl; r < r1; r += rl_n) {
       float4 d = *reinterpret_cast<const float4*>(dy + (size_t)r * N + col);
@@ -88,6 +95,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__
         *reinterpret_cast<float4*>(dy + (size_t)r * N + col) = d;
       }
       acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+      if (amax) {
+        const float a = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));
+        if (r < b1) m0 = fmaxf(m0, a);
+        else if (r < b2) m1 = fmaxf(m1, a);
+        else m2 = fmaxf(m2, a);
+      }
+    }
+  }
+  if (amax) {   // wave maxima -> one atomic per wave and image touched
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      m0 = fmaxf(m0, __shfl_xor(m0, off));
+      m1 = fmaxf(m1, __shfl_xor(m1, off));
+      m2 = fmaxf(m2, __shfl_xor(m2, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      const int slot = (int)((blockIdx.y * 4 + (threadIdx.x >> 6) + blockIdx.x * 7) & 63);
+      unsigned* a = reinterpret_cast<unsigned*>(amax);
+      if (m0 > 0.f) atomicMax(a + img0 * 64 + slot, __float_as_uint(m0));
+      if (m1 > 0.f) atomicMax(a + (img0 + 1) * 64 + slot, __float_as_uint(m1));
+      if (m2 > 0.f) atomicMax(a + (img0 + 2) * 64 + slot, __float_as_uint(m2));
     }
   }
   red[threadIdx.x] = acc;
@@ -147,13 +175,18 @@ size_t colsum_ws_bytes(long M, int N) {
   return (size_t)((M + rpc - 1) / rpc) * N * sizeof(float);
 }
 
+// amax (optional): [M / rows_per_image][64] slots, ZEROED by the caller, receive max |masked dy| per image; needs
+// rows_per_image >= colsum_rpc(M) / 2 (a chunk then touches at most three images), else ignored -> returns through
+// *amax_done (optional) whether the maxima were written
 hipError_t relu_bwd_colsum_launch(float* dy, const float* y, long M, int N, int relu, float* db,
-                                  float* ws, hipStream_t st) {
+                                  float* ws, hipStream_t st, float* amax, long rows_per_image, bool* amax_done) {
   const int rpc = colsum_rpc(M);
   const int chunks = (int)((M + rpc - 1) / rpc);
   const int cgn = N / 4, cgb = cgn < 256 ? cgn : 256;
+  const bool with_max = amax && rows_per_image > 0 && 2 * rows_per_image >= rpc;
+  if (amax_done) *amax_done = with_max;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((cgn + cgb - 1) / cgb, chunks), dim3(256), 0, st, dy, y,
-                     M, N, relu, rpc, ws);
+                     M, N, relu, rpc, ws, with_max ? amax : nullptr, with_max ? rows_per_image : 1L);
   hipLaunchKernelGGL(colsum_finish8_kernel, dim3((N + 7) / 8), dim3(256), 0, st, ws, chunks, N, db);
   return hipGetLastError();
 }
@@ -164,7 +197,7 @@ hipError_t image_colsum_launch(const float* x, int B, long N, int C, float* out,
   if (N % rpc == 0) {  // chunks never straddle two images: one pass + a grouped finish
     const int cpg = (int)(N / rpc), cgn = C / 4, cgb = cgn < 256 ? cgn : 256;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((cgn + cgb - 1) / cgb, B * cpg), dim3(256), 0, st,
-                       const_cast<float*>(x), (const float*)nullptr, (long)B * N, C, 0, rpc, ws);
+                       const_cast<float*>(x), (const float*)nullptr, (long)B * N, C, 0, rpc, ws, (float*)nullptr, 1L);
     hipLaunchKernelGGL(colsum_finish8_kernel, dim3((C + 7) / 8, B), dim3(256), 0, st, ws, cpg, C, out);
     return hipGetLastError();
   }

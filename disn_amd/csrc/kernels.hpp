@@ -173,8 +173,10 @@ hipError_t pack_kn_T_launch(const float* w, int K, int N, float* packed, hipStre
 hipError_t pack_conv_bwd_launch(const float* w, int Cin, int Cout, float* packed, hipStream_t st);
 // dZ = dY * (Y > 0) in place (relu != 0) and column sums of dZ -> db[N] (+= when accumulate)
 size_t colsum_ws_bytes(long M, int N);
+// amax / rows_per_image / amax_done: see backward.hip (per-image maxima of the masked gradient in the same pass)
 hipError_t relu_bwd_colsum_launch(float* dy, const float* y, long M, int N, int relu, float* db,
-                                  float* ws, hipStream_t st);
+                                  float* ws, hipStream_t st, float* amax = nullptr, long rows_per_image = 0,
+                                  bool* amax_done = nullptr);
 // d(sdf_loss)/d(pred): -sign(10*gt - pred) * w * 1000/M, w = 4 if gt <= 0.01 else 1
 hipError_t loss_grad_launch(const float* pred, const float* gt, long M, float sdf_weight,
                             float mask_weight, float* dpred, hipStream_t st);

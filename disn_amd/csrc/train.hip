@@ -177,9 +177,11 @@ int dense_bwd(const float* a, int lda, int K, const float* w_kn, const float* dz
 int conv_bwd(const float* x, int B, int H, int W, int Cin, const float* w, const float* dz, int Cout,
              float wd, float* dx, float* dw, float* col, const BwdWs& s, hipStream_t st,
              const float* prepacked = nullptr, const void* h2img = nullptr, float* amax = nullptr,
-             const float* amax_x = nullptr) {
+             const float* amax_x = nullptr, bool amax_ready = false) {
   const long M = (long)B * H * W;
-  if (amax && Cin != 3) {  // maxima of dz per image: the data gradient's operand scales, the weight gradient's bound
+  // maxima of dz per image: the data gradient's operand scales, the weight gradient's bound (amax_ready: already
+  // written by the ReLU-mask / bias-gradient pass, relu_bwd_colsum_launch)
+  if (amax && Cin != 3 && !amax_ready) {
     DISN_TRY(hipMemsetAsync(amax, 0, (size_t)B * 64 * sizeof(float), st));
     DISN_TRY(amax64_accumulate_launch(dz, (size_t)H * W * Cout, amax, st, B, 64));
   }
@@ -236,7 +238,7 @@ struct TrainWs {
   float* conv_h2img[13];
   float* conv_h2bT[13];   // the same for the data gradients (mirrored taps, transposed channels)
   float* amax;
-  float* amax_bwd;        // [B][64]: maxima of the layer gradient being propagated
+  float* amax_bwd;        // [13][B][64]: per-image maxima of every layer gradient (written by the ReLU-mask pass)
   float* wmax;            // [16]: max |w| of the 12 packed convolution tensors
   BwdWs bw;
   size_t total;
@@ -315,8 +317,8 @@ TrainWs train_layout(void* ws, int B, int N) {
   for (int i = 1; i < 13; ++i) t.conv_h2img[i] = b.take(conv_h2_image_bytes(kConv[i].cin, kConv[i].cout) / sizeof(float) + 1);
   t.conv_h2bT[0] = nullptr;
   for (int i = 1; i < 13; ++i) t.conv_h2bT[i] = b.take(conv_h2_image_bytes(kConv[i].cout, kConv[i].cin) / sizeof(float) + 1);
-  t.amax = b.take((size_t)14 * B * 64);
-  t.amax_bwd = b.take((size_t)B * 64);
+  t.amax = b.take((size_t)27 * B * 64);       // 14 slot sets of the forward chain + 13 of the layer gradients
+  t.amax_bwd = t.amax + (size_t)14 * B * 64;  // [13][B][64], zeroed with the others by the resize launch
   t.wmax = b.take(16);
   t.red_aux = b.take(colsum_ws_bytes(B, 4096) / sizeof(float) + 1);
   size_t red = colsum_ws_bytes(M, 512);
@@ -552,7 +554,7 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
     DISN_TRY(conv_h2_pack_multi_launch(cj, st));
   }
   DISN_TRY(resize_bilinear_launch(img, B, DISN_IMG_H, DISN_IMG_W, 3, t.resized, DISN_VGG_SIZE,
-                                  DISN_VGG_SIZE, 3, 0, st, 0, h2fwd ? t.amax : nullptr, h2fwd ? 14 * B * 64 : 0));
+                                  DISN_VGG_SIZE, 3, 0, st, 0, h2fwd ? t.amax : nullptr, h2fwd ? 27 * B * 64 : 0));
   const float* x = t.resized;
   for (int i = 0; i < 13; ++i) {
     const ConvL& c = kConv[i];
@@ -698,7 +700,10 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
       dy = const_cast<float*>(dcur);
     }
     const long rows = (long)B * c.hw * c.hw;
-    DISN_TRY(relu_bwd_colsum_launch(dy, t.act[i], rows, c.cout, 1, G(2 * i + 1), s.red_ws, st));
+    float* amax_i = h2fwd && i > 0 ? t.amax_bwd + (size_t)i * B * 64 : nullptr;
+    bool amax_ready = false;
+    DISN_TRY(relu_bwd_colsum_launch(dy, t.act[i], rows, c.cout, 1, G(2 * i + 1), s.red_ws, st, amax_i,
+                                    (long)c.hw * c.hw, &amax_ready));
     const float* xin = i == 0 ? t.resized : (kConv[i - 1].pool ? t.pooled[i - 1] : t.act[i - 1]);
     float* dx = nullptr;
     if (i > 0) {
@@ -706,8 +711,8 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
       if (dx == dy) dx = bufs[which ^ 1];
     }
     DISN_RC(conv_bwd(xin, B, c.hw, c.hw, c.cin, P(2 * i), dy, c.cout, wd, dx, G(2 * i), t.col, s, st,
-                     t.conv_bT[i], h2fwd && i > 0 ? t.conv_h2bT[i] : nullptr, h2fwd && i > 0 ? t.amax_bwd : nullptr,
-                     h2fwd && i > 0 ? t.amax + (size_t)B * 64 * i : nullptr));
+                     t.conv_bT[i], h2fwd && i > 0 ? t.conv_h2bT[i] : nullptr, amax_i,
+                     h2fwd && i > 0 ? t.amax + (size_t)B * 64 * i : nullptr, amax_ready));
     if (dx) {
       which = (dx == bufs[0]) ? 1 : 0;
       dcur = dx;
