@@ -177,6 +177,57 @@ def resize_bilinear_legacy_mt(img: np.ndarray, out_h: int, out_w: int) -> np.nda
     return (top + (bot - top) * yl).numpy()
 
 
+def resize_bilinear_legacy_blocks(img: np.ndarray, out_h: int, out_w: int, workers: int = 1) -> np.ndarray:
+    """resize_bilinear_legacy in two passes over row blocks on a thread pool (numpy releases the GIL inside its
+    loops).  Pass 1 forms the x-interpolated SOURCE rows T[h] = row[xlo] + (row[xhi] - row[xlo]) * xl once per source
+    row; an output row's `top` / `bot` of the one-pass form are exactly T[ylo] / T[yhi] (the same float32 expression
+    on the same operands), so pass 2's T[ylo] + (T[yhi] - T[ylo]) * yl reproduces the one-pass result bit for bit
+    (tests/test_oracle.py) -- TF's CPU kernel caches the x weights per row the same way.  bench.py's cpu_baseline
+    leg uses it for the five 137x137 tap up-samples (110 MB of output: memory bound, scales with the threads)."""
+    from concurrent.futures import ThreadPoolExecutor
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    B, H, W, C = img.shape
+    ylo, yhi, yl = resize_index_table(H, out_h)
+    xlo, xhi, xl = resize_index_table(W, out_w)
+    xl4 = xl[None, None, :, None]
+    T = np.empty((B, H, out_w, C), np.float32)
+    out = np.empty((B, out_h, out_w, C), np.float32)
+    workers = max(1, int(workers))
+
+    def blocks(n):
+        nb = max(1, min(n, 4 * workers))
+        edges = np.linspace(0, n, nb + 1).astype(int)
+        return [(int(a), int(b)) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+
+    def pass1(rng):
+        a, b = rng
+        rows = img[:, a:b]
+        tl = rows[:, :, xlo]
+        d = rows[:, :, xhi]
+        np.subtract(d, tl, out=d)
+        np.multiply(d, xl4, out=d)
+        np.add(tl, d, out=T[:, a:b])
+
+    def pass2(rng):
+        a, b = rng
+        top = T[:, ylo[a:b]]
+        d = T[:, yhi[a:b]]
+        np.subtract(d, top, out=d)
+        np.multiply(d, yl[None, a:b, None, None], out=d)
+        np.add(top, d, out=out[:, a:b])
+
+    if workers == 1:
+        for r in blocks(H):
+            pass1(r)
+        for r in blocks(out_h):
+            pass2(r)
+    else:
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(pass1, blocks(H)))
+            list(ex.map(pass2, blocks(out_h)))
+    return out
+
+
 def resampler_mt(data: np.ndarray, warp: np.ndarray) -> np.ndarray:
     """resampler with torch-CPU ops (multi-threaded), same expressions / order as the numpy form: bit-identical"""
     import torch

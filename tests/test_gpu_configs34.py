@@ -1,0 +1,145 @@
+"""BASELINE configs 3 and 4 against the FULL float64 oracle (VERDICT r3 #2a, #2b): the goldens of
+tests/golden/make_golden_cfg34.py were computed from the oracle's own features and embedding -- nothing in the
+reference values comes from the GPU.
+
+  config 3  test/create_sdf.py:241-285 at --sdf_res 256, one image: every 64th point of the 257^3 grid + the pad point
+            (a) through the device-side dense-grid driver (`create_sdf`: folded feature map + fused point MLP),
+            (b) through the reference's own 80-split `sess.run` loop with its 47 zero pad points;
+  config 4  the same at batch_size 8, sharded: eight DISTINCT images, cameras and boxes through `sharded_create_sdf`
+            (c) in a one-rank RCCL group (the 8-rank job's call sequence), both exchanges,
+            (d) as two ranks sharing this GPU (gloo: RCCL refuses two ranks on one device), all_to_all.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from oracle import disn_oracle as O
+
+pytestmark = pytest.mark.gpu
+PRED_ATOL = 1e-5          # north_star's bar on pred_sdf, absolute, against the float64 oracle
+
+sys.path.insert(0, GOLDEN)
+import make_golden_cfg34 as G   # noqa: E402   (inputs are regenerated from the committed generator, goldens loaded)
+
+
+def _store():
+    from disn_amd.weights import WeightStore
+    return WeightStore.random_init(G.WEIGHT_SEED, mode="he")
+
+
+def test_cfg3_strided_device_driver():
+    """(a) create_sdf -> [1, 257^3] of pred / 10; every 64th point against the float64 oracle"""
+    from disn_amd import create_sdf as cs
+    from disn_amd.engine import SdfEngine
+    gold = np.load(os.path.join(GOLDEN, "cfg3_strided.npz"))["pred64"]
+    c3 = G.cfg3_inputs()
+    eng = SdfEngine(_store())
+    res = cs.create_sdf(eng, c3["img"], c3["trans_mat"], np.asarray(c3["sdf_params"], np.float64)[None], G.RES)
+    assert res.shape == (1, G.TOTAL)
+    got = res[0][torch.from_numpy(c3["idx"]).cuda()].cpu().numpy().astype(np.float64) * 10.0
+    err = float(np.abs(got - gold[:-1]).max())
+    print("\n[parity cfg3 device driver] max |10 gpu - f64| %.3g over %d strided points of 257^3 (|pred| max %.3g)" % (
+        err, got.size, float(np.abs(gold).max())))
+    assert err <= PRED_ATOL
+
+
+def test_cfg3_reference_split_loop_with_pad_points():
+    """(b) the loop of test/create_sdf.py:241-285 verbatim in shape: SPLIT_SIZE = 80 feeds of NUM_SAMPLE_POINTS =
+    212 183 points (the last one ends in 47 zero pad points), `sess.run([pred_sdf, ref_img, sample_img_points])`,
+    un-pad, / SDF_WEIGHT; every 64th point + the pad points against the float64 oracle"""
+    from disn_amd import create_sdf as cs
+    import disn_amd.model_normalization as model
+    from disn_amd.graph import Session
+    gold = np.load(os.path.join(GOLDEN, "cfg3_strided.npz"))["pred64"]
+    c3 = G.cfg3_inputs()
+    total, split, nsp, pad = cs.split_plan(G.RES)
+    assert (total, split, nsp, pad) == (G.TOTAL, 80, 212183, 47)
+    sess = Session(_store())
+    pls = model.placeholder_inputs(1, 1, (137, 137), num_sample_pc=nsp)
+    ep = model.get_model(pls, 1, None, bn=False)
+    extra = np.zeros((pad, 3), np.float32)
+    pts = np.concatenate([cs.grid_points_host(c3["sdf_params"], G.RES), extra], 0).reshape(split, 1, nsp, 3)
+    acc = np.zeros((split, 1, nsp, 1), np.float32)
+    for sp in range(split):
+        feed = {pls["sample_pc"]: pts[sp], pls["sample_pc_rot"]: pts[sp], pls["imgs"]: c3["img"],
+                pls["trans_mat"]: c3["trans_mat"]}
+        pred, ref_img, xy = sess.run([ep["pred_sdf"], ep["ref_img"], ep["sample_img_points"]], feed_dict=feed)
+        acc[sp] = pred
+    flat = np.swapaxes(acc, 0, 1).reshape(1, -1, 1)
+    result = flat[:, :total, :] / np.float32(10.0)
+    got = result[0, c3["idx"], 0].astype(np.float64) * 10.0
+    err = float(np.abs(got - gold[:-1]).max())
+    err_pad = float(np.abs(flat[0, total:, 0].astype(np.float64) - gold[-1]).max())
+    print("\n[parity cfg3 session loop, 80 splits] max |gpu - f64| %.3g strided, %.3g on the %d pad points" % (
+        err, err_pad, pad))
+    assert err <= PRED_ATOL and err_pad <= PRED_ATOL
+
+
+_RANK_SCRIPT = '''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(golden)r)
+import make_golden_cfg34 as G
+torch.cuda.set_device(0)
+backend = %(backend)r
+if backend == "nccl":
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+from disn_amd import parallel as par
+from disn_amd.engine import SdfEngine
+from disn_amd.weights import WeightStore
+gold = np.load(os.path.join(%(golden)r, "cfg4_sampled.npz"))["pred64"]
+c4 = G.cfg4_inputs()
+eng = SdfEngine(WeightStore.random_init(G.WEIGHT_SEED, mode="he"))
+worst = 0.0
+for exchange in %(exchanges)r:
+    res = par.sharded_create_sdf(eng, c4["imgs"], c4["trans_mat"], c4["sdf_params"], G.RES, exchange=exchange)
+    full, own = (res, list(range(8))) if exchange == "all_gather" else res
+    assert full.shape == (len(own), G.TOTAL)
+    assert exchange == "all_gather" or own == par.owned_images(8, world, rank)
+    for i, b in enumerate(own):
+        idx = torch.from_numpy(c4["idx"][b][:gold.shape[1]]).to(full.device)
+        got = full[i][idx].cpu().numpy().astype(np.float64) * 10.0
+        err = float(np.abs(got - gold[b]).max())
+        worst = max(worst, err)
+        assert err <= 1e-5, (exchange, b, err)
+    del res, full
+print("CFG4_OK rank %%d of %%d worst %%.3g" %% (rank, world, worst), flush=True)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _run_ranks(tmp_path, world, backend, exchanges, port):
+    script = tmp_path / ("cfg4_%s_%d.py" % (backend, world))
+    script.write_text(_RANK_SCRIPT % {"root": ROOT, "golden": GOLDEN, "backend": backend, "exchanges": exchanges})
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=env))
+    outs = [p.communicate(timeout=1200) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "CFG4_OK" in so, (so[-1500:], se[-3000:])
+    return [so for so, _ in outs]
+
+
+def test_cfg4_eight_distinct_images_one_rank_rccl(tmp_path):
+    """(c) eight distinct images / cameras / boxes, 257^3 each, through sharded_create_sdf in a one-rank RCCL group
+    (all_to_all_single and all_gather_into_tensor: the 8-rank job's collectives), sampled points vs the float64 oracle"""
+    outs = _run_ranks(tmp_path, 1, "nccl", ["all_to_all", "all_gather"], 29541)
+    print("\n[parity cfg4 one-rank RCCL]", outs[0].strip().splitlines()[-1])
+
+
+def test_cfg4_two_ranks_share_the_gpu(tmp_path):
+    """(d) two ranks on this one GPU (gloo), flat index range cut in two, all_to_all: each rank ends with the full
+    grids of its four images and checks them against the float64 oracle"""
+    outs = _run_ranks(tmp_path, 2, "gloo", ["all_to_all"], 29542)
+    for so in outs:
+        print("\n[parity cfg4 two ranks]", so.strip().splitlines()[-1])

@@ -191,6 +191,8 @@ def test_multithreaded_resize_and_resampler_are_bit_identical():
     for h, c, o in ((224, 8, 137), (14, 16, 137), (137, 3, 224), (56, 4, 137)):
         x = rng.standard_normal((2, h, h, c)).astype(np.float32)
         assert np.array_equal(O.resize_bilinear_legacy(x, o, o), O.resize_bilinear_legacy_mt(x, o, o))
+        for workers in (1, 3):     # the two-pass row-block form the cpu_baseline leg threads over
+            assert np.array_equal(O.resize_bilinear_legacy(x, o, o), O.resize_bilinear_legacy_blocks(x, o, o, workers))
     m = rng.standard_normal((2, 137, 137, 24)).astype(np.float32)
     w = (rng.random((2, 500, 2)) * 141 - 2).astype(np.float32)
     w[0, :4] = [[0, 0], [136, 136], [136, 0], [np.nan, 1]]
@@ -242,3 +244,32 @@ def test_grid_float32_params_caveat():
     bound = R * np.spacing(step.astype(np.float32)).astype(np.float64) / 2 + np.spacing(np.float32(1.0))
     print("non-dyadic float32 box, R = 100: max |difference| per axis %s (bound %s)" % (d, bound))
     assert (d <= bound).all() and d.max() > 0 and d.max() < 2e-7 * 2.0
+
+
+def test_cfg3_cfg4_goldens_reproduce_from_the_oracle():
+    """tests/golden/cfg3_strided.npz / cfg4_sampled.npz (make_golden_cfg34.py) are what the float64 oracle gives:
+    a subset is recomputed here (one float64 encode: cfg4's image 1 is cfg3's demo image) and must match exactly"""
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden_cfg34 as G
+    g3 = np.load(os.path.join(GOLDEN, "cfg3_strided.npz"))
+    g4 = np.load(os.path.join(GOLDEN, "cfg4_sampled.npz"))
+    assert g3["pred64"].shape == (len(range(0, G.TOTAL, G.CFG3_STRIDE)) + 1,) and g4["pred64"].shape == (8, 8288)
+    assert int(g3["stride"]) == G.CFG3_STRIDE and int(g4["stride"]) == G.CFG4_STRIDE and int(g3["weight_seed"]) == G.WEIGHT_SEED
+    W = O.init_weights(G.WEIGHT_SEED, "he")
+    c3, c4 = G.cfg3_inputs(), G.cfg4_inputs()
+    assert np.array_equal(c4["imgs"][1], c3["img"][0]) and len({im.tobytes() for im in c4["imgs"]}) == 8
+    _, emb, maps, _ = O.encode(c3["img"], W, np.float64)
+    sel = np.arange(0, c3["idx"].size, 4099)
+    pts = np.concatenate([G.grid_points_at(c3["sdf_params"], G.RES, c3["idx"][sel]), np.zeros((1, 3), np.float32)])
+    got = G.oracle_pred64(W, emb, maps, c3["trans_mat"], pts)
+    assert np.allclose(got[:-1], g3["pred64"][sel], rtol=0, atol=1e-12) and abs(got[-1] - g3["pred64"][-1]) <= 1e-12
+    sel4 = np.arange(0, 8288, 257)
+    pts4 = G.grid_points_at(c4["sdf_params"][1], G.RES, c4["idx"][1][sel4])
+    got4 = G.oracle_pred64(W, emb, maps, c4["trans_mat"][1:2], pts4)
+    assert np.allclose(got4, g4["pred64"][1][sel4], rtol=0, atol=1e-12)
+    # the sampled grid points are the reference grid's points (test/create_sdf.py:246-256), bit for bit
+    small = O.grid_points(c4["sdf_params"][3], 16)
+    assert np.array_equal(G.grid_points_at(c4["sdf_params"][3], 16, np.arange(17 ** 3)), small)
