@@ -14,7 +14,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # DISN_AMD_LIB: tools/ only -- points the binding at a tuning build (csrc/build.py --tuning), never set by the product
 LIB_PATH = os.environ.get("DISN_AMD_LIB") or os.path.join(HERE, "csrc", "libdisn_amd.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 

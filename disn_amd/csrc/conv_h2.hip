@@ -47,24 +47,63 @@ namespace disn {
 
 // ---------------------------------------------------------------------------------------------------
 // weight image: for n-block nb (32 output channels), k16 block kb (input channels 16 kb .. 16 kb + 15), tap t:
-//   two 1-KiB planes (h, l), lane (j, g) holds W[t][16 kb + 8 g + e][32 nb + j] * s_w, e = 0..7
+//   two 1-KiB planes (h, l), lane (j, g) holds W[t][16 kb + 8 g + e][32 nb + j] * s_w[32 nb + j], e = 0..7
 // at byte ((((nb * (Cin / 16) + kb) * 9 + t) * 2 + plane) * 64 + lane) * 16: the nine taps of one k16 block are one
-// contiguous 18 KiB -- what one k-wave reads per chunk, whatever the number of k-waves.  Behind the image:
-// {s_w, 1 / s_w}.
+// contiguous 18 KiB -- what one k-wave reads per chunk, whatever the number of k-waves.
+// Scales are PER OUTPUT CHANNEL (round 4): s_w[c] = the power of two that puts max |W[:, :, c]| into [2^13, 2^14).  A
+// per-tensor scale leaves an entry 2^-19 below the tensor's maximum with five significant bits (f16's subnormal floor
+// is 2^-24 absolute), which is where trained weights with outlier output channels put the columns of the ordinary
+// channels (tools/split_model.py: 2e-3 on pred against 2e-6).  Behind the image (the tail): inv_sw[Cout] = 1 / s_w[c]
+// -- what a lane multiplies its column's accumulators with, next to the bias -- and Cout floats of scratch for the
+// column-maximum pass.
 // ---------------------------------------------------------------------------------------------------
 // flip_t: w is the FORWARD tensor [taps][Cout][Cin] of the layer whose data gradient this image serves -- the image is
 // the one of w'[t][ci][co] = w[taps - 1 - t][co][ci] (taps mirrored, channels transposed: dx = conv(dz, w'))
+
+// column maxima of one tensor, viewed as [outer][mid][inner] floats (TF HWIO: taps, Cin_fwd, Cout_fwd): max |w| per INNER
+// index -> cmax_inner (the columns of the forward image) and per MID index -> cmax_mid (the columns of the flipped
+// image); either may be null.  A workgroup reduces 4096 consecutive floats in LDS tables, then one global atomic per
+// touched column (non-negative floats: integer maximum of the bit patterns; the tables must be zeroed first).
+__device__ __forceinline__ void h2_colmax_chunk(const float* __restrict__ p, long base, int mid, int inner,
+                                                float* __restrict__ cmax_inner, float* __restrict__ cmax_mid,
+                                                unsigned* tab_i, unsigned* tab_m) {
+  for (int i = threadIdx.x; i < 1024; i += 256) { tab_i[i] = 0u; tab_m[i] = 0u; }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long e = base + (long)(k * 256 + threadIdx.x) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(p + e);
+    const float a[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+    if (cmax_inner) {
+      const int c0 = (int)(e % inner);  // inner % 4 == 0: the four elements are four consecutive columns
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomicMax(&tab_i[c0 + q], __float_as_uint(a[q]));
+    }
+    if (cmax_mid) atomicMax(&tab_m[(int)((e / inner) % mid)], __float_as_uint(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]))));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    if (cmax_inner && i < inner && tab_i[i]) atomicMax(reinterpret_cast<unsigned*>(cmax_inner) + i, tab_i[i]);
+    if (cmax_mid && i < mid && tab_m[i]) atomicMax(reinterpret_cast<unsigned*>(cmax_mid) + i, tab_m[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void h2_colmax_kernel(const float* __restrict__ w, int mid, int inner,
+                                                        float* __restrict__ cmax_inner, float* __restrict__ cmax_mid) {
+  __shared__ unsigned tab_i[1024], tab_m[1024];
+  h2_colmax_chunk(w, (long)blockIdx.x * 4096, mid, inner, cmax_inner, cmax_mid, tab_i, tab_m);
+}
+
+__device__ __forceinline__ float* h2_tail(unsigned char* image, int Cin, int Cout, int taps) {
+  return reinterpret_cast<float*>(image + (size_t)Cin * taps * Cout * 4);  // inv_sw[Cout], then cmax[Cout]
+}
+
 __global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int taps,
-                                                           const float* __restrict__ amax,
                                                            unsigned char* __restrict__ image, int flip_t) {
   const int KB = Cin >> 4;
   const size_t frags = (size_t)(Cout >> 5) * KB * taps;
-  const float s = ch2::pow2_scale(amax[0], 13);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float* meta = reinterpret_cast<float*>(image + (size_t)Cin * taps * Cout * 4);
-    meta[0] = s;
-    meta[1] = 1.0f / s;
-  }
+  float* tail = h2_tail(image, Cin, Cout, taps);
+  const float* cmax = tail + Cout;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < frags * 64; idx += (size_t)gridDim.x * 256) {
     const int lane = (int)(idx & 63);
     size_t f = idx >> 6;
@@ -78,6 +117,8 @@ __global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restri
       f = ((size_t)nb * KB + kb) * taps + t;
     }
     const int j = lane & 31, g = lane >> 5;
+    const float s = ch2::pow2_scale(cmax[32 * nb + j], 13);
+    if (kb == 0 && t == 0 && g == 0) tail[32 * nb + j] = 1.0f / s;
     ch_h8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -94,28 +135,25 @@ __global__ __launch_bounds__(256) void conv_h2_pack_kernel(const float* __restri
   }
 }
 
-size_t conv_h2_image_bytes(int Cin, int Cout) { return (size_t)Cin * 9 * Cout * 4 + 256; }
+size_t h2_image_bytes(int K, int N, int taps) { return (size_t)K * taps * N * 4 + (size_t)N * 8 + 256; }
+size_t conv_h2_image_bytes(int Cin, int Cout) { return h2_image_bytes(Cin, Cout, 9); }
 
-// ---- the same for a list of 3x3 tensors: one maximum pass, one pack pass (train.hip) ----------------------------
-__global__ __launch_bounds__(256) void conv_h2_wmax_multi_kernel(const ConvH2PackJobs jobs) {
-  // a workgroup reduces 4096 consecutive floats of ONE tensor (tensor sizes are multiples of 36864 = 9 * 4096)
-  __shared__ float red[4];
+// ---- the same for a list of 3x3 tensors: one clearing pass, one maximum pass, one pack pass (train.hip) -----------
+__global__ __launch_bounds__(256) void conv_h2_tail_clear_multi_kernel(const ConvH2PackJobs jobs) {
+  const ConvH2PackJob& J = jobs.j[blockIdx.x];
+  float* cmax = h2_tail(J.image, J.Cin, J.Cout, 9) + J.Cout;
+  for (int i = threadIdx.x; i < J.Cout; i += 256) cmax[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void conv_h2_colmax_multi_kernel(const ConvH2PackJobs jobs) {
+  // a workgroup reduces 4096 consecutive floats of ONE tensor (tensor sizes are multiples of 36864 = 9 * 4096) for the
+  // forward image (columns = inner index) and the flipped image (columns = mid index) of its slot
+  __shared__ unsigned tab_i[1024], tab_m[1024];
   const long base = (long)blockIdx.x * 4096;
   int s = 0;
   while (s + 1 < jobs.nslots && jobs.seg_begin[s + 1] <= base) ++s;
-  const float* p = jobs.seg[s] + (base - jobs.seg_begin[s]);
-  float m = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)(k * 256 + threadIdx.x) * 4);
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    atomicMax(reinterpret_cast<unsigned*>(jobs.wmax) + s, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+  h2_colmax_chunk(jobs.seg[s], base - jobs.seg_begin[s], jobs.seg_mid[s], jobs.seg_inner[s], jobs.cmax_fwd[s],
+                  jobs.cmax_flip[s], tab_i, tab_m);
 }
 
 __global__ __launch_bounds__(256) void conv_h2_pack_multi_kernel(const ConvH2PackJobs jobs) {
@@ -132,13 +170,9 @@ __global__ __launch_bounds__(256) void conv_h2_pack_multi_kernel(const ConvH2Pac
   }
   const ConvH2PackJob& J = jobs.j[ji];
   const int Cin = J.Cin, Cout = J.Cout, KB = Cin >> 4, taps = 9;
-  const float s = ch2::pow2_scale(jobs.wmax[J.slot], 13);
+  float* tail = h2_tail(J.image, Cin, Cout, taps);
+  const float* cmax = tail + Cout;
   size_t f = (size_t)(f0 - J.frag_begin) + (threadIdx.x >> 6);
-  if (f == 0 && threadIdx.x == 0) {
-    float* meta = reinterpret_cast<float*>(J.image + (size_t)Cin * taps * Cout * 4);
-    meta[0] = s;
-    meta[1] = 1.0f / s;
-  }
   const int lane = threadIdx.x & 63;
   int t = (int)(f % taps);
   int kb = (int)((f / taps) % KB);
@@ -149,6 +183,8 @@ __global__ __launch_bounds__(256) void conv_h2_pack_multi_kernel(const ConvH2Pac
     f = ((size_t)nb * KB + kb) * taps + t;
   }
   const int j = lane & 31, g = lane >> 5;
+  const float s = ch2::pow2_scale(cmax[32 * nb + j], 13);
+  if (kb == 0 && t == 0 && g == 0) tail[32 * nb + j] = 1.0f / s;
   ch_h8 hi, lo;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -174,30 +210,49 @@ void conv_h2_pack_job_add(ConvH2PackJobs& jobs, const float* w_fwd, int Cin_fwd,
   jobs.total_frags += (long)(J.Cout >> 5) * (J.Cin >> 4) * 9;
   if (slot >= jobs.nslots) {   // slots are added in order (0, 1, ...), one tensor each; seg_begin[0] == 0
     jobs.seg[slot] = w_fwd;
+    jobs.seg_mid[slot] = Cin_fwd;
+    jobs.seg_inner[slot] = Cout_fwd;
+    jobs.cmax_fwd[slot] = nullptr;
+    jobs.cmax_flip[slot] = nullptr;
     jobs.seg_begin[slot + 1] = jobs.seg_begin[slot] + (long)9 * Cin_fwd * Cout_fwd;
     jobs.nslots = slot + 1;
   }
+  // the scratch half of the image's tail collects its column maxima (one image per slot and direction)
+  float* cmax = reinterpret_cast<float*>(J.image + (size_t)J.Cin * 9 * J.Cout * 4) + J.Cout;
+  if (flip_t) jobs.cmax_flip[slot] = cmax; else jobs.cmax_fwd[slot] = cmax;
 }
 
 #ifndef CH2_UBENCH
-// jobs.wmax: nslots device floats
 hipError_t conv_h2_pack_multi_launch(const ConvH2PackJobs& jobs, hipStream_t st) {
   if (jobs.n == 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(jobs.wmax, 0, (size_t)jobs.nslots * sizeof(float), st);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(conv_h2_wmax_multi_kernel, dim3((unsigned)(jobs.seg_begin[jobs.nslots] / 4096)), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL(conv_h2_tail_clear_multi_kernel, dim3((unsigned)jobs.n), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL(conv_h2_colmax_multi_kernel, dim3((unsigned)(jobs.seg_begin[jobs.nslots] / 4096)), dim3(256), 0, st, jobs);
   hipLaunchKernelGGL(conv_h2_pack_multi_kernel, dim3((unsigned)(jobs.total_frags / 4)), dim3(256), 0, st, jobs);
   return hipGetLastError();
 }
 #endif
 
 #ifndef CH2_UBENCH
-// w: TF HWIO [3][3][Cin][Cout]; scratch: one float (max |w|)
+// w: TF HWIO [taps][Cin][Cout] (flip_t: the forward tensor [taps][Cout][Cin] of the image's layer); the column maxima
+// are collected in the image's own tail (`scratch` is no longer used)
 hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, float* scratch, hipStream_t st,
                                int taps, int flip_t) {
-  hipError_t e = amax_launch(w, (size_t)taps * Cin * Cout, scratch, st);
+  (void)scratch;
+  if (Cin > 1024 * 4 || Cout > 1024 || ((size_t)taps * Cin * Cout) % 4096) return hipErrorInvalidValue;
+  unsigned char* img = static_cast<unsigned char*>(image);
+  float* cmax = reinterpret_cast<float*>(img + (size_t)Cin * taps * Cout * 4) + Cout;
+  hipError_t e = hipMemsetAsync(cmax, 0, (size_t)Cout * sizeof(float), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(conv_h2_pack_kernel, dim3(1024), dim3(256), 0, st, w, Cin, Cout, taps, scratch,
+  // forward: columns = the inner index of [taps][Cin][Cout]; flipped: the tensor is [taps][Cout_img][Cin_img] and the
+  // image's columns are its MID index
+  const unsigned grid = (unsigned)(((size_t)taps * Cin * Cout) / 4096);
+  if (flip_t) {
+    if (Cout > 1024 || Cin % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(h2_colmax_kernel, dim3(grid), dim3(256), 0, st, w, Cout, Cin, (float*)nullptr, cmax);
+  } else {
+    hipLaunchKernelGGL(h2_colmax_kernel, dim3(grid), dim3(256), 0, st, w, Cin, Cout, cmax, (float*)nullptr);
+  }
+  hipLaunchKernelGGL(conv_h2_pack_kernel, dim3(1024), dim3(256), 0, st, w, Cin, Cout, taps,
                      static_cast<unsigned char*>(image), flip_t);
   return hipGetLastError();
 }
@@ -320,7 +375,7 @@ __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) voi
   // after the weight queue below is in flight (loads return in order: waiting for these must not wait for those) ----
   const float* meta = reinterpret_cast<const float*>(P.wimg + (size_t)Cin * 9 * Cout * 4);
   float amax_lane = P.in_amax[(size_t)b * P.amax_stride + lane];
-  const float inv_sw = meta[1];
+  const float inv_sw = meta[n0 + (lane & 31)];  // per output channel (column): the pack scales every column to [2^13, 2^14)
 
   // ---- A rows of this lane: logical row sigma(i) of block mb -> centre pixel in the halo -----------------------
   int arow[MB];
@@ -717,9 +772,7 @@ size_t disn_pack_conv_h2_bytes(int Cin, int Cout) {
 int disn_pack_conv_h2(const float* w_hwio, int Cin, int Cout, void* image, void* stream) {
   if (!w_hwio || !image || Cin <= 0 || Cout <= 0) return DISN_E_ARG;
   if (Cin % 64 || Cout % 64) return DISN_E_SHAPE;
-  // the float behind {s_w, 1/s_w} in the image's tail is the scratch of the max |w| pass
-  float* scratch = reinterpret_cast<float*>(static_cast<char*>(image) + (size_t)Cin * 9 * Cout * 4) + 2;
-  const hipError_t e = disn::conv_h2_pack_launch(w_hwio, Cin, Cout, image, scratch, (hipStream_t)stream);
+  const hipError_t e = disn::conv_h2_pack_launch(w_hwio, Cin, Cout, image, nullptr, (hipStream_t)stream);
   return e == hipSuccess ? 0 : (int)e;
 }
 

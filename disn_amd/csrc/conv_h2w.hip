@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
 
   const float* meta = reinterpret_cast<const float*>(P.wimg + (size_t)Cin * 9 * Cout * 4);
   float amax_lane = P.in_amax[(size_t)b * P.amax_stride + lane];
-  const float inv_sw = meta[1];
+  const float inv_sw = meta[n0 + (lane & 31)];  // per output channel (column): the pack scales every column to [2^13, 2^14)
 
   // ---- A rows of this lane: hardware row i of block bg is logical row sigma(i) -> tile row 32 bg + sigma(i) ->
   // window (row-major over the patch) and position in it -> top-left tap of that pixel in the halo -----------------

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256 * NW, 1) void dense_h2_kernel(const DenseH2Dev 
     if (P.amax_rows > 0 && P.in_bias_rows > 0) { ib += (size_t)(m0 / P.in_bias_rows) * K; nb = K; }
     for (int i = lane; i < nb; i += 64) bmax_lane = fmaxf(bmax_lane, fabsf(ib[i]));
   }
-  const float inv_sw = meta[1];
+  const float inv_sw = meta[n0 + (lane & 31)];  // per output channel (column): the pack scales every column to [2^13, 2^14)
 
   int arow[MB];
   {
@@ -305,14 +305,13 @@ extern "C" {
 
 size_t disn_pack_dense_h2_bytes(int K, int N) {
   if (K <= 0 || N <= 0 || K % 64 || N % 64) return 0;
-  return (size_t)K * N * 4 + 256;
+  return disn::h2_image_bytes(K, N, 1);
 }
 
 int disn_pack_dense_h2(const float* w_kn, int K, int N, void* image, void* stream) {
   if (!w_kn || !image || K <= 0 || N <= 0) return DISN_E_ARG;
   if (K % 64 || N % 64) return DISN_E_SHAPE;
-  float* scratch = reinterpret_cast<float*>(static_cast<char*>(image) + (size_t)K * N * 4) + 2;
-  const hipError_t e = disn::conv_h2_pack_launch(w_kn, K, N, image, scratch, (hipStream_t)stream, 1);
+  const hipError_t e = disn::conv_h2_pack_launch(w_kn, K, N, image, nullptr, (hipStream_t)stream, 1);
   return e == hipSuccess ? 0 : (int)e;
 }
 

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void dense_h2w_kernel(const Dens
     if (P.amax_rows > 0 && P.in_bias_rows > 0) { ib += (size_t)(m0 / P.in_bias_rows) * K; nb = K; }
     for (int i = lane; i < nb; i += 64) bmax_lane = fmaxf(bmax_lane, fabsf(ib[i]));
   }
-  const float inv_sw = meta[1];
+  const float inv_sw = meta[n0 + (lane & 31)];  // per output channel (column): the pack scales every column to [2^13, 2^14)
 
   int arow[MB];
   {

@@ -265,6 +265,7 @@ hipError_t mlp_fused_launch(bool local, const void* image, const float* w1, cons
 
 // ---- conv_h2.hip: the single-image 3x3 convolution (two-term f16 split, halo in LDS, K parallel inside the workgroup) ----
 size_t conv_h2_image_bytes(int Cin, int Cout);
+size_t h2_image_bytes(int K, int N, int taps);   // payload + inv_sw[N] + column-maximum scratch[N] + pad
 // w: TF HWIO [3][3][Cin][Cout] (taps = 9) or a [K = Cin][N = Cout] matrix (taps = 1, dense_h2.hip); scratch: one
 // device float; the image holds taps * Cin * Cout * 4 + 256 bytes.  flip_t: w is the forward tensor [taps][Cout][Cin]
 // of a layer and the image the one of its data gradient, w'[t][ci][co] = w[taps - 1 - t][co][ci] (train.hip)
@@ -283,8 +284,10 @@ struct ConvH2PackJob {
 struct ConvH2PackJobs {
   int n, nslots;
   long total_frags;
-  float* wmax;             // [nslots] device floats (scratch)
+  float* wmax;             // unused since round 4 (column maxima live in the images' tails)
   const float* seg[16];    // tensor of slot s
+  int seg_mid[16], seg_inner[16];          // its [9][mid][inner] shape (Cin_fwd, Cout_fwd)
+  float *cmax_fwd[16], *cmax_flip[16];     // column-maximum scratch in the tail of the slot's forward / flipped image
   long seg_begin[17];      // in floats, multiples of 4096
   ConvH2PackJob j[32];
 };

@@ -57,10 +57,15 @@ constexpr int kPairs = kPairsL2 + 16 * kPairsA + 16 * kPairsB;  // 1056 (tile, k
 constexpr int kSlotBytes = 16384;                             // 8 pairs
 constexpr int kSlots = kPairs / 8;                            // 132 per pass over the image
 constexpr size_t kImageBytes = (size_t)kPairs * 2048;         // 2 162 688
-// meta (16 floats behind the image): [0..3] s_w of conv2, conv3, fold2/conv1, fold2/conv2; [4..7] 1/s_w; [8] max_f ||W4[:,f]||_1; [9] max_f ||W3[:,f]||_1
+// meta (behind the image): floats [8] max_f ||W4[:,f]||_1; [9] max_f ||W3[:,f]||_1; from float 64 on the inverse
+// weight scales PER OUTPUT FEATURE (round 4; as conv_h2.hip's per-column scales): isw2[256], isw3[512], isw4[512],
+// isw5[256] -- layer l's feature f is packed as W[:, f] * s, s = the power of two that puts max |W[:, f]| into
+// [2^13, 2^14), and its accumulator is multiplied by 1 / s next to the bias
+constexpr int mS2 = 64, mS3 = mS2 + 256, mS4 = mS3 + 512, mS5 = mS4 + 512, kMetaFloats = mS5 + 256;
 // constants of one stream in LDS (floats)
 constexpr int cW1 = 0, cB1 = 192, cB2 = 256, cB3 = 512, cB4 = 1024, cB5 = 1536, cW6 = 1792, cB6 = 2048;
-constexpr int kConstFloats = 2052;
+constexpr int cS2 = 2052, cS3 = cS2 + 256, cS4 = cS3 + 512, cS5 = cS4 + 512;
+constexpr int kConstFloats = cS5 + 256;
 }  // namespace fm
 
 // ---------------------------------------------------------------------------------------------------
@@ -73,7 +78,8 @@ __device__ __forceinline__ float pow2_scale_for(float amax, int target_exp) {
   return __uint_as_float((unsigned)(127 + target_exp - e) << 23);
 }
 
-// one workgroup per layer: amax -> scale; conv3 and fold2/conv1 (point rows) also the largest column 1-norm
+// one workgroup per layer: per-feature (column) amax -> inverse scale; conv3 and fold2/conv1 (point rows) also the
+// largest column 1-norm
 __global__ __launch_bounds__(256) void fm_meta_kernel(const float* __restrict__ w2, const float* __restrict__ w3,
                                                       const float* __restrict__ w4, const float* __restrict__ w5,
                                                       float* __restrict__ meta) {
@@ -82,21 +88,15 @@ __global__ __launch_bounds__(256) void fm_meta_kernel(const float* __restrict__ 
   const float* w = layer == 0 ? w2 : (layer == 1 ? w3 : (layer == 2 ? w4 : w5));
   const int K = layer == 0 ? 64 : (layer == 1 ? 256 : 512);
   const int N = layer == 0 ? 256 : (layer == 3 ? 256 : 512);
-  float m = 0.f;
-  for (int i = threadIdx.x; i < K * N; i += 256) m = fmaxf(m, fabsf(w[i]));
-  red[threadIdx.x] = m;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const float s = pow2_scale_for(red[0], 13);
-    meta[layer] = s;
-    meta[4 + layer] = 1.0f / s;
+  {
+    float* isw = meta + (layer == 0 ? fm::mS2 : (layer == 1 ? fm::mS3 : (layer == 2 ? fm::mS4 : fm::mS5)));
+    for (int f = threadIdx.x; f < N; f += 256) {
+      float m = 0.f;
+      for (int k = 0; k < K; ++k) m = fmaxf(m, fabsf(w[(size_t)k * N + f]));
+      isw[f] = 1.0f / pow2_scale_for(m, 13);
+    }
   }
   if (layer == 1 || layer == 2) {
-    __syncthreads();
     float c = 0.f;
     for (int f = threadIdx.x; f < N; f += 256) {
       float a = 0.f;
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void fm_pack_kernel(const float* __restrict__ 
   fm_pair_coords(p, layer, nt, kb);
   const float* w = layer == 0 ? w2 : (layer == 1 ? w3 : (layer == 2 ? w4 : w5));
   const int N = layer == 0 ? 256 : (layer == 3 ? 256 : 512);
-  const float s = meta[layer];
   const int i = lane & 31, g = lane >> 5;
+  const float s = 1.0f / meta[(layer == 0 ? fm::mS2 : (layer == 1 ? fm::mS3 : (layer == 2 ? fm::mS4 : fm::mS5))) + 32 * nt + i];
   h8 hi, lo;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void fm_pack_kernel(const float* __restrict__ 
   out[((size_t)p * 2 + 1) * 64 + lane] = lo;
 }
 
-size_t mlp_fused_image_bytes() { return fm::kImageBytes + 256; }
+size_t mlp_fused_image_bytes() { return fm::kImageBytes + fm::kMetaFloats * sizeof(float) + 64; }
 
 hipError_t mlp_fused_pack_launch(const float* w2, const float* w3, const float* w4_point, const float* w5,
                                  void* image, hipStream_t st) {
@@ -353,13 +353,16 @@ __device__ __forceinline__ int fm_exp_of(float m) {
 // bias + ReLU + scale + two-term split of one output tile -> the two reduction blocks it becomes
 template <bool GATHER>
 __device__ __forceinline__ void fm_tile_to_frags(const f32x16& acc, const float* bias32 /* LDS, + 4g applied */,
+                                                 const float* isw32 /* LDS, + 4g applied: 1 / weight scale per feature */,
                                                  const unsigned char* grows /* LDS: 16 pieces, + 16 lane applied */,
                                                  const float (&wt)[4], float inv, float s, h8 (&fh)[2],
                                                  h8 (&fl)[2]) {
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
     const float4 bb = *reinterpret_cast<const float4*>(bias32 + 8 * rq);
+    const float4 ss = *reinterpret_cast<const float4*>(isw32 + 8 * rq);
     float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+    const float i4[4] = {ss.x * inv, ss.y * inv, ss.z * inv, ss.w * inv};   // exact: powers of two
     if (GATHER) {  // + the four resampled pmap rows (sample4's summation order: ff, cc, fc, cf)
       float gs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -376,7 +379,7 @@ __device__ __forceinline__ void fm_tile_to_frags(const f32x16& acc, const float*
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int r = 4 * rq + c;
-      const float v = fmaxf(fmaf(acc[r], inv, b4[c]), 0.f) * s;
+      const float v = fmaxf(fmaf(acc[r], i4[c], b4[c]), 0.f) * s;
       const _Float16 h = (_Float16)v;
       fh[r >> 3][r & 7] = h;
       fl[r >> 3][r & 7] = (_Float16)(v - (float)h);
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
   cst[fm::cB5 + tid] = P.b5[tid];
   cst[fm::cW6 + tid] = P.w6[tid];
   if (tid == 0) cst[fm::cB6] = P.b6[0];
-  const float inv_sw2 = meta[4], inv_sw3 = meta[5], inv_sw4 = meta[6], inv_sw5 = meta[7];
+  for (int i = tid; i < fm::kMetaFloats - fm::mS2; i += 256) cst[fm::cS2 + i] = meta[fm::mS2 + i];  // isw2 | isw3 | isw4 | isw5
   const float cw4 = meta[8], cw3 = meta[9];
   float addmax4 = LOCAL ? P.pmap_amax[0] : 0.f, addmax3 = 0.f;
   float T[12];
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
       m = fmaxf(m, __shfl_xor(m, 32));
       const int e = fm_exp_of(m);
       const float s = fm_exp2i(14 - e);
-      inv2 = fm_exp2i(e - 14) * inv_sw2;
+      inv2 = fm_exp2i(e - 14);
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -612,10 +615,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           const float4 bb = *reinterpret_cast<const float4*>(&cst[fm::cB2 + 32 * nt + 8 * rq + 4 * g]);
+          const float4 ss = *reinterpret_cast<const float4*>(&cst[fm::cS2 + 32 * nt + 8 * rq + 4 * g]);
           const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+          const float s4v[4] = {ss.x * inv2, ss.y * inv2, ss.z * inv2, ss.w * inv2};   // exact: powers of two
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float v = fmaxf(fmaf(z2[nt][4 * rq + c], inv2, b4[c]), 0.f);
+            const float v = fmaxf(fmaf(z2[nt][4 * rq + c], s4v[c], b4[c]), 0.f);
             z2[nt][4 * rq + c] = v;
             m = fmaxf(m, v);
           }
@@ -624,16 +629,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
       m = fmaxf(m, __shfl_xor(m, 32));
       const int e2 = fm_exp_of(m);
       const float s2 = fm_exp2i(14 - e2);
-      inv3 = fm_exp2i(e2 - 14) * inv_sw3;
+      inv3 = fm_exp2i(e2 - 14);
       // conv3's and fold2/conv1's outputs are consumed tile by tile: scales from the bounds
       //   |h3| <= max|h2| * max_f ||W3[:,f]||_1 + max|b3|,   |h4| <= that * max_f ||W4[:,f]||_1 + max|additive term|
       const float bound3 = fmaf(m, cw3, addmax3);
       const int e3 = fm_exp_of(bound3);
       s3 = fm_exp2i(14 - e3);
-      inv4 = fm_exp2i(e3 - 14) * inv_sw4;
+      inv4 = fm_exp2i(e3 - 14);
       const int e4 = fm_exp_of(fmaf(bound3, cw4, addmax4));
       s4 = fm_exp2i(14 - e4);
-      inv5 = fm_exp2i(e4 - 14) * inv_sw5;
+      inv5 = fm_exp2i(e4 - 14);
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
       for (int kb = 0; kb < 16; ++kb) FM_STEP0(32 + kb, "v", acc, x2h[kb], x2l[kb], kb == 0);
       h8 fh[2], fl[2];
       FM_SETTLE_ACC("v", acc);
-      fm_tile_to_frags<false>(acc, &cst[fm::cB3 + 32 * it + 4 * g], nullptr, wt, inv3, s3, fh, fl);
+      fm_tile_to_frags<false>(acc, &cst[fm::cB3 + 32 * it + 4 * g], &cst[fm::cS3 + 32 * it + 4 * g], nullptr, wt, inv3, s3, fh, fl);
       FM_SETTLE_IN4(fh[0], fl[0], fh[1], fl[1]);
 #pragma unroll
       for (int r = 0; r < 32; ++r)  // reduction block 2it (r < 16) / 2it+1 for output tile r & 15
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
       h8 fh[2], fl[2];
       FM_SETTLE_ACC("a", acc4[it]);
       if (LOCAL) gather_wait();
-      fm_tile_to_frags<LOCAL>(acc4[it], &cst[fm::cB4 + 32 * it + 4 * g], &lds[gbuf + lane * 16], wt, inv4, s4, fh, fl);
+      fm_tile_to_frags<LOCAL>(acc4[it], &cst[fm::cB4 + 32 * it + 4 * g], &cst[fm::cS4 + 32 * it + 4 * g], &lds[gbuf + lane * 16], wt, inv4, s4, fh, fl);
       if (LOCAL && it < 15) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the gather buffer are done
         gather_issue(std::integral_constant<int, (it < 15 ? it + 1 : 15)>{});
@@ -700,10 +705,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
           const int f0 = 32 * nt + 8 * rq + 4 * g;
           const float4 bb = *reinterpret_cast<const float4*>(&cst[fm::cB5 + f0]);
           const float4 ww = *reinterpret_cast<const float4*>(&cst[fm::cW6 + f0]);
-          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 0], inv5, bb.x), 0.f), ww.x, dot);
-          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 1], inv5, bb.y), 0.f), ww.y, dot);
-          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 2], inv5, bb.z), 0.f), ww.z, dot);
-          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 3], inv5, bb.w), 0.f), ww.w, dot);
+          const float4 ss = *reinterpret_cast<const float4*>(&cst[fm::cS5 + f0]);
+          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 0], ss.x * inv5, bb.x), 0.f), ww.x, dot);
+          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 1], ss.y * inv5, bb.y), 0.f), ww.y, dot);
+          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 2], ss.z * inv5, bb.z), 0.f), ww.z, dot);
+          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 3], ss.w * inv5, bb.w), 0.f), ww.w, dot);
         }
       }
       dot += __shfl_xor(dot, 32);

@@ -38,7 +38,7 @@ extern "C" {
 #define DISN_E_WS (-3)    /* workspace too small */
 
 /* ABI version of this header; disn_abi_version() returns the library's. */
-#define DISN_ABI_VERSION 7
+#define DISN_ABI_VERSION 8
 int disn_abi_version(void);
 
 /* ---------------------------------------------------------------------- *
@@ -65,7 +65,13 @@ int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w
  * f16 split of both operands (x = h + l after a power-of-two scale; l_a h_b + h_a l_b + h_a h_b accumulated in
  * fp32), the 3x3 halo of a 2-D pixel patch staged once in LDS, all K parallelism inside the workgroup -- no
  * split-K pass.  disn_pack_conv_h2: TF HWIO [3][3][Cin][Cout] -> the weight image (Cin, Cout multiples of 64;
- * `image` holds disn_pack_conv_h2_bytes).  disn_conv3x3_h2: out = act(conv(in) + bias) [B,H,W,Cout]; optional
+ * `image` holds disn_pack_conv_h2_bytes).  OPERAND SCALES (round 4): activations one power of two per IMAGE (largest
+ * magnitude -> [2^14, 2^15)); weights one power of two per OUTPUT CHANNEL (largest |entry| of the column -> [2^13,
+ * 2^14); the inverse scales are the image's tail, a lane multiplies its column's accumulators with its own next to
+ * the bias).  The two-term split keeps ~22 bits of an operand down to 2^-17 of its scale's maximum (below, f16's
+ * 2^-24 subnormal floor takes over): with per-column weight scales, trained-like weights with log-normal channel
+ * gains and outlier channels x 1000 stay inside the 1e-5 bar (tests/test_gpu_stress.py; a per-TENSOR weight scale, rounds
+ * 2-3, left the ordinary columns of such a tensor with a handful of bits: tools/split_model.py).  disn_conv3x3_h2: out = act(conv(in) + bias) [B,H,W,Cout]; optional
  * pool_out = its 2x2 max pool [B,H/2,W/2,Cout] (H, W even), optional out_amax = max |out| (the activation scale
  * of a following disn_conv3x3_h2 inside disn_encode*; here every image's own maximum is measured first: as inside
  * disn_encode* the scale of an image, hence its bits, never depend on the other images of the call).

@@ -120,6 +120,55 @@ def init_weights(seed: int = 0, mode: str = "xavier", num_classes: int = 1024) -
     return out
 
 
+def trained_like_weights(seed: int = 0, sigma: float = 1.0, outlier_frac: float = 0.01, outlier_gain: float = 1.0e3,
+                         heavy_tail_df: float = 4.0, num_classes: int = 1024) -> Dict[str, np.ndarray]:
+    """Synthetic weights with the STATISTICS of trained ones (the released SDF_DISN / vgg_16.ckpt checkpoints of
+    README.md:27-39 are not available offline): heavy-tailed entries (Student-t, `heavy_tail_df` degrees of freedom,
+    He variance 2 / fan_in), N(0, 0.1) biases, and per-channel gains -- every output channel c of every hidden layer
+    is multiplied by g_c = exp(sigma * N(0,1)), a fraction `outlier_frac` of the channels by a further `outlier_gain`,
+    and the rows every consumer of that channel reads are divided by g_c (next convolution, fc6, the local stream's
+    fold2/conv1 rows of the five taps, the global stream's fold2/conv1 rows of the embedding).  ReLU and max-pool are
+    positively homogeneous and resize / resampler are linear, so in exact arithmetic the network function is that of
+    the ungained weights (|pred| stays O(1), the 1e-5 absolute bar stays meaningful), while every activation tensor
+    now has log-normal channel magnitudes with outlier channels 10^3 above the rest -- what a per-tensor power-of-two
+    operand scale (conv_h2w / dense_h2w / mlp_fused) has to survive."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    t_std = math.sqrt(heavy_tail_df / (heavy_tail_df - 2.0))
+    for name, shp in variable_shapes(num_classes).items():
+        if name.endswith("/weights"):
+            kh, kw, ci, co = shp
+            w = rng.standard_t(heavy_tail_df, size=shp) * (math.sqrt(2.0 / (kh * kw * ci)) / t_std)
+            out[name] = w.astype(np.float64)
+        else:
+            out[name] = rng.normal(0.0, 0.1, size=shp).astype(np.float64)
+    convs = ["vgg_16/%s/%s_%d" % (sc, sc, j) for sc, n, _ in VGG_CFG for j in range(1, n + 1)]
+    chain = []          # (producer, [(consumer, first input row of the producer's channels)])
+    tap_row = {nm: 512 + sum(TAP_CHANNELS[:i]) for i, nm in enumerate(TAP_NAMES)}
+    for i, nm in enumerate(convs):
+        cons = [(convs[i + 1], 0)] if i + 1 < len(convs) else [("vgg_16/fc6", 0)]
+        leaf = nm.rsplit("/", 1)[1]
+        if leaf in tap_row:
+            cons.append(("sdfprediction_imgfeat/fold2/conv1", tap_row[leaf]))
+        chain.append((nm, cons))
+    chain += [("vgg_16/fc6", [("vgg_16/fc7", 0)]), ("vgg_16/fc7", [("vgg_16/fc8", 0)]),
+              ("vgg_16/fc8", [("sdfprediction/fold2/conv1", 512)])]
+    for sc in ("sdfprediction", "sdfprediction_imgfeat"):
+        seq = ["fold1/conv1", "fold1/conv2", "fold1/conv3", "fold2/conv1", "fold2/conv2", "fold2/conv5"]
+        for a, b in zip(seq[:-1], seq[1:]):
+            chain.append(("%s/%s" % (sc, a), [("%s/%s" % (sc, b), 0)]))
+    for prod, cons in chain:
+        co = out[prod + "/biases"].shape[0]
+        g = np.exp(sigma * rng.standard_normal(co))
+        g = np.where(rng.random(co) < outlier_frac, g * outlier_gain, g)
+        out[prod + "/weights"] = out[prod + "/weights"] * g
+        out[prod + "/biases"] = out[prod + "/biases"] * g
+        for cname, row0 in cons:
+            w = out[cname + "/weights"]
+            w[:, :, row0:row0 + co, :] = w[:, :, row0:row0 + co, :] / g[None, None, :, None]
+    return {k: v.astype(np.float32) for k, v in out.items()}
+
+
 # --------------------------------------------------------------------------
 # row A / E : tf.image.resize_bilinear, TF1 legacy (align_corners=False)
 # --------------------------------------------------------------------------

@@ -43,10 +43,11 @@ def split(x):
 
 
 def pack(w_hwio):
-    """-> (image [frags][plane][lane][8] float16, s_w): the byte order of the device image"""
+    """-> (image [frags][plane][lane][8] float16, s_w [Cout]): the byte order of the device image; one power-of-two
+    scale per output channel (column), largest |entry| of the column -> [2^13, 2^14)"""
     _, _, cin, cout = w_hwio.shape
     w = w_hwio.reshape(9 * cin, cout).astype(np.float32)
-    s = pow2_scale(np.abs(w).max(), 13)
+    s = np.array([pow2_scale(m, 13) for m in np.abs(w).max(axis=0)], np.float32)
     KB = cin // 16
     frags = (cout // 32) * KB * 9
     img = np.zeros((frags, 2, 64, 8), np.float16)
@@ -55,7 +56,7 @@ def pack(w_hwio):
         for lane in range(64):
             j, g = lane & 31, lane >> 5
             ci = 16 * kb + 8 * g + np.arange(8)
-            v = w[t * cin + ci, 32 * nb + j] * s
+            v = w[t * cin + ci, 32 * nb + j] * s[32 * nb + j]
             img[f, 0, lane], img[f, 1, lane] = split(v.astype(np.float32))
     return img, s
 
@@ -73,7 +74,7 @@ def conv_tile(x, img, s_w, bias, tiling, tile, relu=True, exact_operands=False):
     tyi, txi, nt = tile
     y0, x0 = tyi * TH, txi * TW
     sa = pow2_scale(np.abs(x).max(), 14)
-    descale = np.float32(1.0) / sa * (np.float32(1.0) / s_w)
+    descale = np.float32(1.0) / sa * (np.float32(1.0) / np.asarray(s_w, np.float32))     # [Cout]: per column
     out, pooled, vmax = {}, {}, 0.0
     for wn in range(NW):
         n0 = (nt * NW + wn) * 32
@@ -132,7 +133,7 @@ def conv_tile(x, img, s_w, bias, tiling, tile, relu=True, exact_operands=False):
                     yy = y0 + mb * RPS + seg
                     for e in range(4):
                         r, tx = 4 * q + e, pos0 + e
-                        v = tot[mb, r, lane] * float(descale) + float(bias[n0 + j])
+                        v = tot[mb, r, lane] * float(descale[n0 + j]) + float(bias[n0 + j])
                         if relu:
                             v = max(v, 0.0)
                         val[mb, r, lane] = v

@@ -60,7 +60,7 @@ def conv_tile(x, img, s_w, bias, variant, tile, relu=True):
     tyi, txi, nt = tile
     y0, x0 = tyi * TH, txi * TW
     sa = pow2_scale(np.abs(x).max(), 14)
-    descale = np.float32(1.0) / sa * (np.float32(1.0) / s_w)
+    descale = np.float32(1.0) / sa * (np.float32(1.0) / np.asarray(s_w, np.float32))     # [Cout]: per column
     acc = np.zeros((MWV, NWV, WK, MB, 16, 64), np.float64)
     for c in range(NC):
         # ---- the halo in byte-addressed LDS (one buffer; f16 element a at byte 2a), NaN = never written ----
@@ -122,7 +122,7 @@ def conv_tile(x, img, s_w, bias, variant, tile, relu=True):
                             yy, xx = y0 + 2 * wy, x0 + 2 * wx
                             v = []
                             for e in range(4):
-                                t = tot[mb, 4 * q + e, lane] * float(descale) + float(bias[n0 + j])
+                                t = tot[mb, 4 * q + e, lane] * float(descale[n0 + j]) + float(bias[n0 + j])
                                 if relu:
                                     t = max(t, 0.0)
                                 v.append(t)

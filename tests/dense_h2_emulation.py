@@ -19,16 +19,17 @@ TILES = {(1, 2): "<1,2,KPW>", (2, 2): "<2,2,KPW>", (2, 4): "<2,4,KPW>", (4, 2): 
 
 
 def pack(w_kn):
-    """[K][N] -> (image [frags][plane][lane][8] float16, s_w): frag index nb * (K / 16) + kb (one tap)"""
+    """[K][N] -> (image [frags][plane][lane][8] float16, s_w [N]): frag index nb * (K / 16) + kb (one tap); one
+    power-of-two scale per output column"""
     K, N = w_kn.shape
-    s = pow2_scale(np.abs(w_kn).max(), 13)
+    s = np.array([pow2_scale(m, 13) for m in np.abs(w_kn).max(axis=0)], np.float32)
     KB = K // 16
     img = np.zeros(((N // 32) * KB, 2, 64, 8), np.float16)
     for f in range(img.shape[0]):
         kb, nb = f % KB, f // KB
         for lane in range(64):
             j, g = lane & 31, lane >> 5
-            v = (w_kn[16 * kb + 8 * g + np.arange(8), 32 * nb + j] * s).astype(np.float32)
+            v = (w_kn[16 * kb + 8 * g + np.arange(8), 32 * nb + j] * s[32 * nb + j]).astype(np.float32)
             img[f, 0, lane], img[f, 1, lane] = split(v)
     return img, s
 
@@ -115,7 +116,7 @@ def dense_tile(a1, a2, img, s_w, bias, MB, NW, KPW, tile, amax, in_bias=None, re
                             for r in range(16):
                                 acc[wk, mb, r, lane] += Dm[(r & 3) + 8 * (r >> 2) + 4 * g, j]
         tot = (acc[0] + acc[2]) + (acc[1] + acc[3])
-        descale = (1.0 / float(cur_scale if presplit else sa)) * (1.0 / float(s_w))
+        descale = (1.0 / float(cur_scale if presplit else sa)) * (1.0 / np.asarray(s_w, np.float64))   # [N]: per column
         for wk in range(WK):                                    # wave wk finishes register quad wk
             for lane in range(64):
                 j, g = lane & 31, lane >> 5
@@ -123,7 +124,7 @@ def dense_tile(a1, a2, img, s_w, bias, MB, NW, KPW, tile, amax, in_bias=None, re
                 for mb in range(MB):
                     for e in range(4):
                         r, m = 4 * wk + e, m0 + mb * 32 + L0 + e
-                        v = tot[mb, r, lane] * descale + float(bias[n0 + j])
+                        v = tot[mb, r, lane] * descale[n0 + j] + float(bias[n0 + j])
                         if relu:
                             v = max(v, 0.0)
                         if m < M:

@@ -55,14 +55,19 @@ def split16(v: np.ndarray):
     return h, l
 
 
+ISW_OFF = (64, 64 + 256, 64 + 256 + 512, 64 + 256 + 512 + 512)   # fm::mS2 .. mS5
+META = 64 + 256 + 512 + 512 + 256
+
+
 def pack_image(w2, w3, w4p, w5):
-    """-> (image [PAIRS, 2, 64, 8] float16, meta float32[16]) exactly as fm_meta_kernel + fm_pack_kernel"""
+    """-> (image [PAIRS, 2, 64, 8] float16, meta float32[META]) exactly as fm_meta_kernel + fm_pack_kernel: meta[8],
+    meta[9] the column 1-norm bounds, from float 64 on the inverse weight scales per output feature (isw2[256],
+    isw3[512], isw4[512], isw5[256])"""
     ws = [np.asarray(w, np.float32) for w in (w2, w3, w4p, w5)]
-    meta = np.zeros(16, np.float32)
+    meta = np.zeros(META, np.float32)
     for i, w in enumerate(ws):
-        s = pow2_scale_for(float(np.abs(w).max()), 13)
-        meta[i] = s
-        meta[4 + i] = 1.0 / s
+        s = np.array([pow2_scale_for(float(m), 13) for m in np.abs(w).max(axis=0)], np.float32)
+        meta[ISW_OFF[i]:ISW_OFF[i] + w.shape[1]] = np.float32(1.0) / s
     meta[8] = np.float32(np.abs(ws[2]).sum(axis=0, dtype=np.float32).max() * np.float32(1.0001))
     meta[9] = np.float32(np.abs(ws[1]).sum(axis=0, dtype=np.float32).max() * np.float32(1.0001))
     img = np.zeros((PAIRS, 2, 64, 8), np.float16)
@@ -73,7 +78,7 @@ def pack_image(w2, w3, w4p, w5):
         layer, nt, kb = pair_coords(p)
         w = ws[layer]
         k = phi(kb, g[:, None], t[None, :])                       # [64, 8]
-        v = w[k, (32 * nt + i)[:, None]] * np.float32(meta[layer])
+        v = w[k, (32 * nt + i)[:, None]] * (np.float32(1.0) / meta[ISW_OFF[layer] + 32 * nt + i])[:, None]
         img[p, 0], img[p, 1] = split16(v)
     return img, meta
 
@@ -103,7 +108,7 @@ def fused_stream(img, meta, consts, pts, add4=None):
     lane = np.arange(64)
     j, g = lane & 31, lane >> 5
     f32 = np.float32
-    inv_sw = meta[4:8]
+    isw = [meta[o:o + n] for o, n in zip(ISW_OFF, (256, 512, 512, 256))]     # per output feature
     cw4, cw3 = meta[8], meta[9]
     x, y, z = (pts[j, c].astype(f32) for c in range(3))
     t = np.arange(8)
@@ -120,7 +125,7 @@ def fused_stream(img, meta, consts, pts, add4=None):
     m = np.maximum(m, m[lane ^ 32])
     e = exp_of(m)
     s = (2.0 ** (14 - e)).astype(f32)
-    inv2 = (2.0 ** (e - 14)).astype(f32) * inv_sw[0]
+    inv2 = (2.0 ** (e - 14)).astype(f32)
     x1 = [split16(e1[kb] * s[:, None]) for kb in range(4)]
 
     p = 0   # stream position
@@ -140,26 +145,26 @@ def fused_stream(img, meta, consts, pts, add4=None):
             assert pair_coords(p) == (0, nt, kb)
             z2[nt] = pair(z2[nt], *x1[kb])
     for nt in range(8):
-        z2[nt] = np.maximum(z2[nt] * inv2[:, None] + consts["b2"][feat_of_reg(nt)], 0)
+        z2[nt] = np.maximum(z2[nt] * (inv2[:, None] * isw[0][feat_of_reg(nt)]) + consts["b2"][feat_of_reg(nt)], 0)
     m = z2.max(axis=(0, 2))
     m = np.maximum(m, m[lane ^ 32])
     e2 = exp_of(m)
     s2 = (2.0 ** (14 - e2)).astype(f32)
-    inv3 = (2.0 ** (e2 - 14)).astype(f32) * inv_sw[1]
+    inv3 = (2.0 ** (e2 - 14)).astype(f32)
     bound3 = (m * cw3 + np.abs(consts["b3"]).max()).astype(f32)
     e3 = exp_of(bound3)
     s3 = (2.0 ** (14 - e3)).astype(f32)
-    inv4 = (2.0 ** (e3 - 14)).astype(f32) * inv_sw[2]
+    inv4 = (2.0 ** (e3 - 14)).astype(f32)
     e4 = exp_of((bound3 * cw4 + f32(consts["addmax4"])).astype(f32))
     s4 = (2.0 ** (14 - e4)).astype(f32)
-    inv5 = (2.0 ** (e4 - 14)).astype(f32) * inv_sw[3]
+    inv5 = (2.0 ** (e4 - 14)).astype(f32)
     x2 = []
     for nt in range(8):
         for hf in range(2):
             x2.append(split16(z2[nt][:, 8 * hf:8 * hf + 8] * s2[:, None]))
 
-    def tile_to_frags(acc, bias, inv, sc, nt, add=None):
-        v = acc * inv[:, None] + bias[feat_of_reg(nt)]
+    def tile_to_frags(acc, bias, inv, sc, nt, add=None, layer=1):
+        v = acc * (inv[:, None] * isw[layer][feat_of_reg(nt)]) + bias[feat_of_reg(nt)]
         if add is not None:
             v = v + add[j[:, None], feat_of_reg(nt)]
         v = (np.maximum(v, 0) * sc[:, None]).astype(f32)
@@ -180,14 +185,14 @@ def fused_stream(img, meta, consts, pts, add4=None):
     # phase B
     acc5 = np.zeros((8, 64, 16), f32)
     for it in range(16):
-        fr = tile_to_frags(acc4[it], consts["b4"], inv4, s4, it, add4)
+        fr = tile_to_frags(acc4[it], consts["b4"], inv4, s4, it, add4, layer=2)
         for r in range(16):
             assert pair_coords(p) == (3, r & 7, 2 * it + (r >> 3))
             acc5[r & 7] = pair(acc5[r & 7], *fr[r >> 3])
     assert p == PAIRS
     dot = np.zeros(64, f32)
     for nt in range(8):
-        h5 = np.maximum(acc5[nt] * inv5[:, None] + consts["b5"][feat_of_reg(nt)], 0)
+        h5 = np.maximum(acc5[nt] * (inv5[:, None] * isw[3][feat_of_reg(nt)]) + consts["b5"][feat_of_reg(nt)], 0)
         dot += (h5 * consts["w6"][feat_of_reg(nt)]).sum(axis=1, dtype=f32)
     dot = dot + dot[lane ^ 32] + f32(consts["b6"])
     return dot[:32]

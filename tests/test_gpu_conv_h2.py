@@ -44,8 +44,8 @@ def test_weight_image_equals_the_layout_restatement(ops):
     ref, s = E.pack(w)
     n = ref.size * 2
     assert np.array_equal(img[:n].view(np.float16).reshape(ref.shape), ref)
-    meta = img[n:n + 8].view(np.float32)
-    assert meta[0] == s and meta[1] == 1.0 / s
+    inv_sw = img[n:n + 4 * 64].view(np.float32)             # the tail: 1 / s_w per output channel
+    assert np.array_equal(inv_sw, np.float32(1.0) / s)
 
 
 VGG_SHAPES = [(224, 64, 64), (112, 64, 128), (112, 128, 128), (56, 128, 256), (56, 256, 256), (28, 256, 512),

@@ -43,8 +43,8 @@ def test_device_pack_equals_the_layout_restatement(eng_store, scope):
     ref_img, ref_meta = E.pack_image(*ws)
     nb = E.PAIRS * 2048
     got_img = raw[:nb].view(np.float16).reshape(E.PAIRS, 2, 64, 8)
-    got_meta = raw[nb:nb + 64].view(np.float32)
-    assert np.array_equal(got_meta[:8], ref_meta[:8]), (got_meta[:10], ref_meta[:10])
+    got_meta = raw[nb:nb + 4 * E.META].view(np.float32)
+    assert np.array_equal(got_meta[64:], ref_meta[64:])                       # inverse weight scales per output feature
     np.testing.assert_allclose(got_meta[8:10], ref_meta[8:10], rtol=1e-5)     # column 1-norms: summation order
     assert np.array_equal(got_img.view(np.uint16), ref_img.view(np.uint16))
 
