@@ -241,7 +241,7 @@ def resize_bilinear_legacy_blocks(img: np.ndarray, out_h: int, out_w: int, worke
     xl4 = xl[None, None, :, None]
     T = np.empty((B, H, out_w, C), np.float32)
     out = np.empty((B, out_h, out_w, C), np.float32)
-    workers = max(1, int(workers))
+    workers = max(1, int(workers)) if B * out_h * out_w * C >= (1 << 21) else 1   # small outputs: pool start-up dominates
 
     def blocks(n):
         nb = max(1, min(n, 4 * workers))

@@ -42,10 +42,10 @@ def test_single_step_form_on_trained_like_statistics(stress):
     """one image per call: conv_h2.hip / dense_h2.hip (K parallel inside the workgroup)"""
     s, g = stress, stress["gold"]
     for b in (0, 1):
-        emb, pred = s["eng"].encode_query(s["dev"](s["inp"]["imgs"][b:b + 1]), s["dev"](s["inp"]["pts_a"][b:b + 1]),
+        enc, pred = s["eng"].encode_query(s["dev"](s["inp"]["imgs"][b:b + 1]), s["dev"](s["inp"]["pts_a"][b:b + 1]),
                                           s["dev"](s["inp"]["trans_mat"][b:b + 1]))
         e = _report("single step, image %d" % b, pred.cpu().numpy().reshape(-1), g["pred64_a"][b])
-        ee = _report("single step, image %d, embedding" % b, emb.cpu().numpy()[0], g["emb64"][b])
+        ee = _report("single step, image %d, embedding" % b, enc.embedding.cpu().numpy()[0], g["emb64"][b])
         assert e <= PRED_ATOL
         assert ee <= 1e-5 + 2e-6 * float(np.abs(g["emb64"][b]).max())
 
@@ -53,12 +53,11 @@ def test_single_step_form_on_trained_like_statistics(stress):
 def test_batched_form_on_trained_like_statistics(stress):
     """four images per call: conv_h2w.hip / dense_h2w.hip (K sequential); taps against the oracle's at their scale"""
     s, g = stress, stress["gold"]
-    emb, pred = s["eng"].encode_query(s["dev"](s["inp"]["imgs"]), s["dev"](s["inp"]["pts_a"]), s["dev"](s["inp"]["trans_mat"]))
+    enc, pred = s["eng"].encode_query(s["dev"](s["inp"]["imgs"]), s["dev"](s["inp"]["pts_a"]), s["dev"](s["inp"]["trans_mat"]))
     worst = 0.0
     for b in range(4):
         worst = max(worst, _report("batched call, image %d" % b, pred[b].cpu().numpy().reshape(-1), g["pred64_a"][b]))
     assert worst <= PRED_ATOL
-    enc = s["eng"].encode(s["dev"](s["inp"]["imgs"]))
     stride = int(g["tap_stride"])
     for t, nm in zip(enc.taps, O.TAP_NAMES):
         got = t.cpu().numpy()[[0, 3]].reshape(2, -1)[:, ::stride].astype(np.float64)
