@@ -49,10 +49,11 @@ MLP_FOLD_FIELDS = ("l_w4_point", "l_w4_feat", "l_x4_point", "l_x4_feat")   # opt
 MLP_FUSED_FIELDS = ("g_fused", "l_fused")   # optional: *_fused entry points (disn_mlp_fused_pack images)
 MLP_T_FIELDS = ("g_w4_global_t",)           # optional: g_w4_global transposed [512][1024]
 MLP_D_FIELDS = ("g_d2", "g_d3", "g_d4_point", "g_d5", "l_d2", "l_d3", "l_d4", "l_d5")   # optional: dense_h2 images
+MLP_FEAT_FIELDS = ("l_feat",)               # optional: disn_mlp_fused_feat_pack image (fused small-set local stream)
 
 
 class MlpWeights(C.Structure):  # disn_mlp_weights_t
-    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS + MLP_X3_FIELDS + MLP_FOLD_FIELDS + MLP_FUSED_FIELDS + MLP_T_FIELDS + MLP_D_FIELDS]
+    _fields_ = [(n, C.c_void_p) for n in MLP_FIELDS + MLP_X3_FIELDS + MLP_FOLD_FIELDS + MLP_FUSED_FIELDS + MLP_T_FIELDS + MLP_D_FIELDS + MLP_FEAT_FIELDS]
 
 
 CAM_FIELDS = tuple("%s_%s%d" % (t, k, i) for t in "srt" for i in (1, 2, 3) for k in "wb")
@@ -107,9 +108,14 @@ SIGNATURES = {
     "disn_project": (I, [P, P, I, I, P, P]),
     "disn_gather": (I, [P, P, I, I, P, P]),
     "disn_gather_taps": (I, [C.POINTER(C.c_void_p * 5), P, P, I, I, P, P]),
+    "disn_gather_taps_split": (I, [C.POINTER(C.c_void_p * 5), P, P, I, I, P, P, P]),
     "disn_gather_fold": (I, [P, P, P, I, P, P, P, P]),
     "disn_mlp_fused_image_bytes": (Z, []),
     "disn_mlp_fused_pack": (I, [P, P, P, P, P, P]),
+    "disn_mlp_fused_feat_image_bytes": (Z, []),
+    "disn_mlp_fused_feat_pack": (I, [P, P, P, P, P, P]),
+    "disn_query_taps_fused_workspace_bytes": (Z, [I, I]),
+    "disn_query_taps_fused": (I, [C.POINTER(MlpWeights), C.POINTER(C.c_void_p * 5), P, P, P, P, I, I, P, P, Z, P]),
     "disn_amax": (I, [P, L, P, P]),
     "disn_query_fused_workspace_bytes": (Z, [I, L]),
     "disn_query_fused": (I, [C.POINTER(MlpWeights), P, P, P, P, P, P, I, L, P, P, Z, P]),

@@ -463,6 +463,33 @@ const int kMapPixels = DISN_IMG_H * DISN_IMG_W;
 
 const int kFeatPad = 1536;   // gathered feature rows zero-padded to a multiple of 256 columns (dense_h2 chunks)
 
+// ---- the fused point MLP of a SMALL point set (round 4; models/sdfnet.py:71-90,173-186 + model_normalization.py:171-204)
+// B images x N points (N % 128 == 0), no feature map and no folded map: the gather from the taps writes the 1472
+// features in split form (one power-of-two scale per image from the taps' maxima), mlp_fused_kernel<local, FEAT> takes
+// them as 96 extra reduction blocks of fold2/conv1, mlp_fused_kernel<global> runs with the image's folded bias row and
+// adds the local sums: two launches per call behind the gather, every activation in registers.
+bool fused_small_ok(const disn_mlp_weights_t* w, int B, int N) {
+  return x3_enabled() && tune::fused_small != 0 && w->g_fused && w->l_feat && N % 128 == 0 && (long)B * N <= kChunk;
+}
+// tap_slots[k]: image 0's 64 activation-maximum slots of tap k (image b's are slot_stride floats further each);
+// featmax: B floats of scratch; lsum: B * N floats of scratch
+int fused_small_local(const disn_mlp_weights_t* w, float* const taps[5], const float* const tap_slots[5],
+                      size_t slot_stride, const float* trans_mat, const float* pts, const float* pts_rot, int B, int N,
+                      float* feat_split, float* featmax, float* lsum, hipStream_t st) {
+  DISN_TRY(tap_amax_launch(tap_slots, slot_stride, B, featmax, st));
+  DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, feat_split, st, kFeatPad, nullptr, 0, 0, featmax));
+  DISN_TRY(mlp_fused_small_launch(true, w->l_feat, w->l_w1, w->l_b1, w->l_b2, w->l_b3, w->l_b4, w->l_b5, w->l_w6, w->l_b6,
+                                  pts_rot, N, B, feat_split, kFeatPad, featmax, nullptr, lsum, 1.0f, st));
+  return 0;
+}
+int fused_small_global(const disn_mlp_weights_t* w, const float* gbias, const float* pts_rot, int B, int N,
+                       const float* lsum, float* sdf, float out_div, hipStream_t st) {
+  DISN_TRY(mlp_fused_small_launch(false, w->g_fused, w->g_w1, w->g_b1, w->g_b2, w->g_b3, gbias, w->g_b5, w->g_w6, w->g_b6,
+                                  pts_rot, N, B, nullptr, 0, nullptr, lsum, sdf, out_div, st));
+  return 0;
+}
+
+
 struct QueryWs {
   float *gbias, *gemv_ws, *feat, *pts;
   MlpWs mlp;
@@ -914,6 +941,29 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   const float* pool5 = nullptr;
   bool gather_on_st = false;
   if (ctx->pipe_wait) DISN_TRY(hipStreamWaitEvent(st, ctx->pipe_wait, 0));  // behind the previous step's convolutions
+  // Round 4: a batched call (>= kConvWideMinImages images) with the fused small-set kernels -- nothing runs beside the
+  // convolutions; behind conv5_3 the auxiliary stream gathers (split form) and runs the local stream's one launch
+  // under the fc head; the global stream's one launch follows the folded bias and adds the local sums.
+  bool conv_h2_all = x3_enabled();
+  for (int i = 0; i < 13; ++i) conv_h2_all = conv_h2_all && vw->conv_w_h2[i] != nullptr;
+  if (two && conv_h2_all && !featmap && B >= tune::conv_wide_min && fused_small_ok(mw, B, N)) {
+    rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, nullptr, e.vgg, &pool5, st);
+    if (rc) return rc;
+    DISN_TRY(hipEventRecord(ctx->ev[7], st));
+    DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
+    static const int tap_layer[5] = {1, 3, 6, 9, 12};
+    const float* slots[5];
+    for (int k = 0; k < 5; ++k) slots[k] = e.vgg.amax + (size_t)B * 64 * (tap_layer[k] + 1);
+    if ((rc = fused_small_local(mw, taps, slots, 64, trans_mat, pts, pts_rot, B, N, e.q.feat, e.q.mlp.amax, e.q.mlp.l5,
+                                ctx->aux)))
+      return rc;
+    DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
+    if (ctx->pipe_record) DISN_TRY(hipEventRecord(ctx->pipe_record, st));
+    if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
+    { const int grc = gbias_layer(mw, embedding, B, e.q.gbias, e.q.gemv_ws, st); if (grc) return grc; }
+    DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
+    return fused_small_global(mw, e.q.gbias, pts_rot, B, N, e.q.mlp.l5, sdf, 1.0f, st);
+  }
   const bool h2 = two && B <= kH2Imgs && mlp_h2(mw, N);   // small point sets: the dense_h2 layers, image by image
   const int feat_ld = h2 && !featmap ? kFeatPad : DISN_FEAT_DIM;
   const int hb = h2 && N % 64 == 0 ? B : 1;   // images per h2 launch
@@ -1052,6 +1102,16 @@ int disn_gather_taps(const float* const taps[5], const float* trans_mat, const f
   for (int i = 0; i < 5; ++i)
     if (!taps[i]) return DISN_E_ARG;
   DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, feat, (hipStream_t)stream));
+  return 0;
+}
+
+int disn_gather_taps_split(const float* const taps[5], const float* trans_mat, const float* pts, int B, int N,
+                           const float* feat_amax, void* feat_split, void* stream) {
+  if (!taps || !trans_mat || !pts || !feat_amax || !feat_split || B <= 0 || N <= 0) return DISN_E_ARG;
+  for (int i = 0; i < 5; ++i)
+    if (!taps[i]) return DISN_E_ARG;
+  DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, static_cast<float*>(feat_split),
+                                      (hipStream_t)stream, kFeatPad, nullptr, 0, 0, feat_amax));
   return 0;
 }
 
@@ -1200,6 +1260,68 @@ int disn_mlp_fused_pack(const float* w2, const float* w3, const float* w4_point,
   if (!w2 || !w3 || !w4_point || !w5 || !image) return DISN_E_ARG;
   DISN_TRY(mlp_fused_pack_launch(w2, w3, w4_point, w5, image, (hipStream_t)stream));
   return 0;
+}
+
+size_t disn_mlp_fused_feat_image_bytes(void) { return mlp_fused_feat_image_bytes(); }
+
+int disn_mlp_fused_feat_pack(const float* w2, const float* w3, const float* w4, const float* w5, void* image,
+                             void* stream) {
+  if (!w2 || !w3 || !w4 || !w5 || !image) return DISN_E_ARG;
+  DISN_TRY(mlp_fused_feat_pack_launch(w2, w3, w4, w5, image, (hipStream_t)stream));
+  return 0;
+}
+
+namespace {
+struct TapsFusedWs {
+  float *gbias, *gemv_ws, *feat, *slots, *featmax, *lsum;
+  size_t total;
+};
+TapsFusedWs taps_fused_layout(void* ws, int B, int N) {
+  Bump b(ws);
+  TapsFusedWs f;
+  f.gbias = b.take((size_t)B * 512 * sizeof(float));
+  f.gemv_ws = b.take(gemv_ws_bytes(B, DISN_EMBED_DIM, 512));
+  f.feat = b.take((size_t)B * N * kFeatPad * sizeof(float));
+  f.slots = b.take((size_t)5 * B * 64 * sizeof(float));
+  f.featmax = b.take((size_t)B * sizeof(float));
+  f.lsum = b.take((size_t)B * N * sizeof(float));
+  f.total = (b.off + 255) & ~size_t(255);
+  return f;
+}
+}  // namespace
+
+size_t disn_query_taps_fused_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0 || N % 128 || (long)B * N > kChunk) return 0;
+  return taps_fused_layout(nullptr, B, N).total;
+}
+
+int disn_query_taps_fused(const disn_mlp_weights_t* w, const float* const taps[5], const float* embedding,
+                          const float* trans_mat, const float* pts, const float* pts_rot, int B, int N, float* sdf,
+                          void* ws, size_t ws_bytes, void* stream) {
+  if (!mlp_weights_ok(w) || !w->g_fused || !w->l_feat || !taps || !embedding || !trans_mat || !pts || !pts_rot || !sdf ||
+      !ws || B <= 0 || N <= 0)
+    return DISN_E_ARG;
+  for (int i = 0; i < 5; ++i)
+    if (!taps[i]) return DISN_E_ARG;
+  if (N % 128 || (long)B * N > kChunk) return DISN_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const TapsFusedWs f = taps_fused_layout(ws, B, N);
+  if (f.total > ws_bytes) return DISN_E_WS;
+  // the taps' exact maxima, per image (inside disn_encode_query they come out of the convolutions' epilogues: the
+  // same numbers, hence the same split scale and the same bits)
+  static const int hw[5] = {224, 112, 56, 28, 14}, ch[5] = {64, 128, 256, 512, 512};
+  DISN_TRY(hipMemsetAsync(f.slots, 0, (size_t)5 * B * 64 * sizeof(float), st));
+  const float* slots[5];
+  for (int k = 0; k < 5; ++k) {
+    slots[k] = f.slots + (size_t)k * B * 64;
+    DISN_TRY(amax64_accumulate_launch(taps[k], (size_t)hw[k] * hw[k] * ch[k], f.slots + (size_t)k * B * 64, st, B, 64));
+  }
+  float* tp[5];
+  for (int k = 0; k < 5; ++k) tp[k] = const_cast<float*>(taps[k]);
+  int rc = fused_small_local(w, tp, slots, 64, trans_mat, pts, pts_rot, B, N, f.feat, f.featmax, f.lsum, st);
+  if (rc) return rc;
+  { const int grc = gbias_layer(w, embedding, B, f.gbias, f.gemv_ws, st); if (grc) return grc; }
+  return fused_small_global(w, f.gbias, pts_rot, B, N, f.lsum, sdf, 1.0f, st);
 }
 
 int disn_amax(const float* x, int64_t n, float* out, void* stream) {
@@ -1419,6 +1541,7 @@ int densew_m64 = -1, densew_c128 = -1;
 int conv11_wgs = 0;
 int tn_interleave = -1;
 int conv5_whole = 1;
+int fused_small = 1;
 long long* ch2_stamps = nullptr;
 }
 }  // namespace disn
@@ -1428,16 +1551,16 @@ extern "C" int disn_tuning_set_ptr(int key, void* p) {
   return 0;
 }
 // tuning builds only (build.py --tuning -> libdisn_amd_tuning.so): 0 x3, 1 overlap, 2 bf_splits, 3 skip_pack,
-// 4 fused_safe, 5-7 gemm_force, 8 gemv_wgs, 9 dense_mb, 10 dense_nw, 11 dense_kpw, 12 conv_occ, 13 conv_occ_mask, 14 conv_occ_min, 15 aux_cu_mode, 16 conv_img_major, 17 conv_wide_min, 18 l4_ranges, 19 gather_l16, 20 densew_m64, 21 densew_c128, 22 conv11_wgs, 23 tn_interleave, 24 conv5_whole
+// 4 fused_safe, 5-7 gemm_force, 8 gemv_wgs, 9 dense_mb, 10 dense_nw, 11 dense_kpw, 12 conv_occ, 13 conv_occ_mask, 14 conv_occ_min, 15 aux_cu_mode, 16 conv_img_major, 17 conv_wide_min, 18 l4_ranges, 19 gather_l16, 20 densew_m64, 21 densew_c128, 22 conv11_wgs, 23 tn_interleave, 24 conv5_whole, 25 fused_small
 extern "C" int disn_tuning_set(int key, int value) {
-  int* k[25] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
+  int* k[26] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
                 &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
                 &disn::tune::gemm_force[2], &disn::tune::gemv_wgs, &disn::tune::dense_mb,
                 &disn::tune::dense_nw, &disn::tune::dense_kpw, &disn::tune::conv_occ, &disn::tune::conv_occ_mask,
                 &disn::tune::conv_occ_min, &disn::tune::aux_cu_mode,
                 &disn::tune::conv_img_major, &disn::tune::conv_wide_min, &disn::tune::l4_ranges, &disn::tune::gather_l16, &disn::tune::densew_m64, &disn::tune::densew_c128,
-                &disn::tune::conv11_wgs, &disn::tune::tn_interleave, &disn::tune::conv5_whole};
-  if (key < 0 || key > 24) return DISN_E_ARG;
+                &disn::tune::conv11_wgs, &disn::tune::tn_interleave, &disn::tune::conv5_whole, &disn::tune::fused_small};
+  if (key < 0 || key > 25) return DISN_E_ARG;
   *k[key] = value;
   return 0;
 }

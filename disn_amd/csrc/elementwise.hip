@@ -311,13 +311,22 @@ __device__ __forceinline__ float4 tap_pixel(const float* __restrict__ tap, int h
   return o;
 }
 
+// power of two s with amax * s in [2^14, 2^15) (amax > 0 after feat_split_amax's floor); as pow2_scale_for of
+// mlp_fused.hip: the two sides of the split form must pick the same scale
+__device__ __forceinline__ float split_pow2_scale(float amax) {
+  const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+  if (!(amax > 0.f) || e > 100 || e < -100) return 1.0f;
+  return __uint_as_float((unsigned)(127 + 14 - e) << 23);
+}
+
 template <bool L16>
 __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
                                                                    const float* __restrict__ trans_mat,
                                                                    const float* __restrict__ pts, int B,
                                                                    int n, int c4_begin, int c4_count,
                                                                    float* __restrict__ feat, int feat_ld,
-                                                                   float* __restrict__ amax, size_t amax_stride) {
+                                                                   float* __restrict__ amax, size_t amax_stride,
+                                                                   const float* __restrict__ split_amax) {
   // B images x n points each (rows image-major); tap k of image b at t.p[k] + b * t.stride[k].  feat_ld > 1472
   // (all five taps only): rows of feat_ld floats, columns 1472 .. feat_ld - 1 written as zeros (c4_count covers
   // them) -- a zero-padded K for a GEMM that wants 256-column chunks (dense_h2.hip).
@@ -325,6 +334,10 @@ __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
   // at amax[b * amax_stride + iw] (plain store, every (b, iw) writes): the dense_h2 layer behind takes the maximum
   // over the G entries as its operand scale -- no extra pass over feat and no atomics (same-line atomics cost ~4 ns
   // EACH on this part: one per wave made the 14 us kernel a 60 us one).
+  // split_amax != nullptr (round 4, the operand of mlp_fused_kernel<local, FEAT>): the row is written in SPLIT form --
+  // the same fp32 value v, then x = v * s with the image's power-of-two scale s = 2^14 / 2^e(max(split_amax[b], 2^-20))
+  // (split_amax[b] >= max |tap| of image b bounds every feature), h = f16(x), l = f16(x - h); every 8 channels take
+  // their 32 bytes as [h8 | l8].  A thread's four channels are 8 bytes of each plane.
   const size_t per_img = (size_t)n * c4_count;
   size_t i, end, step;
   int iw = 0, bimg = 0;
@@ -449,7 +462,21 @@ __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
 #undef DISN_LERP
     }
     }
-    *reinterpret_cast<float4*>(feat + pt * feat_ld + c) = o;
+    if (split_amax) {
+      const float sc = split_pow2_scale(feat_split_amax(split_amax[b]));
+      const float xs[4] = {o.x * sc, o.y * sc, o.z * sc, o.w * sc};
+      _Float16 hh[4], ll[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hh[e] = (_Float16)xs[e];
+        ll[e] = (_Float16)(xs[e] - (float)hh[e]);
+      }
+      unsigned char* row = reinterpret_cast<unsigned char*>(feat) + (pt * (size_t)feat_ld + (size_t)(c & ~7)) * 4 + ((c & 4) ? 8 : 0);
+      *reinterpret_cast<uint2*>(row) = *reinterpret_cast<const uint2*>(hh);
+      *reinterpret_cast<uint2*>(row + 16) = *reinterpret_cast<const uint2*>(ll);
+    } else {
+      *reinterpret_cast<float4*>(feat + pt * feat_ld + c) = o;
+    }
     vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
   }
   if (amax) {
@@ -483,7 +510,7 @@ int project_gather_taps_amax_blocks(int n, int feat_ld, int tap_begin, int tap_e
 hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
                                       const float* pts, int B, int n, int tap_begin, int tap_end,
                                       float* feat, hipStream_t st, int feat_ld, float* amax,
-                                      size_t amax_stride, int amax_cap) {
+                                      size_t amax_stride, int amax_cap, const float* split_amax) {
   static const int c4_off[6] = {0, 16, 48, 112, 240, DISN_FEAT4};
   static const int ch[5] = {64, 128, 256, 512, 512};
   TapSet t;
@@ -500,15 +527,15 @@ hipError_t project_gather_taps_launch(const float* const taps[5], const float* t
     int G = project_gather_taps_amax_blocks(n, feat_ld, tap_begin, tap_end);
     if (amax_cap > 0 && G > amax_cap) G = amax_cap;   // entries the caller has room for
     if (tune::gather_l16) hipLaunchKernelGGL(project_gather_taps_kernel<true>, dim3((unsigned)(B * G)), dim3(1024), 0, st, t, trans_mat, pts, B, n,
-                       c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
+                       c4_begin, c4_count, feat, feat_ld, amax, amax_stride, split_amax);
     else hipLaunchKernelGGL(project_gather_taps_kernel<false>, dim3((unsigned)(B * G)), dim3(1024), 0, st, t, trans_mat, pts, B, n,
-                       c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
+                       c4_begin, c4_count, feat, feat_ld, amax, amax_stride, split_amax);
     return hipGetLastError();
   }
   if (tune::gather_l16) hipLaunchKernelGGL(project_gather_taps_kernel<true>, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
-                     trans_mat, pts, B, n, c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
+                     trans_mat, pts, B, n, c4_begin, c4_count, feat, feat_ld, amax, amax_stride, split_amax);
   else hipLaunchKernelGGL(project_gather_taps_kernel<false>, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
-                     trans_mat, pts, B, n, c4_begin, c4_count, feat, feat_ld, amax, amax_stride);
+                     trans_mat, pts, B, n, c4_begin, c4_count, feat, feat_ld, amax, amax_stride, split_amax);
   return hipGetLastError();
 }
 

@@ -129,7 +129,9 @@ hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_
 hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
                                       const float* pts, int B, int n, int tap_begin, int tap_end,
                                       float* feat, hipStream_t st, int feat_ld = 0, float* amax = nullptr,
-                                      size_t amax_stride = 0, int amax_cap = 0);
+                                      size_t amax_stride = 0, int amax_cap = 0, const float* split_amax = nullptr);
+// split_amax != nullptr ([B] floats, >= max |tap| of each image): rows in SPLIT form (two f16 planes of feature * the
+// image's power-of-two scale, [h8 | l8] per 8 channels) -- the operand of mlp_fused_small_launch(local)
 // amax != nullptr (all five taps): max |feat| per workgroup at amax[b * amax_stride + (0 .. blocks - 1)]
 int project_gather_taps_amax_blocks(int n, int feat_ld, int tap_begin = 0, int tap_end = 5);  // feat_ld > 1472: zero-padded rows
 // folded local fold2/conv1 (disn_fold_local): h = relu(pre + resample(pmap_b)(pts) + bias), [n,512]
@@ -242,6 +244,18 @@ hipError_t mc_emit_launch(const float* vol, const GridSpec& g, float iso, float*
 
 // ---- mlp_fused.hip: both point MLPs as one persistent kernel per stream, activations in registers ----
 size_t mlp_fused_image_bytes();
+size_t mlp_fused_feat_image_bytes();
+// the floor under an image's feature maximum before it becomes the split scale (shared by the gather that writes the
+// split form and the fused kernel that consumes it: the same bits); 2^-20 loses nothing (the scaled values stay < 2^15)
+__host__ __device__ inline float feat_split_amax(float a) { return a > 9.5367431640625e-07f ? a : 9.5367431640625e-07f; }
+// w4: the whole local fold2/conv1 matrix [512 + 1472][512]
+hipError_t mlp_fused_feat_pack_launch(const float* w2, const float* w3, const float* w4, const float* w5, void* image,
+                                      hipStream_t st);
+hipError_t mlp_fused_small_launch(bool local, const void* image, const float* w1, const float* b1, const float* b2,
+                                  const float* b3, const float* b4, const float* b5, const float* w6, const float* b6,
+                                  const float* pts_rot, long long rows_per_image, int images, const void* feat_split,
+                                  int feat_ld, const float* feat_amax, const float* add_in, float* out, float out_div,
+                                  hipStream_t st);
 // w2 [64][256], w3 [256][512], w4_point [512][512] (the point rows of fold2/conv1), w5 [512][256]: TF [K][N]
 hipError_t mlp_fused_pack_launch(const float* w2, const float* w3, const float* w4_point, const float* w5,
                                  void* image, hipStream_t st);
@@ -254,6 +268,8 @@ hipError_t amax64_accumulate_launch(const float* x, size_t n, float* out64, hipS
                                     size_t out_stride = 0);
 // maximum of n non-negative slots; groups > 1: `groups` runs of n slots, `stride` floats apart
 hipError_t amax_fold_launch(const float* slots, float* out, hipStream_t st, int n = 64, int groups = 1, int stride = 0);
+// out[b] = the maximum over five 64-slot groups (the five taps' activation maxima of image b: slots[k] + b * image_stride)
+hipError_t tap_amax_launch(const float* const slots[5], size_t image_stride, int B, float* out, hipStream_t st);
 // one stream for n points of one image; pts_rot == nullptr: points k0.. of `grid`.  local: gather from
 // pmap + 'sdfprediction_imgfeat', out = (add_in + sum) / out_div; global: 'sdfprediction' with b4 = the
 // folded per-image bias row, out = sum

@@ -57,6 +57,15 @@ constexpr int kPairs = kPairsL2 + 16 * kPairsA + 16 * kPairsB;  // 1056 (tile, k
 constexpr int kSlotBytes = 16384;                             // 8 pairs
 constexpr int kSlots = kPairs / 8;                            // 132 per pass over the image
 constexpr size_t kImageBytes = (size_t)kPairs * 2048;         // 2 162 688
+// FEAT form (round 4: the local stream of a SMALL point set, the gathered features as extra reduction blocks of
+// fold2/conv1 -- models/sdfnet.py:180's concat [point 512 | feature 1472]): between phase A and phase B, phase A2 =
+// 16 iterations x {six reduction blocks 32 + 6 it2 .. (feature columns 96 it2 .. 96 it2 + 95 of the zero-padded
+// 1536) for the 16 output tiles: 96 pairs}.  1536 = 32 x 48 pairs: every later pair keeps its position mod 48, i.e.
+// its fragment register set (mod 3) and ring-slot parity (mod 16)
+constexpr int kFeatBlocks = 96, kFeatCols = 16 * kFeatBlocks, kFeatReal = 1472;   // 1536 columns, 1472 real
+constexpr int kPairsA2 = 96;
+constexpr int kPairsFeat = kPairs + 16 * kPairsA2;              // 2592
+constexpr size_t kImageBytesFeat = (size_t)kPairsFeat * 2048;   // 5 308 416
 // meta (behind the image): floats [8] max_f ||W4[:,f]||_1; [9] max_f ||W3[:,f]||_1; from float 64 on the inverse
 // weight scales PER OUTPUT FEATURE (round 4; as conv_h2.hip's per-column scales): isw2[256], isw3[512], isw4[512],
 // isw5[256] -- layer l's feature f is packed as W[:, f] * s, s = the power of two that puts max |W[:, f]| into
@@ -80,19 +89,22 @@ __device__ __forceinline__ float pow2_scale_for(float amax, int target_exp) {
 
 // one workgroup per layer: per-feature (column) amax -> inverse scale; conv3 and fold2/conv1 (point rows) also the
 // largest column 1-norm
+// k4: rows of w4 -- 512 (the point rows) or 1984 (FEAT form: + the 1472 feature rows, whose largest column 1-norm
+// goes to meta[10])
 __global__ __launch_bounds__(256) void fm_meta_kernel(const float* __restrict__ w2, const float* __restrict__ w3,
                                                       const float* __restrict__ w4, const float* __restrict__ w5,
-                                                      float* __restrict__ meta) {
+                                                      float* __restrict__ meta, int k4) {
   __shared__ float red[256];
   const int layer = blockIdx.x;
   const float* w = layer == 0 ? w2 : (layer == 1 ? w3 : (layer == 2 ? w4 : w5));
-  const int K = layer == 0 ? 64 : (layer == 1 ? 256 : 512);
+  const int Kall = layer == 0 ? 64 : (layer == 1 ? 256 : (layer == 2 ? k4 : 512));
+  const int K = layer == 0 ? 64 : (layer == 1 ? 256 : 512);     // rows of the point part (the 1-norm bound below)
   const int N = layer == 0 ? 256 : (layer == 3 ? 256 : 512);
   {
     float* isw = meta + (layer == 0 ? fm::mS2 : (layer == 1 ? fm::mS3 : (layer == 2 ? fm::mS4 : fm::mS5)));
     for (int f = threadIdx.x; f < N; f += 256) {
       float m = 0.f;
-      for (int k = 0; k < K; ++k) m = fmaxf(m, fabsf(w[(size_t)k * N + f]));
+      for (int k = 0; k < Kall; ++k) m = fmaxf(m, fabsf(w[(size_t)k * N + f]));
       isw[f] = 1.0f / pow2_scale_for(m, 13);
     }
   }
@@ -110,11 +122,27 @@ __global__ __launch_bounds__(256) void fm_meta_kernel(const float* __restrict__ 
       __syncthreads();
     }
     if (threadIdx.x == 0) meta[layer == 2 ? 8 : 9] = red[0] * 1.0001f;  // summation-order slack: the bound must hold
+    if (layer == 2 && k4 > 512) {   // the feature rows' largest column 1-norm
+      __syncthreads();
+      c = 0.f;
+      for (int f = threadIdx.x; f < N; f += 256) {
+        float a = 0.f;
+        for (int k = 512; k < k4; ++k) a += fabsf(w[(size_t)k * N + f]);
+        c = fmaxf(c, a);
+      }
+      red[threadIdx.x] = c;
+      __syncthreads();
+      for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) meta[10] = red[0] * 1.0001f;
+    }
   }
 }
 
 // pair index -> layer (0: conv2, 1: conv3, 2: fold2/conv1, 3: fold2/conv2), output tile, reduction block
-__host__ __device__ inline void fm_pair_coords(int p, int& layer, int& nt, int& kb) {
+__host__ __device__ inline void fm_pair_coords(int p, int& layer, int& nt, int& kb, bool feat = false) {
   if (p < fm::kPairsL2) { layer = 0; nt = p >> 2; kb = p & 3; return; }
   p -= fm::kPairsL2;
   if (p < 16 * fm::kPairsA) {  // phase A, iteration it = output tile of conv3
@@ -123,18 +151,32 @@ __host__ __device__ inline void fm_pair_coords(int p, int& layer, int& nt, int& 
     layer = 2; nt = (r - 16) & 15; kb = 2 * it + ((r - 16) >> 4);
     return;
   }
-  p -= 16 * fm::kPairsA;  // phase B, iteration it = output tile of fold2/conv1
+  p -= 16 * fm::kPairsA;
+  if (feat) {  // phase A2, iteration it2: reduction blocks 32 + 6 it2 + {0..5}, two at a time for the 16 output tiles
+    if (p < 16 * fm::kPairsA2) {
+      const int it2 = p / fm::kPairsA2, r = p - it2 * fm::kPairsA2;
+      layer = 2; nt = r & 15; kb = 32 + 6 * it2 + 2 * (r >> 5) + ((r >> 4) & 1);
+      return;
+    }
+    p -= 16 * fm::kPairsA2;
+  }
+  // phase B, iteration it = output tile of fold2/conv1
   layer = 3; nt = p & 7; kb = 2 * (p >> 4) + ((p >> 3) & 1);
 }
 
+// k4 > 512: the FEAT image (w4 = the whole [k4][512] fold2/conv1 matrix; rows >= k4 of the padded 2048 are zeros).
+// Slot order of the FEATURE blocks (kb >= 32): natural -- lane (i, g), slot t <-> row 16 kb + 8 g + t: the B operand
+// comes from memory there (eight consecutive channels per lane), not from an MFMA's C layout
 __global__ __launch_bounds__(256) void fm_pack_kernel(const float* __restrict__ w2, const float* __restrict__ w3,
                                                       const float* __restrict__ w4, const float* __restrict__ w5,
-                                                      const float* __restrict__ meta, _Float16* __restrict__ image) {
+                                                      const float* __restrict__ meta, _Float16* __restrict__ image,
+                                                      int k4) {
+  const bool feat = k4 > 512;
   const int idx = blockIdx.x * 256 + threadIdx.x;  // (pair, lane)
-  if (idx >= fm::kPairs * 64) return;
+  if (idx >= (feat ? fm::kPairsFeat : fm::kPairs) * 64) return;
   const int p = idx >> 6, lane = idx & 63;
   int layer, nt, kb;
-  fm_pair_coords(p, layer, nt, kb);
+  fm_pair_coords(p, layer, nt, kb, feat);
   const float* w = layer == 0 ? w2 : (layer == 1 ? w3 : (layer == 2 ? w4 : w5));
   const int N = layer == 0 ? 256 : (layer == 3 ? 256 : 512);
   const int i = lane & 31, g = lane >> 5;
@@ -142,8 +184,8 @@ __global__ __launch_bounds__(256) void fm_pack_kernel(const float* __restrict__ 
   h8 hi, lo;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const int k = 16 * kb + (t & 3) + 8 * (t >> 2) + 4 * g;  // phi(kb, g, t)
-    const float v = w[(size_t)k * N + 32 * nt + i] * s;
+    const int k = (layer == 2 && kb >= 32) ? 16 * kb + 8 * g + t : 16 * kb + (t & 3) + 8 * (t >> 2) + 4 * g;  // phi(kb, g, t)
+    const float v = (layer == 2 && k >= k4) ? 0.f : w[(size_t)k * N + 32 * nt + i] * s;
     const _Float16 h = (_Float16)v;
     hi[t] = h;
     lo[t] = (_Float16)(v - (float)h);
@@ -154,13 +196,23 @@ __global__ __launch_bounds__(256) void fm_pack_kernel(const float* __restrict__ 
 }
 
 size_t mlp_fused_image_bytes() { return fm::kImageBytes + fm::kMetaFloats * sizeof(float) + 64; }
+size_t mlp_fused_feat_image_bytes() { return fm::kImageBytesFeat + fm::kMetaFloats * sizeof(float) + 64; }
 
 hipError_t mlp_fused_pack_launch(const float* w2, const float* w3, const float* w4_point, const float* w5,
                                  void* image, hipStream_t st) {
   float* meta = reinterpret_cast<float*>(static_cast<char*>(image) + fm::kImageBytes);
-  hipLaunchKernelGGL(fm_meta_kernel, dim3(4), dim3(256), 0, st, w2, w3, w4_point, w5, meta);
+  hipLaunchKernelGGL(fm_meta_kernel, dim3(4), dim3(256), 0, st, w2, w3, w4_point, w5, meta, 512);
   hipLaunchKernelGGL(fm_pack_kernel, dim3((fm::kPairs * 64 + 255) / 256), dim3(256), 0, st, w2, w3, w4_point, w5,
-                     meta, reinterpret_cast<_Float16*>(image));
+                     meta, reinterpret_cast<_Float16*>(image), 512);
+  return hipGetLastError();
+}
+// the FEAT image of the local stream: w4 = the whole fold2/conv1 matrix [512 + 1472][512]
+hipError_t mlp_fused_feat_pack_launch(const float* w2, const float* w3, const float* w4, const float* w5, void* image,
+                                      hipStream_t st) {
+  float* meta = reinterpret_cast<float*>(static_cast<char*>(image) + fm::kImageBytesFeat);
+  hipLaunchKernelGGL(fm_meta_kernel, dim3(4), dim3(256), 0, st, w2, w3, w4, w5, meta, 512 + fm::kFeatReal);
+  hipLaunchKernelGGL(fm_pack_kernel, dim3((fm::kPairsFeat * 64 + 255) / 256), dim3(256), 0, st, w2, w3, w4, w5, meta,
+                     reinterpret_cast<_Float16*>(image), 512 + fm::kFeatReal);
   return hipGetLastError();
 }
 
@@ -220,6 +272,23 @@ hipError_t amax_fold_launch(const float* slots, float* out, hipStream_t st, int 
   return hipGetLastError();
 }
 
+struct TapSlots { const float* p[5]; size_t stride; };
+__global__ void tap_amax_kernel(const TapSlots t, float* __restrict__ out) {
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) m = fmaxf(m, t.p[k][(size_t)blockIdx.x * t.stride + threadIdx.x]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (threadIdx.x == 0) out[blockIdx.x] = m;
+}
+hipError_t tap_amax_launch(const float* const slots[5], size_t image_stride, int B, float* out, hipStream_t st) {
+  TapSlots t;
+  for (int k = 0; k < 5; ++k) t.p[k] = slots[k];
+  t.stride = image_stride;
+  hipLaunchKernelGGL(tap_amax_kernel, dim3(B), dim3(64), 0, st, t, out);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------
@@ -234,9 +303,17 @@ struct FusedDev {
   const float* T;          // trans_mat [4][3] of this image, device memory (local)
   const float* pmap;       // [137*137][512] (local)
   const float* pmap_amax;  // max |pmap| (local)
-  const float* add_in;     // local: the global stream's per-point sums; global: nullptr
+  const float* add_in;     // per-point sums of the other stream (added before the division), or nullptr
   float* out;
   float out_div;
+  // rows of several images in one launch (image-major, rows_per_image a multiple of 128; 0: one image): the global
+  // stream takes image b's bias row b4 + 512 b, the FEAT form image b's feature maximum
+  long long rows_per_image;
+  // FEAT form: gathered features in SPLIT form (project_gather_taps_kernel with a scale): row p = feat_ld floats' worth
+  // of bytes, every 8 channels as [h8 | l8] (f16 planes of feature * feat_split_scale(feat_amax[image]))
+  const unsigned char* feat;
+  const float* feat_amax;  // [images] max |tap| of the image: the bound of every gathered feature
+  int feat_ld;             // 1536
 };
 
 #define FM_FENCE() asm volatile("" ::: "memory")
@@ -307,6 +384,63 @@ __device__ __forceinline__ void fm_wait_vm(int n) {
   else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
   else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// the FEAT form's counts (4 per ring request, 12 per feature request: every multiple of 4 up to 60 occurs)
+__device__ __forceinline__ void fm_wait_vm4(int n) {
+  switch (n >= 60 ? 15 : (n >> 2)) {
+    case 15: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+// the six reduction blocks of one phase-A2 iteration for this wave's 32 points: lane (j, g) takes, per block b, the 32
+// bytes [h8 | l8] of channels 16 b + 8 g .. + 7 of its row -- global (sbase + voff) + 64 b (+ 16: the l plane) -> LDS
+// dst + 1024 (2 b + plane) (+ 16 lane).  The instruction offset moves the LDS address too: M0 is stepped so that the
+// twelve pieces land 1 KiB apart (piece 2b at M0 = dst + 2048 b - 64 b, piece 2b + 1 at M0 = dst + 2048 b + 1024 - 64 b - 16)
+__device__ __forceinline__ void fm_glds_feat(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_add_u32 m0, m0, 1008\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:16\n\t"
+      "s_add_u32 m0, m0, 976\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:64\n\t"
+      "s_add_u32 m0, m0, 1008\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:80\n\t"
+      "s_add_u32 m0, m0, 976\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:128\n\t"
+      "s_add_u32 m0, m0, 1008\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:144\n\t"
+      "s_add_u32 m0, m0, 976\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:192\n\t"
+      "s_add_u32 m0, m0, 1008\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:208\n\t"
+      "s_add_u32 m0, m0, 976\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:256\n\t"
+      "s_add_u32 m0, m0, 1008\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:272\n\t"
+      "s_add_u32 m0, m0, 976\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:320\n\t"
+      "s_add_u32 m0, m0, 1008\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:336\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory", "scc");
 }
 
 // projection + resampler corner weights exactly as elementwise.hip (project_point / sample4): no
@@ -396,11 +530,17 @@ __device__ __forceinline__ void fm_static_for(F&& f) {
   fm_static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-template <bool LOCAL, bool SAFE>
+// FEAT (with LOCAL): the local stream of a small point set -- no folded map; the gathered features (split form, one
+// scale per image) are 96 more reduction blocks of fold2/conv1 (phase A2), see fm::kPairsA2
+template <bool LOCAL, bool SAFE, bool FEAT = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
-  constexpr int R = LOCAL ? 5 : 9;  // ring slots
+  static_assert(!FEAT || LOCAL, "the FEAT form is the local stream's");
+  constexpr int R = FEAT ? 6 : (LOCAL ? 5 : 9);  // ring slots
   constexpr int DP = R - 2;         // a slot is requested DP syncs before the sync that waits for it
-  constexpr int GBUF = LOCAL ? 16384 : 0;
+  constexpr int GBUF = FEAT ? 12288 : (LOCAL ? 16384 : 0);   // per wave: four pmap rows of a tile / six feature blocks
+  constexpr int KP = FEAT ? fm::kPairsFeat : fm::kPairs;     // pairs per tile
+  constexpr int KSLOTS = KP / 8;
+  constexpr int QB = fm::kPairsL2 + 16 * fm::kPairsA + (FEAT ? 16 * fm::kPairsA2 : 0);   // first pair of phase B
   constexpr int RING_BYTES = R * fm::kSlotBytes;
   constexpr int CONST_OFF = RING_BYTES + 4 * GBUF;
   constexpr int LDS_BYTES = CONST_OFF + fm::kConstFloats * 4;
@@ -412,7 +552,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
   float* const cst = reinterpret_cast<float*>(&lds[CONST_OFF]);
   const int gbuf = RING_BYTES + wave * GBUF;  // byte offset of this wave's gather buffer
   const unsigned lds0 = fm_lds_addr(lds);
-  const float* meta = reinterpret_cast<const float*>(P.image + fm::kImageBytes);
+  const float* meta = reinterpret_cast<const float*>(P.image + (FEAT ? fm::kImageBytesFeat : fm::kImageBytes));
 
   // ---- constants -> LDS -------------------------------------------------------------------------------
   for (int i = tid; i < 192; i += 256) cst[fm::cW1 + i] = P.w1[i];
@@ -426,11 +566,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
   cst[fm::cW6 + tid] = P.w6[tid];
   if (tid == 0) cst[fm::cB6] = P.b6[0];
   for (int i = tid; i < fm::kMetaFloats - fm::mS2; i += 256) cst[fm::cS2 + i] = meta[fm::mS2 + i];  // isw2 | isw3 | isw4 | isw5
-  const float cw4 = meta[8], cw3 = meta[9];
-  float addmax4 = LOCAL ? P.pmap_amax[0] : 0.f, addmax3 = 0.f;
+  const float cw4 = meta[8], cw3 = meta[9], cw4f = FEAT ? meta[10] : 0.f;
+  float addmax4 = (LOCAL && !FEAT) ? P.pmap_amax[0] : 0.f, addmax3 = 0.f;
   float T[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) T[i] = LOCAL ? P.T[i] : 0.f;
+  for (int i = 0; i < 12; ++i) T[i] = (LOCAL && !FEAT) ? P.T[i] : 0.f;
   __syncthreads();
   {  // largest |bias| of conv3, largest |additive term| of fold2/conv1 (bias, or the folded per-image bias)
     float m3 = 0.f, m4 = 0.f;
@@ -447,6 +587,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
     addmax3 = m3;
     addmax4 += m4;
   }
+  const float addmax4_bias = addmax4;   // FEAT: max |b4| (the feature term is added per image)
 
   // ---- weight ring + the ledger of this wave's LDS-DMA loads ------------------------------------------------
   // Loads retire in order, so "the loads of batch X have landed" == "at most (issued - issued_after_X)
@@ -462,14 +603,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
     fm_glds_4k(P.image + (size_t)issue_slot * fm::kSlotBytes, img_voff, lds0 + issue_pos * fm::kSlotBytes + wave * 4096);
     issued += 4;
     mark[mi] = issued;
-    issue_slot = issue_slot + 1 == fm::kSlots ? 0 : issue_slot + 1;
+    issue_slot = issue_slot + 1 == KSLOTS ? 0 : issue_slot + 1;
     issue_pos = issue_pos + 1 == R ? 0 : issue_pos + 1;
   };
   int pix[4] = {0, 0, 0, 0};  // byte offsets of this lane's 16 bytes in the four pmap rows (tile 0)
   float wt[4] = {0.f, 0.f, 0.f, 0.f};
   // the four resampled pmap rows of output tile NT: 16 B per lane and piece (NT is a type: compile time)
   auto gather_issue = [&](auto nt_c) {
-    if constexpr (LOCAL) {
+    if constexpr (LOCAL && !FEAT) {
       constexpr int NT = decltype(nt_c)::value;
 #pragma unroll
       for (int tp = 0; tp < 4; ++tp) fm_glds_tap<NT>(P.pmap, (unsigned)pix[tp], lds0 + gbuf + tp * 4096);
@@ -480,8 +621,18 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
   auto gather_wait = [&]() {
     FM_FENCE();
     if (SAFE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (FEAT) fm_wait_vm4(issued - gmark);
     else fm_wait_vm(issued - gmark);
     FM_FENCE();
+  };
+  // FEAT: the six feature blocks of phase-A2 iteration it2 of the tile whose first row is row0 -> this wave's buffer
+  unsigned feat_voff = 0;   // this lane's row within the tile (clamped to the last row of the launch) and 32-byte half
+  auto feat_issue = [&](long long row0, int it2) {
+    if constexpr (FEAT) {
+      fm_glds_feat(P.feat + (size_t)row0 * (size_t)(P.feat_ld * 4) + (size_t)it2 * 384, feat_voff, lds0 + gbuf);
+      issued += 12;
+      gmark = issued;
+    }
   };
   // The sync for a slot runs in the MIDDLE of the slot before it (after pair 3 of 8), so that the first
   // fragments of the next slot can be read ahead of the last MFMAs of the current one: wait for this
@@ -492,6 +643,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
   auto sync_slot = [&](int parity, bool issue) {
     FM_FENCE();
     if (SAFE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (FEAT) fm_wait_vm4(issued - mark[0]);
     else fm_wait_vm(issued - mark[0]);
     __builtin_amdgcn_s_barrier();
     FM_FENCE();
@@ -517,7 +669,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
   // read pair Q+2, three MFMAs (small terms first), and after pair 3 of a slot the sync for the next slot
 #define FM_STEP_(Q, CLS, ACC, XH, XL, FIRST)                 \
   {                                                          \
-    if ((Q) + 2 < fm::kPairs) FM_LDW((Q) + 2);               \
+    if ((Q) + 2 < KP) FM_LDW((Q) + 2);                       \
     if (FIRST) FM_MFMA0(CLS, ACC, wl[(Q) % 3], XH);          \
     else FM_MFMA(CLS, ACC, wl[(Q) % 3], XH);                 \
     FM_MFMA(CLS, ACC, wh[(Q) % 3], XL);                      \
@@ -533,11 +685,37 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
     const long long pidx = tile * 128 + wave * 32 + j;
     const bool valid = pidx < P.n;
     const long long pc = valid ? pidx : P.n - 1;
+    // ---- this tile's image (rows of several images in one launch) ---------------------------------------
+    float sfeat = 1.0f, inv_sfeat = 1.0f;
+    if (P.rows_per_image > 0 || FEAT) {
+      const int img = P.rows_per_image > 0 ? (int)((tile * 128) / P.rows_per_image) : 0;
+      if (!LOCAL) {  // the global stream's folded bias row of this image (and the bound's additive term)
+        __syncthreads();
+        for (int i = tid; i < 512; i += 256) cst[fm::cB4 + i] = P.b4[(size_t)img * 512 + i];
+        __syncthreads();
+        float m4 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m4 = fmaxf(m4, fabsf(cst[fm::cB4 + lane + 64 * i]));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m4 = fmaxf(m4, __shfl_xor(m4, off));
+        addmax4 = m4;
+      }
+      if (FEAT) {  // every gathered feature is a convex combination of tap values: |feat| <= max |tap| of the image
+        const float fmax = feat_split_amax(P.feat_amax[img]);
+        sfeat = pow2_scale_for(fmax, 14);
+        inv_sfeat = 1.0f / sfeat;
+        addmax4 = fmaf(fmax, cw4f, addmax4_bias);
+      }
+    }
+    if (FEAT) {
+      feat_voff = (unsigned)(pc - tile * 128) * (unsigned)(P.feat_ld * 4) + (unsigned)g * 32u;
+      feat_issue(tile * 128, 0);
+    }
     float x, y, z, xp, yp, zp;
     if (P.pts_rot) {
       x = P.pts_rot[pc * 3]; y = P.pts_rot[pc * 3 + 1]; z = P.pts_rot[pc * 3 + 2];
       xp = x; yp = y; zp = z;
-      if (LOCAL) { xp = P.pts[pc * 3]; yp = P.pts[pc * 3 + 1]; zp = P.pts[pc * 3 + 2]; }
+      if (LOCAL && !FEAT) { xp = P.pts[pc * 3]; yp = P.pts[pc * 3 + 1]; zp = P.pts[pc * 3 + 2]; }
     } else {  // grid_points_kernel's expression (numpy.linspace in float64, cast to float32)
       const long long k = P.k0 + pc, res = P.grid.res;
       const int idx[3] = {(int)(k % res), (int)((k / res) % res), (int)(k / (res * res))};
@@ -551,7 +729,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
       }
       x = xp = c[0]; y = yp = c[1]; z = zp = c[2];
     }
-    if (LOCAL) {
+    if (LOCAL && !FEAT) {
       fm_project_taps(T, xp, yp, zp, pix, wt);
 #pragma unroll
       for (int tp = 0; tp < 4; ++tp) pix[tp] = (pix[tp] + 4 * g) * 4;
@@ -676,22 +854,52 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
       if (LOCAL && it == 14) gather_issue(std::integral_constant<int, 0>{});  // pmap rows of fold2/conv1's tile 0: one iteration of cover
     }
 
+    // ---- phase A2 (FEAT): the gathered features as 96 more reduction blocks of fold2/conv1 ------------------
+    if constexpr (FEAT) {
+      // the accumulators so far hold (h3 s3)(W s_w); the features come scaled by the image's s_feat: one exact
+      // power-of-two rescale, s_feat / s3, makes the two parts one sum at scale s_feat s_w
+      const float rs = sfeat * (1.0f / s3);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        FM_SETTLE_ACC("a", acc4[i]);
+        acc4[i] = acc4[i] * rs;
+        FM_SETTLE_IN1("a", acc4[i]);
+      }
+      inv4 = inv_sfeat;
+#pragma unroll 1
+      for (int it2 = 0; it2 < 16; ++it2) {
+        h8 fh6[6], fl6[6];
+        gather_wait();   // this iteration's six blocks are in the wave's buffer
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          fh6[b] = *reinterpret_cast<const h8*>(&lds[gbuf + (2 * b) * 1024 + lane * 16]);
+          fl6[b] = *reinterpret_cast<const h8*>(&lds[gbuf + (2 * b + 1) * 1024 + lane * 16]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer is read: the next iteration's blocks may land
+        if (it2 < 15) feat_issue(tile * 128, it2 + 1);
+        fm_static_for<96>([&](auto r_c) {  // reduction block 6 it2 + 2 (r >> 5) + ((r >> 4) & 1) for output tile r & 15
+          constexpr int r = decltype(r_c)::value;
+          FM_STEP(32 + 768 + r, "a", acc4[r & 15], fh6[2 * (r >> 5) + ((r >> 4) & 1)], fl6[2 * (r >> 5) + ((r >> 4) & 1)]);
+        });
+      }
+    }
+
     // ---- phase B: fold2/conv1's tiles drained into fold2/conv2 (512 -> 256): 16 iterations x 16 pairs ------
     f32x16 acc5[8];
     fm_static_for<16>([&](auto it_c) {
       constexpr int it = decltype(it_c)::value;
       h8 fh[2], fl[2];
       FM_SETTLE_ACC("a", acc4[it]);
-      if (LOCAL) gather_wait();
-      fm_tile_to_frags<LOCAL>(acc4[it], &cst[fm::cB4 + 32 * it + 4 * g], &cst[fm::cS4 + 32 * it + 4 * g], &lds[gbuf + lane * 16], wt, inv4, s4, fh, fl);
-      if (LOCAL && it < 15) {
+      if (LOCAL && !FEAT) gather_wait();
+      fm_tile_to_frags<(LOCAL && !FEAT)>(acc4[it], &cst[fm::cB4 + 32 * it + 4 * g], &cst[fm::cS4 + 32 * it + 4 * g], &lds[gbuf + lane * 16], wt, inv4, s4, fh, fl);
+      if (LOCAL && !FEAT && it < 15) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the gather buffer are done
         gather_issue(std::integral_constant<int, (it < 15 ? it + 1 : 15)>{});
       }
       FM_SETTLE_IN4(fh[0], fl[0], fh[1], fl[1]);
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        FM_STEP0(32 + 768 + 16 * it + r, "v", acc5[r & 7], fh[r >> 3], fl[r >> 3], it == 0 && r < 8);
+        FM_STEP0(QB + 16 * it + r, "v", acc5[r & 7], fh[r >> 3], fl[r >> 3], it == 0 && r < 8);
     });
 
     // ---- fold2/conv2 epilogue + fold2/conv5 (256 -> 1): dot with w6 --------------------------------------
@@ -715,7 +923,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
       dot += __shfl_xor(dot, 32);
       dot += cst[fm::cB6];
       if (valid && g == 0) {
-        if (LOCAL) P.out[pidx] = (P.add_in[pidx] + dot) / P.out_div;
+        if (P.add_in) P.out[pidx] = (P.add_in[pidx] + dot) / P.out_div;
+        else if (P.out_div != 1.0f) P.out[pidx] = dot / P.out_div;
         else P.out[pidx] = dot;
       }
     }
@@ -744,6 +953,37 @@ hipError_t mlp_fused_launch(bool local, const void* image, const float* w1, cons
   if (local) {
     if (tune::fused_safe) hipLaunchKernelGGL((mlp_fused_kernel<true, true>), dim3(grid_x), dim3(256), 0, st, P);
     else hipLaunchKernelGGL((mlp_fused_kernel<true, false>), dim3(grid_x), dim3(256), 0, st, P);
+  } else {
+    if (tune::fused_safe) hipLaunchKernelGGL((mlp_fused_kernel<false, true>), dim3(grid_x), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((mlp_fused_kernel<false, false>), dim3(grid_x), dim3(256), 0, st, P);
+  }
+  return hipGetLastError();
+}
+
+// Both streams of a SMALL point set -- `images` images x rows_per_image points (image-major; rows_per_image a multiple
+// of 128) -- in one launch each (round 4): the GLOBAL stream with image b's folded bias row gbias + 512 b, out = its
+// sums (add_in = nullptr) or (add_in + sum) / out_div; the LOCAL stream in the FEAT form on the split-form gathered
+// features (project_gather_taps_launch with split_amax) -- no folded map, activations never leave the registers.
+hipError_t mlp_fused_small_launch(bool local, const void* image, const float* w1, const float* b1, const float* b2,
+                                  const float* b3, const float* b4, const float* b5, const float* w6, const float* b6,
+                                  const float* pts_rot, long long rows_per_image, int images, const void* feat_split,
+                                  int feat_ld, const float* feat_amax, const float* add_in, float* out, float out_div,
+                                  hipStream_t st) {
+  if (rows_per_image <= 0 || rows_per_image % 128 || images <= 0) return hipErrorInvalidValue;
+  if (local && (!feat_split || !feat_amax || feat_ld != fm::kFeatCols)) return hipErrorInvalidValue;
+  FusedDev P{};
+  P.image = static_cast<const unsigned char*>(image);
+  P.w1 = w1; P.b1 = b1; P.b2 = b2; P.b3 = b3; P.b4 = b4; P.b5 = b5; P.w6 = w6; P.b6 = b6;
+  P.pts_rot = pts_rot;
+  P.n = rows_per_image * images;
+  P.rows_per_image = rows_per_image;
+  P.add_in = add_in; P.out = out; P.out_div = out_div;
+  P.feat = static_cast<const unsigned char*>(feat_split); P.feat_amax = feat_amax; P.feat_ld = feat_ld;
+  const long long tiles = P.n / 128;
+  const int grid_x = (int)(tiles < 256 ? tiles : 256);
+  if (local) {
+    if (tune::fused_safe) hipLaunchKernelGGL((mlp_fused_kernel<true, true, true>), dim3(grid_x), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((mlp_fused_kernel<true, false, true>), dim3(grid_x), dim3(256), 0, st, P);
   } else {
     if (tune::fused_safe) hipLaunchKernelGGL((mlp_fused_kernel<false, true>), dim3(grid_x), dim3(256), 0, st, P);
     else hipLaunchKernelGGL((mlp_fused_kernel<false, false>), dim3(grid_x), dim3(256), 0, st, P);

@@ -99,6 +99,9 @@ class DeviceWeights:
             img = ops.mlp_fused_pack(dev(W(scope, "fold1/conv2")), dev(W(scope, "fold1/conv3")), dev(w4[:512]),
                                      dev(W(scope, "fold2/conv2")))
             setattr(m, pre + "_fused", self._hold(img).data_ptr())
+        # ... and the FEAT form of the local stream (small point sets: the gathered features as reduction blocks)
+        m.l_feat = self._hold(ops.mlp_fused_feat_pack(dev(W(l, "fold1/conv2")), dev(W(l, "fold1/conv3")), dev(w4l),
+                                                      dev(W(l, "fold2/conv2")))).data_ptr()
         # dense_h2.hip images (two-term f16): the layers of a small point set (the 2048-point step), one launch each
         def d2(a):
             return self._hold(ops.pack_dense_h2(dev(a))).data_ptr()

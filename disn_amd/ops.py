@@ -407,6 +407,20 @@ def gather_taps(taps: Sequence[torch.Tensor], trans_mat: torch.Tensor, pts: torc
     return out
 
 
+def gather_taps_split(taps: Sequence[torch.Tensor], trans_mat: torch.Tensor, pts: torch.Tensor,
+                      feat_amax: torch.Tensor) -> torch.Tensor:
+    """disn_gather_taps_split: the rows of gather_taps in split form -> uint8 [B, N, 6144] ([h8 | l8] per 8 channels of
+    feature * the image's power-of-two scale from feat_amax [B])"""
+    pts = _chk(pts, "pts")
+    B, N, _ = pts.shape
+    out = torch.empty((B, N, 1536 * 4), dtype=torch.uint8, device=pts.device)
+    arr = (C.c_void_p * 5)(*[_chk(t, "tap").data_ptr() for t in taps])
+    check("disn_gather_taps_split", lib().disn_gather_taps_split(
+        C.byref(arr), _chk(trans_mat, "trans_mat").data_ptr(), pts.data_ptr(), B, N, _chk(feat_amax, "feat_amax").data_ptr(),
+        out.data_ptr(), _stream()))
+    return out
+
+
 def gather_fold(pmap_b: torch.Tensor, trans_mat_b: torch.Tensor, pts: torch.Tensor, pre: torch.Tensor,
                 bias: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """relu(pre + resample(pmap_b)(project(pts)) + bias) for N points of one image (disn_gather_fold)"""
@@ -431,6 +445,41 @@ def mlp_fused_pack(w2: torch.Tensor, w3: torch.Tensor, w4_point: torch.Tensor, w
     out = torch.empty(lib().disn_mlp_fused_image_bytes(), dtype=torch.uint8, device=ws[0].device)
     check("disn_mlp_fused_pack", lib().disn_mlp_fused_pack(ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(),
                                                            ws[3].data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
+def mlp_fused_feat_pack(w2: torch.Tensor, w3: torch.Tensor, w4: torch.Tensor, w5: torch.Tensor) -> torch.Tensor:
+    """FEAT-form weight image of the LOCAL stream (disn_mlp_fused_feat_pack): as mlp_fused_pack with w4 = the whole
+    fold2/conv1 matrix [512 + 1472, 512] (the gathered features are 96 extra reduction blocks of that layer)"""
+    ws = [_chk(t, "w") for t in (w2, w3, w4, w5)]
+    for t, shp in zip(ws, ((64, 256), (256, 512), (1984, 512), (512, 256))):
+        if tuple(t.shape) != shp:
+            raise ValueError("mlp_fused_feat_pack: expected %s, got %s" % (shp, tuple(t.shape)))
+    out = torch.empty(lib().disn_mlp_fused_feat_image_bytes(), dtype=torch.uint8, device=ws[0].device)
+    check("disn_mlp_fused_feat_pack", lib().disn_mlp_fused_feat_pack(ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(),
+                                                                     ws[3].data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
+def query_taps_fused(w: MlpWeights, taps: Sequence[torch.Tensor], embedding: torch.Tensor, trans_mat: torch.Tensor,
+                     pts: torch.Tensor, pts_rot: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """disn_query_taps_fused: rows D..H of B images x N points (N % 128 == 0, B * N <= 65536) from the five taps
+    through the fused small-set kernels (split-form gather + one launch per MLP stream)"""
+    pts = _chk(pts, "pts")
+    pts_rot = pts if pts_rot is None else _chk(pts_rot, "pts_rot")
+    B, N, _ = pts.shape
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=pts.device)
+    need = lib().disn_query_taps_fused_workspace_bytes(B, N)
+    if need == 0:
+        raise ValueError("query_taps_fused: N must be a multiple of 128 and B * N <= 65536, got B %d N %d" % (B, N))
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, pts.device)
+    tp = (C.c_void_p * 5)(*[_chk(t, "tap").data_ptr() for t in taps])
+    check("disn_query_taps_fused", lib().disn_query_taps_fused(
+        C.byref(w), C.byref(tp), _chk(embedding, "embedding").data_ptr(), _chk(trans_mat, "trans_mat").data_ptr(),
+        pts.data_ptr(), pts_rot.data_ptr(), B, N, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
     return out
 
 

@@ -244,6 +244,12 @@ int disn_gather(const float* featmap, const float* xy, int B, int N, float* feat
  * disn_build_featmap + disn_project + disn_gather. */
 int disn_gather_taps(const float* const taps[5], const float* trans_mat, const float* pts, int B, int N,
                      float* feat, void* stream);
+/* The same rows in SPLIT form (round 4), the operand of the fused small-set local stream (disn_query_taps_fused):
+ * feat_split holds B * N rows of 1536 * 4 bytes -- every 8 channels as [h8 | l8], the two f16 planes of
+ * feature * 2^k with k from feat_amax[b] (>= max |tap| of image b; floored at 2^-20): h = f16(x), l = f16(x - h);
+ * channels 1472..1535 zero.  The fp32 feature is disn_gather_taps's, bit for bit. */
+int disn_gather_taps_split(const float* const taps[5], const float* trans_mat, const float* pts, int B, int N,
+                           const float* feat_amax, void* feat_split, void* stream);
 /* The gather of the folded local stream (see disn_fold_local): for N points of ONE image
  * h[n][:] = relu(pre[n][:] + resample(pmap_b)(project(pts[n])) + bias), all [N,512]; h may alias pre. */
 int disn_gather_fold(const float* pmap_b, const float* trans_mat_b, const float* pts, int N, const float* pre,
@@ -283,6 +289,9 @@ typedef struct disn_mlp_weights {
    * [1984][512] zero-padded to [2048][512] and fold2/conv2 of the local stream.  With them a point set of fewer than 8192 points per image runs
    * its layers through dense_h2.hip (disn_encode_query, disn_query, disn_sdf_mlp): one short launch per layer. */
   const void *g_d2, *g_d3, *g_d4_point, *g_d5, *l_d2, *l_d3, *l_d4, *l_d5;
+  /* optional (with g_fused): disn_mlp_fused_feat_pack image of the local stream -- the FEAT form of the fused point
+   * MLP for small point sets (disn_query_taps_fused; batched disn_encode_query calls) */
+  const void* l_feat;
 } disn_mlp_weights_t;
 
 /* scratch for one launch over B images x N points (N per image) */
@@ -422,6 +431,8 @@ int disn_query_grid_folded(const disn_mlp_weights_t* w, const float* pmap, const
  * ring -> MFMA).  fp32-accurate products from a two-term fp16 split of     *
  * every operand (x = h + l, 23 significant bits; power-of-two scales per   *
  * layer for the weights and per point for the activations), fp32           *
+ * layer -- round 4: per OUTPUT FEATURE -- for the weights and per point    *
+ * for the activations), fp32                                               *
  * accumulation.  disn_mlp_fused_pack builds one stream's weight image from *
  * its four MFMA-shaped layers in TF [K][N] layout: fold1/conv2 [64][256],  *
  * fold1/conv3 [256][512], the 512 point rows of fold2/conv1 [512][512],    *
@@ -432,6 +443,24 @@ int disn_query_grid_folded(const disn_mlp_weights_t* w, const float* pmap, const
 size_t disn_mlp_fused_image_bytes(void);
 int disn_mlp_fused_pack(const float* w2, const float* w3, const float* w4_point, const float* w5, void* image,
                         void* stream);
+/* The FEAT form (round 4): the local stream of a SMALL point set -- B images x N points, N a multiple of 128, B * N <=
+ * 65536 -- without a feature map or a folded map (models/sdfnet.py:173-186 on the concat of :180, gather
+ * models/model_normalization.py:171-190).  The gather from the taps writes the 1472 features of a point in SPLIT form
+ * (two f16 planes of feature * 2^k, one k per image from the taps' maxima: every gathered feature is a convex combination
+ * of tap values) and the kernel takes them as 96 extra reduction blocks of fold2/conv1 straight from memory: one launch
+ * for the whole batch, every activation in registers.  disn_mlp_fused_feat_pack: as disn_mlp_fused_pack with w4 = the
+ * WHOLE fold2/conv1 matrix [512 + 1472][512]; set w->l_feat.  disn_query_taps_fused: rows D..H from the five taps
+ * (disn_vgg16_forward / disn_encode outputs) -- gather, local stream, folded global bias, global stream with image b's
+ * bias row, sum; same result as disn_query on the feature map of the same taps up to fp32 rounding (|gpu - f64| <= 1e-5
+ * on the He-weight configurations, tests/test_gpu_fused.py).  disn_encode_query runs the same launches for calls of
+ * >= 4 images (bit-identical to disn_encode + disn_query_taps_fused). */
+size_t disn_mlp_fused_feat_image_bytes(void);
+int disn_mlp_fused_feat_pack(const float* w2, const float* w3, const float* w4, const float* w5, void* image,
+                             void* stream);
+size_t disn_query_taps_fused_workspace_bytes(int B, int N);
+int disn_query_taps_fused(const disn_mlp_weights_t* w, const float* const taps[5], const float* embedding,
+                          const float* trans_mat, const float* pts, const float* pts_rot, int B, int N, float* sdf,
+                          void* ws, size_t ws_bytes, void* stream);
 /* *out = max |x[i]|, n a multiple of 4 */
 int disn_amax(const float* x, int64_t n, float* out, void* stream);
 /* disn_query_folded / disn_query_grid_folded through the fused kernels (two launches per image: global

@@ -21,7 +21,12 @@ PAIRS = PAIRS_L2 + 16 * PAIRS_A + 16 * PAIRS_B      # 1056
 LAYER_DIMS = [(64, 256), (256, 512), (512, 512), (512, 256)]   # conv2, conv3, fold2/conv1 (point rows), fold2/conv2
 
 
-def pair_coords(p: int):
+PAIRS_A2 = 96                                        # FEAT form: phase A2, 16 iterations of six feature blocks
+PAIRS_FEAT = PAIRS + 16 * PAIRS_A2                   # 2592
+FEAT_REAL, FEAT_COLS = 1472, 1536
+
+
+def pair_coords(p: int, feat: bool = False):
     """fm_pair_coords: stream position -> (layer, output tile, reduction block)"""
     if p < PAIRS_L2:
         return 0, p >> 2, p & 3
@@ -32,6 +37,11 @@ def pair_coords(p: int):
             return 1, it, r
         return 2, (r - 16) & 15, 2 * it + ((r - 16) >> 4)
     p -= 16 * PAIRS_A
+    if feat:
+        if p < 16 * PAIRS_A2:
+            it2, r = divmod(p, PAIRS_A2)
+            return 2, r & 15, 32 + 6 * it2 + 2 * (r >> 5) + ((r >> 4) & 1)
+        p -= 16 * PAIRS_A2
     return 3, p & 7, 2 * (p >> 4) + ((p >> 3) & 1)
 
 
@@ -64,20 +74,27 @@ def pack_image(w2, w3, w4p, w5):
     meta[9] the column 1-norm bounds, from float 64 on the inverse weight scales per output feature (isw2[256],
     isw3[512], isw4[512], isw5[256])"""
     ws = [np.asarray(w, np.float32) for w in (w2, w3, w4p, w5)]
+    feat = ws[2].shape[0] > 512              # the FEAT image: w4p is the whole [512 + 1472][512] matrix
     meta = np.zeros(META, np.float32)
     for i, w in enumerate(ws):
         s = np.array([pow2_scale_for(float(m), 13) for m in np.abs(w).max(axis=0)], np.float32)
         meta[ISW_OFF[i]:ISW_OFF[i] + w.shape[1]] = np.float32(1.0) / s
-    meta[8] = np.float32(np.abs(ws[2]).sum(axis=0, dtype=np.float32).max() * np.float32(1.0001))
+    meta[8] = np.float32(np.abs(ws[2][:512]).sum(axis=0, dtype=np.float32).max() * np.float32(1.0001))
+    if feat:
+        meta[10] = np.float32(np.abs(ws[2][512:]).sum(axis=0, dtype=np.float32).max() * np.float32(1.0001))
+        ws[2] = np.concatenate([ws[2], np.zeros((512 + FEAT_COLS - ws[2].shape[0], 512), np.float32)])
     meta[9] = np.float32(np.abs(ws[1]).sum(axis=0, dtype=np.float32).max() * np.float32(1.0001))
-    img = np.zeros((PAIRS, 2, 64, 8), np.float16)
+    npairs = PAIRS_FEAT if feat else PAIRS
+    img = np.zeros((npairs, 2, 64, 8), np.float16)
     lane = np.arange(64)
     i, g = lane & 31, lane >> 5
     t = np.arange(8)
-    for p in range(PAIRS):
-        layer, nt, kb = pair_coords(p)
+    for p in range(npairs):
+        layer, nt, kb = pair_coords(p, feat)
         w = ws[layer]
         k = phi(kb, g[:, None], t[None, :])                       # [64, 8]
+        if layer == 2 and kb >= 32:                               # feature blocks: natural slot order
+            k = 16 * kb + 8 * g[:, None] + t[None, :]
         v = w[k, (32 * nt + i)[:, None]] * (np.float32(1.0) / meta[ISW_OFF[layer] + 32 * nt + i])[:, None]
         img[p, 0], img[p, 1] = split16(v)
     return img, meta
@@ -101,15 +118,41 @@ def exp_of(m):
     return np.clip(e, -100, 100)
 
 
-def fused_stream(img, meta, consts, pts, add4=None):
+def feat_split_scale(featmax: float) -> np.float32:
+    """the image's power-of-two feature scale (elementwise.hip split_pow2_scale o feat_split_amax)"""
+    return np.float32(pow2_scale_for(max(float(featmax), 2.0 ** -20), 14))
+
+
+def split_rows(feat: np.ndarray, featmax: float) -> np.ndarray:
+    """project_gather_taps_kernel's SPLIT form of feature rows [n][1472] -> bytes [n][1536 * 4]: every 8 channels as
+    [h8 | l8] (f16 planes of feature * scale), the padding columns zero"""
+    n = feat.shape[0]
+    x = np.zeros((n, FEAT_COLS), np.float32)
+    x[:, :FEAT_REAL] = feat.astype(np.float32) * feat_split_scale(featmax)
+    h, l = split16(x)
+    out = np.zeros((n, FEAT_COLS // 8, 2, 8), np.float16)
+    out[:, :, 0] = h.reshape(n, -1, 8)
+    out[:, :, 1] = l.reshape(n, -1, 8)
+    return out.reshape(n, -1).view(np.uint8)
+
+
+def fused_stream(img, meta, consts, pts, add4=None, feat_rows=None, featmax=None):
     """One MLP stream for ONE wave (32 points): consts = dict(w1[3,64], b1, b2, b3, b4[512], b5, w6[256], b6);
     add4: optional [32 points, 512] additive term of fold2/conv1 (the resampled pmap rows); its |max| bound is
-    consts['addmax4'].  Returns the 32 per-point sums (fold2/conv5 output incl. b6)."""
+    consts['addmax4'].  FEAT form: feat_rows = split_rows(...) of the wave's 32 points (uint8 [32][6144]), featmax the
+    image's bound; `img` then is the FEAT image.  Returns the 32 per-point sums (fold2/conv5 output incl. b6)."""
+    featf = feat_rows is not None
+    npairs = PAIRS_FEAT if featf else PAIRS
     lane = np.arange(64)
     j, g = lane & 31, lane >> 5
     f32 = np.float32
     isw = [meta[o:o + n] for o, n in zip(ISW_OFF, (256, 512, 512, 256))]     # per output feature
     cw4, cw3 = meta[8], meta[9]
+    addmax4 = np.float32(consts["addmax4"])
+    if featf:
+        fmax = np.float32(max(float(featmax), 2.0 ** -20))
+        sfeat = feat_split_scale(featmax)
+        addmax4 = np.float32(fmax * meta[10] + np.float32(np.abs(consts["b4"]).max()))
     x, y, z = (pts[j, c].astype(f32) for c in range(3))
     t = np.arange(8)
     r16 = np.arange(16)
@@ -142,7 +185,7 @@ def fused_stream(img, meta, consts, pts, add4=None):
     z2 = np.zeros((8, 64, 16), f32)
     for nt in range(8):
         for kb in range(4):
-            assert pair_coords(p) == (0, nt, kb)
+            assert pair_coords(p, featf) == (0, nt, kb)
             z2[nt] = pair(z2[nt], *x1[kb])
     for nt in range(8):
         z2[nt] = np.maximum(z2[nt] * (inv2[:, None] * isw[0][feat_of_reg(nt)]) + consts["b2"][feat_of_reg(nt)], 0)
@@ -155,7 +198,7 @@ def fused_stream(img, meta, consts, pts, add4=None):
     e3 = exp_of(bound3)
     s3 = (2.0 ** (14 - e3)).astype(f32)
     inv4 = (2.0 ** (e3 - 14)).astype(f32)
-    e4 = exp_of((bound3 * cw4 + f32(consts["addmax4"])).astype(f32))
+    e4 = exp_of((bound3 * cw4 + addmax4).astype(f32))
     s4 = (2.0 ** (14 - e4)).astype(f32)
     inv5 = (2.0 ** (e4 - 14)).astype(f32)
     x2 = []
@@ -176,20 +219,34 @@ def fused_stream(img, meta, consts, pts, add4=None):
     for it in range(16):
         acc = np.zeros((64, 16), f32)
         for kb in range(16):
-            assert pair_coords(p) == (1, it, kb)
+            assert pair_coords(p, featf) == (1, it, kb)
             acc = pair(acc, *x2[kb])
         fr = tile_to_frags(acc, consts["b3"], inv3, s3, it)
         for r in range(32):
-            assert pair_coords(p) == (2, r & 15, 2 * it + (r >> 4))
+            assert pair_coords(p, featf) == (2, r & 15, 2 * it + (r >> 4))
             acc4[r & 15] = pair(acc4[r & 15], *fr[r >> 4])
+    # phase A2 (FEAT): one exact rescale s_feat / s3 per point, then the 96 feature blocks from the split rows
+    if featf:
+        acc4 = acc4 * (sfeat / s3)[None, :, None]
+        inv4 = np.full(64, f32(1.0) / sfeat, f32)
+        rows16 = feat_rows.view(np.float16).reshape(32, FEAT_COLS // 8, 2, 8)
+        for it2 in range(16):
+            fr6 = []
+            for b in range(6):                       # lane (j, g): channel group 2 (6 it2 + b) + g of its row
+                grp = 2 * (6 * it2 + b) + g
+                fr6.append((rows16[j, grp, 0], rows16[j, grp, 1]))
+            for r in range(96):
+                blk = 2 * (r >> 5) + ((r >> 4) & 1)
+                assert pair_coords(p, True) == (2, r & 15, 32 + 6 * it2 + blk)
+                acc4[r & 15] = pair(acc4[r & 15], *fr6[blk])
     # phase B
     acc5 = np.zeros((8, 64, 16), f32)
     for it in range(16):
         fr = tile_to_frags(acc4[it], consts["b4"], inv4, s4, it, add4, layer=2)
         for r in range(16):
-            assert pair_coords(p) == (3, r & 7, 2 * it + (r >> 3))
+            assert pair_coords(p, featf) == (3, r & 7, 2 * it + (r >> 3))
             acc5[r & 7] = pair(acc5[r & 7], *fr[r >> 3])
-    assert p == PAIRS
+    assert p == npairs
     dot = np.zeros(64, f32)
     for nt in range(8):
         h5 = np.maximum(acc5[nt] * (inv5[:, None] * isw[3][feat_of_reg(nt)]) + consts["b5"][feat_of_reg(nt)], 0)

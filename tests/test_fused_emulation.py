@@ -75,3 +75,37 @@ def test_emulated_kernel_matches_the_mlp(seed, scale, with_add):
     # the two-term path is as close to float64 as a plain float32 evaluation is (same order of magnitude)
     assert err <= 3e-6, (err, err32)
     assert err <= 4 * err32 + 2e-7, (err, err32)
+
+
+def test_feat_pair_coords_cover_every_block_once():
+    seen = {E.pair_coords(p, True) for p in range(E.PAIRS_FEAT)}
+    assert len(seen) == E.PAIRS_FEAT
+    assert sum(1 for c in seen if c[0] == 2) == ((512 + E.FEAT_COLS) // 16) * 16
+    assert sum(1 for c in seen if c[0] == 2 and c[2] >= 32) == 96 * 16
+    # every later pair keeps its position mod 48: fragment register set (mod 3) and ring-slot parity (mod 16)
+    assert (16 * E.PAIRS_A2) % 48 == 0 and E.PAIRS_FEAT % 8 == 0 and (E.PAIRS_FEAT // 8) % 2 == 0
+
+
+@pytest.mark.parametrize("seed,fscale", [(0, 1.0), (1, 300.0), (2, 1e-3)])
+def test_emulated_feat_form_matches_the_mlp(seed, fscale):
+    """the FEAT form (the gathered features as 96 extra reduction blocks of fold2/conv1, split form from memory, one
+    rescale s_feat / s3 of the accumulators) against the plain MLP on [point 512 | feature 1472]"""
+    w, consts, pts, _ = _make(seed, 1.0, False)
+    rng = np.random.default_rng(100 + seed)
+    w4f = (rng.standard_normal((E.FEAT_REAL, 512)) * np.sqrt(2.0 / 1984) / fscale).astype(np.float32)
+    w4 = np.concatenate([w[2] * np.float32(np.sqrt(512 / 1984.0)), w4f])
+    feat = (np.abs(rng.standard_normal((32, E.FEAT_REAL))) * fscale).astype(np.float32)
+    feat[:, rng.integers(0, E.FEAT_REAL, 15)] *= 40.0                 # outlier channels
+    featmax = float(np.abs(feat).max()) * 1.7                          # the taps' maximum: a bound, not the exact maximum
+    img, meta = E.pack_image(w[0], w[1], w4, w[3])
+    assert img.shape[0] == E.PAIRS_FEAT
+    got = E.fused_stream(img, meta, consts, pts, None, E.split_rows(feat, featmax), featmax)
+    add4 = feat.astype(np.float64) @ w4f.astype(np.float64)
+    wref = [w[0], w[1], w4[:512], w[3]]
+    ref = _mlp_ref(wref, consts, pts, add4)
+    ref32 = _mlp_ref(wref, consts, pts, (feat @ w4f).astype(np.float32), np.float32)
+    sc = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max()) / sc
+    err32 = float(np.abs(ref32 - ref).max()) / sc
+    assert err <= 3e-6, (err, err32)
+    assert err <= 4 * err32 + 2e-7, (err, err32)

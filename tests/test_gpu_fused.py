@@ -150,3 +150,98 @@ def test_counted_waits_equal_wait_for_everything():
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0
     assert "FUSED_CHECK_OK" in r.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 4: the FEAT form -- small point sets straight from the taps (split-form gather + one launch per stream)
+# ---------------------------------------------------------------------------------------------------------------
+def test_device_feat_pack_equals_the_layout_restatement(eng_store):
+    from disn_amd import ops
+    _, store = eng_store
+    scope = "sdfprediction_imgfeat"
+    w = lambda l: np.ascontiguousarray(store["%s/%s/weights" % (scope, l)][0, 0], np.float32)
+    ws = (w("fold1/conv2"), w("fold1/conv3"), w("fold2/conv1"), w("fold2/conv2"))
+    img = ops.mlp_fused_feat_pack(*[torch.from_numpy(a).cuda() for a in ws])
+    torch.cuda.synchronize()
+    raw = img.cpu().numpy()
+    ref_img, ref_meta = E.pack_image(*ws)
+    nb = E.PAIRS_FEAT * 2048
+    got_meta = raw[nb:nb + 4 * E.META].view(np.float32)
+    assert np.array_equal(got_meta[64:], ref_meta[64:])
+    np.testing.assert_allclose(got_meta[8:11], ref_meta[8:11], rtol=1e-5)
+    assert np.array_equal(raw[:nb].view(np.uint16).reshape(E.PAIRS_FEAT, 2, 64, 8), ref_img.view(np.uint16))
+
+
+def test_split_form_gather_is_the_fp32_gather_split(eng_store):
+    """disn_gather_taps_split = disn_gather_taps, then x * 2^k, h = f16(x), l = f16(x - h), [h8 | l8] per 8 channels"""
+    from disn_amd import ops
+    eng, _ = eng_store
+    rng = np.random.default_rng(5)
+    enc = eng.encode(rng.random((2, 137, 137, 3), dtype=np.float32))
+    pts = torch.from_numpy(rng.uniform(-1.2, 1.2, (2, 333, 3)).astype(np.float32)).cuda()
+    tms = torch.from_numpy(np.stack([O.DEMO_TRANS_MAT[0], O.synth_trans_mat(30, 25, 0.8)])).cuda()
+    feat = ops.gather_taps(enc.taps, tms, pts).cpu().numpy()
+    amax = torch.stack([torch.stack([t[b].abs().max() for t in enc.taps]).max() for b in range(2)]).contiguous()
+    got = ops.gather_taps_split(enc.taps, tms, pts, amax).cpu().numpy()
+    for b in range(2):
+        ref = E.split_rows(feat[b], float(amax[b]))
+        assert np.array_equal(got[b], ref), "image %d" % b
+    # a bound above the true maximum only moves the power of two
+    got2 = ops.gather_taps_split(enc.taps, tms, pts, (amax * 3.0).contiguous()).cpu().numpy()
+    assert np.array_equal(got2[1], E.split_rows(feat[1], float(amax[1]) * 3.0))
+
+
+def _oracle_taps(store, enc, pts, tms):
+    fm = np.concatenate([O.resize_bilinear_legacy(t.cpu().numpy(), 137, 137) for t in enc.taps], axis=3)
+    xy = O.get_img_points(pts, tms)
+    feat = O.resampler(fm, xy)[:, :, None, :]
+    return (O.get_sdf_basic2(pts, enc.embedding.cpu().numpy(), store.arrays, dtype=np.float64)
+            + O.get_sdf_basic2_imgfeat_twostream(pts, feat, store.arrays, dtype=np.float64))[..., 0]
+
+
+@pytest.mark.parametrize("B,N", [(1, 128), (2, 256), (3, 1152), (4, 2048), (16, 2048)])
+def test_query_taps_fused_vs_float64_oracle(eng_store, B, N):
+    from disn_amd import ops
+    eng, store = eng_store
+    rng = np.random.default_rng(B * 13 + N)
+    imgs = rng.random((B, 137, 137, 3), dtype=np.float32) * rng.uniform(0.3, 1.0, (B, 1, 1, 1)).astype(np.float32)
+    pts = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    tms = np.stack([O.DEMO_TRANS_MAT[0] if b % 2 == 0 else O.synth_trans_mat(30 + 20 * b, 25, 0.8) for b in range(B)])
+    enc = eng.encode(imgs)
+    dp, dt = torch.from_numpy(pts).cuda(), torch.from_numpy(tms).cuda()
+    f = ops.query_taps_fused(eng.weights.mlp, enc.taps, enc.embedding, dt, dp)
+    f2 = ops.query_taps_fused(eng.weights.mlp, enc.taps, enc.embedding, dt, dp)
+    torch.cuda.synchronize()
+    assert torch.equal(f, f2), "the fused small-set kernels are not bit-reproducible"
+    nb = min(B, 3)                                     # the oracle on the first images (137 x 137 x 1472 maps on the CPU)
+    sub = type(enc)(enc.resized[:nb], [t[:nb] for t in enc.taps], enc.embedding[:nb], None)
+    ref = _oracle_taps(store, sub, pts[:nb], tms[:nb])
+    ef = report_close("fused small-set vs float64", f[:nb].cpu().numpy(), ref, 1e-5)
+    u = eng.query(enc, dp, dt, fold=False, fused=False)            # the layer-by-layer path on the materialised map
+    d = float((f - u).abs().max())
+    print("B=%d N=%d: |fused small - f64| %.3g, |fused small - layer by layer| %.3g (|pred| max %.3g)" % (
+        B, N, ef, d, float(np.abs(ref).max())))
+    assert d <= 1e-5
+    # an image's bits do not depend on its companions or its position in the call
+    if B >= 2:
+        one = ops.query_taps_fused(eng.weights.mlp, [t[B - 1:B].contiguous() for t in enc.taps],
+                                   enc.embedding[B - 1:B].contiguous(), dt[B - 1:B].contiguous(), dp[B - 1:B].contiguous())
+        assert torch.equal(one[0], f[B - 1])
+
+
+@pytest.mark.parametrize("B,N", [(4, 2048), (6, 640)])
+def test_batched_encode_query_runs_the_fused_small_set_kernels(eng_store, B, N):
+    """disn_encode_query of >= 4 images (N % 128 == 0) = disn_encode + disn_query_taps_fused, bit for bit: the split
+    scale comes from the convolutions' epilogue maxima there and from a pass over the taps here -- the same numbers"""
+    from disn_amd import ops
+    eng, _ = eng_store
+    rng = np.random.default_rng(B + N)
+    imgs = torch.from_numpy(rng.random((B, 137, 137, 3), dtype=np.float32)).cuda()
+    pts = torch.from_numpy(rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)).cuda()
+    tms = torch.from_numpy(np.repeat(O.DEMO_TRANS_MAT, B, axis=0)).cuda()
+    enc, pred = eng.encode_query(imgs, pts, tms)
+    enc2 = eng.encode(imgs)
+    for a, b in zip(enc.taps, enc2.taps):
+        assert torch.equal(a, b)
+    q = ops.query_taps_fused(eng.weights.mlp, enc2.taps, enc2.embedding, tms, pts)
+    assert torch.equal(pred, q), float((pred - q).abs().max())

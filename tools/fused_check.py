@@ -46,6 +46,27 @@ def main():
                 bad += 1
                 print("n=%d rep=%d: %d of %d values differ, max |d| %.3g" % (n, rep, nd, n, float((got - ref).abs().max())))
         print("n=%d ok" % n, flush=True)
+    # the FEAT form (small point sets from the taps: disn_query_taps_fused), several images per launch
+    imgs = rng.random((4, 137, 137, 3), dtype=np.float32)
+    enc4 = eng.encode(imgs)
+    tms = torch.from_numpy(np.repeat(O.DEMO_TRANS_MAT, 4, axis=0)).cuda()
+    from disn_amd import ops
+    for n in (128, 2048, 8192):
+        pts = torch.from_numpy(rng.uniform(-1, 1, (4, n, 3)).astype(np.float32)).cuda()
+        assert setk(4, 1) == 0
+        ref = ops.query_taps_fused(eng.weights.mlp, enc4.taps, enc4.embedding, tms, pts).clone()
+        assert setk(4, 0) == 0
+        for rep in range(6):
+            if rep >= 3:
+                with torch.cuda.stream(side):
+                    noise.add_(1)
+            got = ops.query_taps_fused(eng.weights.mlp, enc4.taps, enc4.embedding, tms, pts)
+            torch.cuda.synchronize()
+            nd = int((got != ref).sum())
+            if nd:
+                bad += 1
+                print("feat form n=%d rep=%d: %d values differ, max |d| %.3g" % (n, rep, nd, float((got - ref).abs().max())))
+        print("feat form n=4x%d ok" % n, flush=True)
     assert torch.isfinite(ref).all()
     if bad:
         print("FUSED_CHECK_FAILED")
