@@ -66,11 +66,21 @@ constexpr int kFeatBlocks = 96, kFeatCols = 16 * kFeatBlocks, kFeatReal = 1472; 
 constexpr int kPairsA2 = 96;
 constexpr int kPairsFeat = kPairs + 16 * kPairsA2;              // 2592
 constexpr size_t kImageBytesFeat = (size_t)kPairsFeat * 2048;   // 5 308 416
-// meta (behind the image): floats [8] max_f ||W4[:,f]||_1; [9] max_f ||W3[:,f]||_1; from float 64 on the inverse
-// weight scales PER OUTPUT FEATURE (round 4; as conv_h2.hip's per-column scales): isw2[256], isw3[512], isw4[512],
-// isw5[256] -- layer l's feature f is packed as W[:, f] * s, s = the power of two that puts max |W[:, f]| into
-// [2^13, 2^14), and its accumulator is multiplied by 1 / s next to the bias
+// EQUALISED hidden features (round 4).  The kernel's hidden activations never leave it, so every hidden feature f of
+// layer l may carry its own power-of-two factor c_l[f]: the image holds W~_l = diag(1 / c_{l-1}) W_l diag(c_l) (c_1 = 1:
+// fold1/conv1 is not an MFMA layer), the kernel adds b_l c_l, scales the folded map's rows / the per-image bias row by
+// c_4 and divides w6 by c_5 -- ReLU commutes with a positive factor, powers of two are exact, the stream's sum is
+// unchanged.  c_l[f] = 2^-e(max_k |W_l[k, f]| / c_{l-1}[k]): every column of W~ has its largest entry in [1, 2), one
+// weight scale 2^13 serves all, and -- the point -- the column 1-norms behind the activation-scale BOUNDS (conv3 and
+// fold2/conv1 outputs are consumed tile by tile, their scales come from |h| <= max |h_prev| max_f ||W~[:, f]||_1 + ...)
+// are those of a normalised network whatever gains training left in the channels.  With the raw weights a trained-like
+// set (oracle trained_like_weights: log-normal channel gains, 1 % outliers x 1000) has column 1-norms 10^4 above the
+// typical one; two such bounds compound to 2^-33 of the f16 range and the result is noise (max error 12 on |pred| 100
+// in tests/fused_emulation.py; 1e-6 with the equalisation).
+// meta (behind the image): floats [8] max_f ||W~4_point[:,f]||_1; [9] max_f ||W~3[:,f]||_1; [10] the same of the feature
+// rows of fold2/conv1 (FEAT form); [11] max_f c_4[f]; from float 64 on c_2[256], c_3[512], c_4[512], c_5[256]
 constexpr int mS2 = 64, mS3 = mS2 + 256, mS4 = mS3 + 512, mS5 = mS4 + 512, kMetaFloats = mS5 + 256;
+constexpr float kInvSw = 1.0f / 8192.0f;   // every column of W~ is packed with the scale 2^13
 // constants of one stream in LDS (floats)
 constexpr int cW1 = 0, cB1 = 192, cB2 = 256, cB3 = 512, cB4 = 1024, cB5 = 1536, cW6 = 1792, cB6 = 2048;
 constexpr int cS2 = 2052, cS3 = cS2 + 256, cS4 = cS3 + 512, cS5 = cS4 + 512;
@@ -89,55 +99,56 @@ __device__ __forceinline__ float pow2_scale_for(float amax, int target_exp) {
 
 // one workgroup per layer: per-feature (column) amax -> inverse scale; conv3 and fold2/conv1 (point rows) also the
 // largest column 1-norm
-// k4: rows of w4 -- 512 (the point rows) or 1984 (FEAT form: + the 1472 feature rows, whose largest column 1-norm
-// goes to meta[10])
+// k4: rows of w4 -- 512 (the point rows) or 1984 (FEAT form: + the 1472 feature rows; their input is not a hidden
+// feature: no row factor).  ONE workgroup: the layers in order, layer l's row factors are layer l-1's column factors.
+__host__ __device__ inline int fm_meta_off(int layer) {
+  return layer == 0 ? fm::mS2 : (layer == 1 ? fm::mS3 : (layer == 2 ? fm::mS4 : fm::mS5));
+}
 __global__ __launch_bounds__(256) void fm_meta_kernel(const float* __restrict__ w2, const float* __restrict__ w3,
                                                       const float* __restrict__ w4, const float* __restrict__ w5,
                                                       float* __restrict__ meta, int k4) {
   __shared__ float red[256];
-  const int layer = blockIdx.x;
-  const float* w = layer == 0 ? w2 : (layer == 1 ? w3 : (layer == 2 ? w4 : w5));
-  const int Kall = layer == 0 ? 64 : (layer == 1 ? 256 : (layer == 2 ? k4 : 512));
-  const int K = layer == 0 ? 64 : (layer == 1 ? 256 : 512);     // rows of the point part (the 1-norm bound below)
-  const int N = layer == 0 ? 256 : (layer == 3 ? 256 : 512);
-  {
-    float* isw = meta + (layer == 0 ? fm::mS2 : (layer == 1 ? fm::mS3 : (layer == 2 ? fm::mS4 : fm::mS5)));
+  __shared__ float rrow[512];   // 1 / c_{l-1}[k] of the hidden input features (1 for layer 0)
+  for (int i = threadIdx.x; i < 512; i += 256) rrow[i] = 1.0f;
+  if (threadIdx.x < 16) meta[threadIdx.x] = 0.f;
+  __syncthreads();
+  for (int layer = 0; layer < 4; ++layer) {
+    const float* w = layer == 0 ? w2 : (layer == 1 ? w3 : (layer == 2 ? w4 : w5));
+    const int Kall = layer == 0 ? 64 : (layer == 1 ? 256 : (layer == 2 ? k4 : 512));
+    const int K = layer == 0 ? 64 : (layer == 1 ? 256 : 512);     // hidden input features (rows with a factor)
+    const int N = layer == 0 ? 256 : (layer == 3 ? 256 : 512);
+    float* c = meta + fm_meta_off(layer);
+    float l1p = 0.f, l1f = 0.f, cmax = 0.f;
     for (int f = threadIdx.x; f < N; f += 256) {
       float m = 0.f;
-      for (int k = 0; k < Kall; ++k) m = fmaxf(m, fabsf(w[(size_t)k * N + f]));
-      isw[f] = 1.0f / pow2_scale_for(m, 13);
+      for (int k = 0; k < Kall; ++k) m = fmaxf(m, fabsf(w[(size_t)k * N + f]) * (k < K ? rrow[k] : 1.0f));
+      const float cf = pow2_scale_for(m, 0);   // m cf in [1, 2); 1 for an all-zero column
+      c[f] = cf;
+      cmax = fmaxf(cmax, cf);
+      float a = 0.f, af = 0.f;
+      for (int k = 0; k < K; ++k) a += fabsf(w[(size_t)k * N + f]) * rrow[k];
+      for (int k = K; k < Kall; ++k) af += fabsf(w[(size_t)k * N + f]);
+      l1p = fmaxf(l1p, a * cf);
+      l1f = fmaxf(l1f, af * cf);
     }
-  }
-  if (layer == 1 || layer == 2) {
-    float c = 0.f;
-    for (int f = threadIdx.x; f < N; f += 256) {
-      float a = 0.f;
-      for (int k = 0; k < K; ++k) a += fabsf(w[(size_t)k * N + f]);
-      c = fmaxf(c, a);
-    }
-    red[threadIdx.x] = c;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    for (int q = 0; q < 3; ++q) {   // workgroup maxima of the two 1-norms and of c
       __syncthreads();
-    }
-    if (threadIdx.x == 0) meta[layer == 2 ? 8 : 9] = red[0] * 1.0001f;  // summation-order slack: the bound must hold
-    if (layer == 2 && k4 > 512) {   // the feature rows' largest column 1-norm
-      __syncthreads();
-      c = 0.f;
-      for (int f = threadIdx.x; f < N; f += 256) {
-        float a = 0.f;
-        for (int k = 512; k < k4; ++k) a += fabsf(w[(size_t)k * N + f]);
-        c = fmaxf(c, a);
-      }
-      red[threadIdx.x] = c;
+      red[threadIdx.x] = q == 0 ? l1p : (q == 1 ? l1f : cmax);
       __syncthreads();
       for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
         __syncthreads();
       }
-      if (threadIdx.x == 0) meta[10] = red[0] * 1.0001f;
+      if (threadIdx.x == 0) {   // summation-order slack on the 1-norms: the bounds must hold
+        if (q == 0 && layer == 1) meta[9] = red[0] * 1.0001f;
+        if (q == 0 && layer == 2) meta[8] = red[0] * 1.0001f;
+        if (q == 1 && layer == 2) meta[10] = red[0] * 1.0001f;
+        if (q == 2 && layer == 2) meta[11] = red[0];
+      }
     }
+    __syncthreads();
+    for (int f = threadIdx.x; f < N; f += 256) rrow[f] = 1.0f / c[f];   // the next layer's row factors
+    __syncthreads();
   }
 }
 
@@ -180,12 +191,14 @@ __global__ __launch_bounds__(256) void fm_pack_kernel(const float* __restrict__ 
   const float* w = layer == 0 ? w2 : (layer == 1 ? w3 : (layer == 2 ? w4 : w5));
   const int N = layer == 0 ? 256 : (layer == 3 ? 256 : 512);
   const int i = lane & 31, g = lane >> 5;
-  const float s = 1.0f / meta[(layer == 0 ? fm::mS2 : (layer == 1 ? fm::mS3 : (layer == 2 ? fm::mS4 : fm::mS5))) + 32 * nt + i];
+  const float s = meta[fm_meta_off(layer) + 32 * nt + i] * 8192.0f;   // c_l[f] 2^13
   h8 hi, lo;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const int k = (layer == 2 && kb >= 32) ? 16 * kb + 8 * g + t : 16 * kb + (t & 3) + 8 * (t >> 2) + 4 * g;  // phi(kb, g, t)
-    const float v = (layer == 2 && k >= k4) ? 0.f : w[(size_t)k * N + 32 * nt + i] * s;
+    // row factor 1 / c_{l-1}[k] of a hidden input feature (layer 0's input and the gathered features have none)
+    const float rk = (layer == 0 || k >= 512) ? 1.0f : 1.0f / meta[fm_meta_off(layer - 1) + k];
+    const float v = (layer == 2 && k >= k4) ? 0.f : w[(size_t)k * N + 32 * nt + i] * rk * s;
     const _Float16 h = (_Float16)v;
     hi[t] = h;
     lo[t] = (_Float16)(v - (float)h);
@@ -201,7 +214,7 @@ size_t mlp_fused_feat_image_bytes() { return fm::kImageBytesFeat + fm::kMetaFloa
 hipError_t mlp_fused_pack_launch(const float* w2, const float* w3, const float* w4_point, const float* w5,
                                  void* image, hipStream_t st) {
   float* meta = reinterpret_cast<float*>(static_cast<char*>(image) + fm::kImageBytes);
-  hipLaunchKernelGGL(fm_meta_kernel, dim3(4), dim3(256), 0, st, w2, w3, w4_point, w5, meta, 512);
+  hipLaunchKernelGGL(fm_meta_kernel, dim3(1), dim3(256), 0, st, w2, w3, w4_point, w5, meta, 512);
   hipLaunchKernelGGL(fm_pack_kernel, dim3((fm::kPairs * 64 + 255) / 256), dim3(256), 0, st, w2, w3, w4_point, w5,
                      meta, reinterpret_cast<_Float16*>(image), 512);
   return hipGetLastError();
@@ -210,7 +223,7 @@ hipError_t mlp_fused_pack_launch(const float* w2, const float* w3, const float* 
 hipError_t mlp_fused_feat_pack_launch(const float* w2, const float* w3, const float* w4, const float* w5, void* image,
                                       hipStream_t st) {
   float* meta = reinterpret_cast<float*>(static_cast<char*>(image) + fm::kImageBytesFeat);
-  hipLaunchKernelGGL(fm_meta_kernel, dim3(4), dim3(256), 0, st, w2, w3, w4, w5, meta, 512 + fm::kFeatReal);
+  hipLaunchKernelGGL(fm_meta_kernel, dim3(1), dim3(256), 0, st, w2, w3, w4, w5, meta, 512 + fm::kFeatReal);
   hipLaunchKernelGGL(fm_pack_kernel, dim3((fm::kPairsFeat * 64 + 255) / 256), dim3(256), 0, st, w2, w3, w4, w5, meta,
                      reinterpret_cast<_Float16*>(image), 512 + fm::kFeatReal);
   return hipGetLastError();
@@ -487,16 +500,14 @@ __device__ __forceinline__ int fm_exp_of(float m) {
 // bias + ReLU + scale + two-term split of one output tile -> the two reduction blocks it becomes
 template <bool GATHER>
 __device__ __forceinline__ void fm_tile_to_frags(const f32x16& acc, const float* bias32 /* LDS, + 4g applied */,
-                                                 const float* isw32 /* LDS, + 4g applied: 1 / weight scale per feature */,
+                                                 const float* c32 /* LDS, + 4g applied: c_4 of the tile's features (GATHER) */,
                                                  const unsigned char* grows /* LDS: 16 pieces, + 16 lane applied */,
                                                  const float (&wt)[4], float inv, float s, h8 (&fh)[2],
                                                  h8 (&fl)[2]) {
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
     const float4 bb = *reinterpret_cast<const float4*>(bias32 + 8 * rq);
-    const float4 ss = *reinterpret_cast<const float4*>(isw32 + 8 * rq);
     float b4[4] = {bb.x, bb.y, bb.z, bb.w};
-    const float i4[4] = {ss.x * inv, ss.y * inv, ss.z * inv, ss.w * inv};   // exact: powers of two
     if (GATHER) {  // + the four resampled pmap rows (sample4's summation order: ff, cc, fc, cf)
       float gs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -507,13 +518,16 @@ __device__ __forceinline__ void fm_tile_to_frags(const f32x16& acc, const float*
         gs[2] = fmaf(wt[tp], v.z, gs[2]);
         gs[3] = fmaf(wt[tp], v.w, gs[3]);
       }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) b4[c] += gs[c];
+      const float4 cc = *reinterpret_cast<const float4*>(c32 + 8 * rq);   // the equalised feature: pmap row f times c_4[f]
+      b4[0] = fmaf(gs[0], cc.x, b4[0]);
+      b4[1] = fmaf(gs[1], cc.y, b4[1]);
+      b4[2] = fmaf(gs[2], cc.z, b4[2]);
+      b4[3] = fmaf(gs[3], cc.w, b4[3]);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int r = 4 * rq + c;
-      const float v = fmaxf(fmaf(acc[r], i4[c], b4[c]), 0.f) * s;
+      const float v = fmaxf(fmaf(acc[r], inv, b4[c]), 0.f) * s;
       const _Float16 h = (_Float16)v;
       fh[r >> 3][r & 7] = h;
       fl[r >> 3][r & 7] = (_Float16)(v - (float)h);
@@ -557,17 +571,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
   // ---- constants -> LDS -------------------------------------------------------------------------------
   for (int i = tid; i < 192; i += 256) cst[fm::cW1 + i] = P.w1[i];
   if (tid < 64) cst[fm::cB1 + tid] = P.b1[tid];
-  cst[fm::cB2 + tid] = P.b2[tid];
+  // (the equalised form: bias_l c_l, w6 / c_5; the c_4 row stays in LDS for the folded map's rows)
+  cst[fm::cB2 + tid] = P.b2[tid] * meta[fm::mS2 + tid];
   for (int i = tid; i < 512; i += 256) {
-    cst[fm::cB3 + i] = P.b3[i];
-    cst[fm::cB4 + i] = P.b4[i];
+    cst[fm::cB3 + i] = P.b3[i] * meta[fm::mS3 + i];
+    cst[fm::cB4 + i] = P.b4[i] * meta[fm::mS4 + i];
+    cst[fm::cS4 + i] = meta[fm::mS4 + i];
   }
-  cst[fm::cB5 + tid] = P.b5[tid];
-  cst[fm::cW6 + tid] = P.w6[tid];
+  cst[fm::cB5 + tid] = P.b5[tid] * meta[fm::mS5 + tid];
+  cst[fm::cW6 + tid] = P.w6[tid] / meta[fm::mS5 + tid];
   if (tid == 0) cst[fm::cB6] = P.b6[0];
-  for (int i = tid; i < fm::kMetaFloats - fm::mS2; i += 256) cst[fm::cS2 + i] = meta[fm::mS2 + i];  // isw2 | isw3 | isw4 | isw5
   const float cw4 = meta[8], cw3 = meta[9], cw4f = FEAT ? meta[10] : 0.f;
-  float addmax4 = (LOCAL && !FEAT) ? P.pmap_amax[0] : 0.f, addmax3 = 0.f;
+  // |pmap row f| c_4[f] <= max |pmap| max c_4
+  float addmax4 = (LOCAL && !FEAT) ? P.pmap_amax[0] * meta[11] : 0.f, addmax3 = 0.f;
   float T[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) T[i] = (LOCAL && !FEAT) ? P.T[i] : 0.f;
@@ -691,7 +707,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
       const int img = P.rows_per_image > 0 ? (int)((tile * 128) / P.rows_per_image) : 0;
       if (!LOCAL) {  // the global stream's folded bias row of this image (and the bound's additive term)
         __syncthreads();
-        for (int i = tid; i < 512; i += 256) cst[fm::cB4 + i] = P.b4[(size_t)img * 512 + i];
+        for (int i = tid; i < 512; i += 256) cst[fm::cB4 + i] = P.b4[(size_t)img * 512 + i] * cst[fm::cS4 + i];
         __syncthreads();
         float m4 = 0.f;
 #pragma unroll
@@ -762,7 +778,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
       m = fmaxf(m, __shfl_xor(m, 32));
       const int e = fm_exp_of(m);
       const float s = fm_exp2i(14 - e);
-      inv2 = fm_exp2i(e - 14);
+      inv2 = fm_exp2i(e - 14) * fm::kInvSw;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -793,12 +809,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           const float4 bb = *reinterpret_cast<const float4*>(&cst[fm::cB2 + 32 * nt + 8 * rq + 4 * g]);
-          const float4 ss = *reinterpret_cast<const float4*>(&cst[fm::cS2 + 32 * nt + 8 * rq + 4 * g]);
           const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
-          const float s4v[4] = {ss.x * inv2, ss.y * inv2, ss.z * inv2, ss.w * inv2};   // exact: powers of two
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float v = fmaxf(fmaf(z2[nt][4 * rq + c], s4v[c], b4[c]), 0.f);
+            const float v = fmaxf(fmaf(z2[nt][4 * rq + c], inv2, b4[c]), 0.f);
             z2[nt][4 * rq + c] = v;
             m = fmaxf(m, v);
           }
@@ -807,16 +821,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
       m = fmaxf(m, __shfl_xor(m, 32));
       const int e2 = fm_exp_of(m);
       const float s2 = fm_exp2i(14 - e2);
-      inv3 = fm_exp2i(e2 - 14);
+      inv3 = fm_exp2i(e2 - 14) * fm::kInvSw;
       // conv3's and fold2/conv1's outputs are consumed tile by tile: scales from the bounds
       //   |h3| <= max|h2| * max_f ||W3[:,f]||_1 + max|b3|,   |h4| <= that * max_f ||W4[:,f]||_1 + max|additive term|
       const float bound3 = fmaf(m, cw3, addmax3);
       const int e3 = fm_exp_of(bound3);
       s3 = fm_exp2i(14 - e3);
-      inv4 = fm_exp2i(e3 - 14);
+      inv4 = fm_exp2i(e3 - 14) * fm::kInvSw;
       const int e4 = fm_exp_of(fmaf(bound3, cw4, addmax4));
       s4 = fm_exp2i(14 - e4);
-      inv5 = fm_exp2i(e4 - 14);
+      inv5 = fm_exp2i(e4 - 14) * fm::kInvSw;
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
@@ -865,7 +879,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
         acc4[i] = acc4[i] * rs;
         FM_SETTLE_IN1("a", acc4[i]);
       }
-      inv4 = inv_sfeat;
+      inv4 = inv_sfeat * fm::kInvSw;
 #pragma unroll 1
       for (int it2 = 0; it2 < 16; ++it2) {
         h8 fh6[6], fl6[6];
@@ -913,11 +927,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
           const int f0 = 32 * nt + 8 * rq + 4 * g;
           const float4 bb = *reinterpret_cast<const float4*>(&cst[fm::cB5 + f0]);
           const float4 ww = *reinterpret_cast<const float4*>(&cst[fm::cW6 + f0]);
-          const float4 ss = *reinterpret_cast<const float4*>(&cst[fm::cS5 + f0]);
-          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 0], ss.x * inv5, bb.x), 0.f), ww.x, dot);
-          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 1], ss.y * inv5, bb.y), 0.f), ww.y, dot);
-          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 2], ss.z * inv5, bb.z), 0.f), ww.z, dot);
-          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 3], ss.w * inv5, bb.w), 0.f), ww.w, dot);
+          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 0], inv5, bb.x), 0.f), ww.x, dot);
+          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 1], inv5, bb.y), 0.f), ww.y, dot);
+          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 2], inv5, bb.z), 0.f), ww.z, dot);
+          dot = fmaf(fmaxf(fmaf(acc5[nt][4 * rq + 3], inv5, bb.w), 0.f), ww.w, dot);
         }
       }
       dot += __shfl_xor(dot, 32);

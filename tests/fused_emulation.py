@@ -70,20 +70,36 @@ META = 64 + 256 + 512 + 512 + 256
 
 
 def pack_image(w2, w3, w4p, w5):
-    """-> (image [PAIRS, 2, 64, 8] float16, meta float32[META]) exactly as fm_meta_kernel + fm_pack_kernel: meta[8],
-    meta[9] the column 1-norm bounds, from float 64 on the inverse weight scales per output feature (isw2[256],
-    isw3[512], isw4[512], isw5[256])"""
+    """-> (image [PAIRS, 2, 64, 8] float16, meta float32[META]) exactly as fm_meta_kernel + fm_pack_kernel.
+    EQUALISED hidden features: layer l's feature f carries the power-of-two factor c_l[f] = 2^-e(max_k |W_l[k, f]| /
+    c_{l-1}[k]) (c_1 = 1; the gathered feature rows of the FEAT form have no row factor): the image holds
+    W~_l = diag(1 / c_{l-1}) W_l diag(c_l) 2^13.  meta[8] / [9] / [10]: the largest column 1-norms of W~4's point rows /
+    W~3 / W~4's feature rows (the bounds), meta[11] = max c_4, from float 64 on c_2[256], c_3[512], c_4[512], c_5[256]"""
     ws = [np.asarray(w, np.float32) for w in (w2, w3, w4p, w5)]
     feat = ws[2].shape[0] > 512              # the FEAT image: w4p is the whole [512 + 1472][512] matrix
     meta = np.zeros(META, np.float32)
+    rrow = np.ones(512, np.float32)
+    wt = []
     for i, w in enumerate(ws):
-        s = np.array([pow2_scale_for(float(m), 13) for m in np.abs(w).max(axis=0)], np.float32)
-        meta[ISW_OFF[i]:ISW_OFF[i] + w.shape[1]] = np.float32(1.0) / s
-    meta[8] = np.float32(np.abs(ws[2][:512]).sum(axis=0, dtype=np.float32).max() * np.float32(1.0001))
+        K = min(w.shape[0], 512) if i == 2 else w.shape[0]          # rows that are hidden features
+        r = np.ones(w.shape[0], np.float32)
+        r[:K] = rrow[:K]
+        wr = (w * r[:, None]).astype(np.float32)
+        c = np.array([pow2_scale_for(float(m), 0) for m in np.abs(wr).max(axis=0)], np.float32)
+        meta[ISW_OFF[i]:ISW_OFF[i] + w.shape[1]] = c
+        l1p = (np.abs(wr[:K]).sum(axis=0, dtype=np.float32) * c).max()
+        if i == 1:
+            meta[9] = np.float32(l1p * np.float32(1.0001))
+        if i == 2:
+            meta[8] = np.float32(l1p * np.float32(1.0001))
+            meta[11] = c.max()
+            if feat:
+                meta[10] = np.float32((np.abs(wr[K:]).sum(axis=0, dtype=np.float32) * c).max() * np.float32(1.0001))
+        wt.append((wr * c[None, :] * np.float32(8192.0)).astype(np.float32))
+        rrow = np.ones(512, np.float32)
+        rrow[:w.shape[1]] = np.float32(1.0) / c
     if feat:
-        meta[10] = np.float32(np.abs(ws[2][512:]).sum(axis=0, dtype=np.float32).max() * np.float32(1.0001))
-        ws[2] = np.concatenate([ws[2], np.zeros((512 + FEAT_COLS - ws[2].shape[0], 512), np.float32)])
-    meta[9] = np.float32(np.abs(ws[1]).sum(axis=0, dtype=np.float32).max() * np.float32(1.0001))
+        wt[2] = np.concatenate([wt[2], np.zeros((512 + FEAT_COLS - wt[2].shape[0], 512), np.float32)])
     npairs = PAIRS_FEAT if feat else PAIRS
     img = np.zeros((npairs, 2, 64, 8), np.float16)
     lane = np.arange(64)
@@ -91,12 +107,11 @@ def pack_image(w2, w3, w4p, w5):
     t = np.arange(8)
     for p in range(npairs):
         layer, nt, kb = pair_coords(p, feat)
-        w = ws[layer]
+        w = wt[layer]
         k = phi(kb, g[:, None], t[None, :])                       # [64, 8]
         if layer == 2 and kb >= 32:                               # feature blocks: natural slot order
             k = 16 * kb + 8 * g[:, None] + t[None, :]
-        v = w[k, (32 * nt + i)[:, None]] * (np.float32(1.0) / meta[ISW_OFF[layer] + 32 * nt + i])[:, None]
-        img[p, 0], img[p, 1] = split16(v)
+        img[p, 0], img[p, 1] = split16(w[k, (32 * nt + i)[:, None]])
     return img, meta
 
 
@@ -146,13 +161,18 @@ def fused_stream(img, meta, consts, pts, add4=None, feat_rows=None, featmax=None
     lane = np.arange(64)
     j, g = lane & 31, lane >> 5
     f32 = np.float32
-    isw = [meta[o:o + n] for o, n in zip(ISW_OFF, (256, 512, 512, 256))]     # per output feature
+    c2, c3, c4, c5 = [meta[o:o + n] for o, n in zip(ISW_OFF, (256, 512, 512, 256))]     # the equalisation factors
+    inv_sw = f32(1.0 / 8192.0)
+    b2, b3, b4, b5 = consts["b2"] * c2, consts["b3"] * c3, consts["b4"] * c4, consts["b5"] * c5
+    w6 = (consts["w6"] / c5).astype(f32)
+    if add4 is not None:
+        add4 = (add4 * c4[None, :]).astype(f32)
     cw4, cw3 = meta[8], meta[9]
-    addmax4 = np.float32(consts["addmax4"])
+    addmax4 = np.float32(np.float32(consts.get("add4max", 0.0)) * meta[11] + np.float32(np.abs(b4).max()))
     if featf:
         fmax = np.float32(max(float(featmax), 2.0 ** -20))
         sfeat = feat_split_scale(featmax)
-        addmax4 = np.float32(fmax * meta[10] + np.float32(np.abs(consts["b4"]).max()))
+        addmax4 = np.float32(fmax * meta[10] + np.float32(np.abs(b4).max()))
     x, y, z = (pts[j, c].astype(f32) for c in range(3))
     t = np.arange(8)
     r16 = np.arange(16)
@@ -168,7 +188,7 @@ def fused_stream(img, meta, consts, pts, add4=None, feat_rows=None, featmax=None
     m = np.maximum(m, m[lane ^ 32])
     e = exp_of(m)
     s = (2.0 ** (14 - e)).astype(f32)
-    inv2 = (2.0 ** (e - 14)).astype(f32)
+    inv2 = (2.0 ** (e - 14)).astype(f32) * inv_sw
     x1 = [split16(e1[kb] * s[:, None]) for kb in range(4)]
 
     p = 0   # stream position
@@ -188,26 +208,26 @@ def fused_stream(img, meta, consts, pts, add4=None, feat_rows=None, featmax=None
             assert pair_coords(p, featf) == (0, nt, kb)
             z2[nt] = pair(z2[nt], *x1[kb])
     for nt in range(8):
-        z2[nt] = np.maximum(z2[nt] * (inv2[:, None] * isw[0][feat_of_reg(nt)]) + consts["b2"][feat_of_reg(nt)], 0)
+        z2[nt] = np.maximum(z2[nt] * inv2[:, None] + b2[feat_of_reg(nt)], 0)
     m = z2.max(axis=(0, 2))
     m = np.maximum(m, m[lane ^ 32])
     e2 = exp_of(m)
     s2 = (2.0 ** (14 - e2)).astype(f32)
-    inv3 = (2.0 ** (e2 - 14)).astype(f32)
-    bound3 = (m * cw3 + np.abs(consts["b3"]).max()).astype(f32)
+    inv3 = (2.0 ** (e2 - 14)).astype(f32) * inv_sw
+    bound3 = (m * cw3 + np.abs(b3).max()).astype(f32)
     e3 = exp_of(bound3)
     s3 = (2.0 ** (14 - e3)).astype(f32)
-    inv4 = (2.0 ** (e3 - 14)).astype(f32)
+    inv4 = (2.0 ** (e3 - 14)).astype(f32) * inv_sw
     e4 = exp_of((bound3 * cw4 + addmax4).astype(f32))
     s4 = (2.0 ** (14 - e4)).astype(f32)
-    inv5 = (2.0 ** (e4 - 14)).astype(f32)
+    inv5 = (2.0 ** (e4 - 14)).astype(f32) * inv_sw
     x2 = []
     for nt in range(8):
         for hf in range(2):
             x2.append(split16(z2[nt][:, 8 * hf:8 * hf + 8] * s2[:, None]))
 
-    def tile_to_frags(acc, bias, inv, sc, nt, add=None, layer=1):
-        v = acc * (inv[:, None] * isw[layer][feat_of_reg(nt)]) + bias[feat_of_reg(nt)]
+    def tile_to_frags(acc, bias, inv, sc, nt, add=None):
+        v = acc * inv[:, None] + bias[feat_of_reg(nt)]
         if add is not None:
             v = v + add[j[:, None], feat_of_reg(nt)]
         v = (np.maximum(v, 0) * sc[:, None]).astype(f32)
@@ -221,14 +241,14 @@ def fused_stream(img, meta, consts, pts, add4=None, feat_rows=None, featmax=None
         for kb in range(16):
             assert pair_coords(p, featf) == (1, it, kb)
             acc = pair(acc, *x2[kb])
-        fr = tile_to_frags(acc, consts["b3"], inv3, s3, it)
+        fr = tile_to_frags(acc, b3, inv3, s3, it)
         for r in range(32):
             assert pair_coords(p, featf) == (2, r & 15, 2 * it + (r >> 4))
             acc4[r & 15] = pair(acc4[r & 15], *fr[r >> 4])
     # phase A2 (FEAT): one exact rescale s_feat / s3 per point, then the 96 feature blocks from the split rows
     if featf:
         acc4 = acc4 * (sfeat / s3)[None, :, None]
-        inv4 = np.full(64, f32(1.0) / sfeat, f32)
+        inv4 = np.full(64, f32(1.0) / sfeat * inv_sw, f32)
         rows16 = feat_rows.view(np.float16).reshape(32, FEAT_COLS // 8, 2, 8)
         for it2 in range(16):
             fr6 = []
@@ -242,14 +262,14 @@ def fused_stream(img, meta, consts, pts, add4=None, feat_rows=None, featmax=None
     # phase B
     acc5 = np.zeros((8, 64, 16), f32)
     for it in range(16):
-        fr = tile_to_frags(acc4[it], consts["b4"], inv4, s4, it, add4, layer=2)
+        fr = tile_to_frags(acc4[it], b4, inv4, s4, it, add4)
         for r in range(16):
             assert pair_coords(p, featf) == (3, r & 7, 2 * it + (r >> 3))
             acc5[r & 7] = pair(acc5[r & 7], *fr[r >> 3])
     assert p == npairs
     dot = np.zeros(64, f32)
     for nt in range(8):
-        h5 = np.maximum(acc5[nt] * (inv5[:, None] * isw[3][feat_of_reg(nt)]) + consts["b5"][feat_of_reg(nt)], 0)
-        dot += (h5 * consts["w6"][feat_of_reg(nt)]).sum(axis=1, dtype=f32)
+        h5 = np.maximum(acc5[nt] * inv5[:, None] + b5[feat_of_reg(nt)], 0)
+        dot += (h5 * w6[feat_of_reg(nt)]).sum(axis=1, dtype=f32)
     dot = dot + dot[lane ^ 32] + f32(consts["b6"])
     return dot[:32]

@@ -108,7 +108,7 @@ for exchange in %(exchanges)r:
         got = full[i][idx].cpu().numpy().astype(np.float64) * 10.0
         err = float(np.abs(got - gold[b]).max())
         worst = max(worst, err)
-        print("cfg4 %s image %d: max |10 gpu - f64| %.3g" % (exchange, b, err), flush=True)
+        print("cfg4 %%s image %%d: max |10 gpu - f64| %%.3g" %% (exchange, b, err), flush=True)
         assert err <= 1e-5, (exchange, b, err)
     del res, full
 print("CFG4_OK rank %%d of %%d worst %%.3g" %% (rank, world, worst), flush=True)

@@ -169,6 +169,7 @@ def test_device_feat_pack_equals_the_layout_restatement(eng_store):
     got_meta = raw[nb:nb + 4 * E.META].view(np.float32)
     assert np.array_equal(got_meta[64:], ref_meta[64:])
     np.testing.assert_allclose(got_meta[8:11], ref_meta[8:11], rtol=1e-5)
+    assert got_meta[11] == ref_meta[11]
     assert np.array_equal(raw[:nb].view(np.uint16).reshape(E.PAIRS_FEAT, 2, 64, 8), ref_img.view(np.uint16))
 
 
@@ -199,7 +200,7 @@ def _oracle_taps(store, enc, pts, tms):
             + O.get_sdf_basic2_imgfeat_twostream(pts, feat, store.arrays, dtype=np.float64))[..., 0]
 
 
-@pytest.mark.parametrize("B,N", [(1, 128), (2, 256), (3, 1152), (4, 2048), (16, 2048)])
+@pytest.mark.parametrize("B,N", [(1, 128), (2, 256), (3, 1152), (4, 2048), (5, 640), (16, 2048)])
 def test_query_taps_fused_vs_float64_oracle(eng_store, B, N):
     from disn_amd import ops
     eng, store = eng_store
@@ -222,11 +223,19 @@ def test_query_taps_fused_vs_float64_oracle(eng_store, B, N):
     print("B=%d N=%d: |fused small - f64| %.3g, |fused small - layer by layer| %.3g (|pred| max %.3g)" % (
         B, N, ef, d, float(np.abs(ref).max())))
     assert d <= 1e-5
-    # an image's bits do not depend on its companions or its position in the call
-    if B >= 2:
+    # an image's bits do not depend on its companions or its position in the call -- within one FORM of the fc head:
+    # calls of < 4 images fold the global bias with the row kernels, calls of >= 4 with the split-K stream kernel
+    # (include/disn_amd.h, "WHICH KERNELS RUN"), so a single image is compared with a call of < 4 and a permuted /
+    # shortened batch with a call of >= 4
+    if 2 <= B < 4:
         one = ops.query_taps_fused(eng.weights.mlp, [t[B - 1:B].contiguous() for t in enc.taps],
                                    enc.embedding[B - 1:B].contiguous(), dt[B - 1:B].contiguous(), dp[B - 1:B].contiguous())
         assert torch.equal(one[0], f[B - 1])
+    if B >= 5:
+        perm = torch.tensor(list(range(B - 1, 0, -1)), device="cuda")          # reversed, image 0 dropped
+        g = ops.query_taps_fused(eng.weights.mlp, [t[perm].contiguous() for t in enc.taps], enc.embedding[perm].contiguous(),
+                                 dt[perm].contiguous(), dp[perm].contiguous())
+        assert torch.equal(g, f[perm])
 
 
 @pytest.mark.parametrize("B,N", [(4, 2048), (6, 640)])
