@@ -665,6 +665,31 @@ def main():
         except Exception as e:   # a failing extra must not cost the contract line
             line.setdefault("extras_failed", {})['point MLP + query-only'] = repr(e)
             print("[bench] extra failed: %s: %r" % ('point MLP + query-only', e), file=sys.stderr)
+        # ---- the point MLP of the TIMED line: fused small-set kernels on the SB x 2048 points of one call ------------
+        try:
+            nb = max(SB, 4)
+            imgs_nb = torch.cat([pool[k % POOL][0] for k in range(nb)], dim=0)
+            pts_nb = torch.cat([pool[k % POOL][1] for k in range(nb)], dim=0)
+            tms_nb = torch.cat([pool[k % POOL][2] for k in range(nb)], dim=0)
+            enc_nb = eng.encode(imgs_nb)
+            amax_nb = torch.stack([torch.stack([t[b].abs().max() for t in enc_nb.taps]).max() for b in range(nb)]).contiguous()
+            ms_gather = ev_time_ms(lambda: ops.gather_taps_split(enc_nb.taps, tms_nb, pts_nb, amax_nb), 20, torch)
+            ms_all = ev_time_ms(lambda: ops.query_taps_fused(eng.weights.mlp, enc_nb.taps, enc_nb.embedding, tms_nb, pts_nb), 20, torch)
+            flop = nb * N_POINTS * MLP_FLOP_PER_PT
+            line["roofline_mlp_small"] = {
+                "kernel": "disn_query_taps_fused on the %d x %d points of one call: 5 x amax64 + tap_amax + project_gather_taps_kernel "
+                          "(split form) + mlp_fused_kernel<local, FEAT> + the global bias fold (split-K GEMV) + mlp_fused_kernel<global>" % (nb, N_POINTS),
+                "bound": "mfma", "ms": ms_all, "ms_gather_alone": ms_gather, "ms_mlp_without_gather": ms_all - ms_gather,
+                "achieved": 3.0 * flop / ms_all / 1e9, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": 3.0 * flop / ms_all / 1e9 / PEAK_F16_MFMA_TFLOPS,
+                "frac_algorithmic": flop / ms_all / 1e9 / PEAK_F16_MFMA_TFLOPS, "ceiling_tflops": PEAK_F16X2_TFLOPS,
+                "flop_per_point": MLP_FLOP_PER_PT, "points_per_s": nb * N_POINTS / ms_all * 1e3,
+                "note": "gather + point MLP of one submitted call, alone on the GPU (VERDICT r3 #1's figure; round 3's seven "
+                        "dense_h2w launches + two gathers took ~0.72 ms for 16 x 2048 points)"}
+            del enc_nb, imgs_nb, pts_nb
+        except Exception as e:   # a failing extra must not cost the contract line
+            line.setdefault("extras_failed", {})['small-set point MLP'] = repr(e)
+            print("[bench] extra failed: %s: %r" % ('small-set point MLP', e), file=sys.stderr)
         # ---- config 3: full 257^3 grid on one GPU (no marching cubes yet) -----------------------
         try:
             from disn_amd import create_sdf as cs
