@@ -674,68 +674,26 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
   for (int i = 0; i <= DP; ++i) ring_issue(i);  // slots 0 .. DP
   sync_slot(0, false);                          // slot 0 (the only sync outside a slot)
 
-  // weight fragments, four register sets: pair q uses set q % 4, the pairs two (and, in a double step, three) ahead
-  // are read meanwhile
-  h8 wh[4], wl[4];
+  // weight fragments, three register sets: pair q uses set q % 3, the pair two ahead is read meanwhile
+  h8 wh[3], wl[3];
 #define FM_LDW(Q)                                                                                   \
   {                                                                                                 \
-    wh[(Q) % 4] = *reinterpret_cast<const h8*>(&lds[sa[((Q) >> 3) & 1] + ((Q)&7) * 2048]);         \
-    wl[(Q) % 4] = *reinterpret_cast<const h8*>(&lds[sa[((Q) >> 3) & 1] + ((Q)&7) * 2048 + 1024]);  \
+    wh[(Q) % 3] = *reinterpret_cast<const h8*>(&lds[sa[((Q) >> 3) & 1] + ((Q)&7) * 2048]);         \
+    wl[(Q) % 3] = *reinterpret_cast<const h8*>(&lds[sa[((Q) >> 3) & 1] + ((Q)&7) * 2048 + 1024]);  \
   }
   // pair Q of the stream (Q: position within the tile's 1056 pairs; compile-time after unrolling):
   // read pair Q+2, three MFMAs (small terms first), and after pair 3 of a slot the sync for the next slot
 #define FM_STEP_(Q, CLS, ACC, XH, XL, FIRST)                 \
   {                                                          \
     if ((Q) + 2 < KP) FM_LDW((Q) + 2);                       \
-    if (FIRST) FM_MFMA0(CLS, ACC, wl[(Q) % 4], XH);          \
-    else FM_MFMA(CLS, ACC, wl[(Q) % 4], XH);                 \
-    FM_MFMA(CLS, ACC, wh[(Q) % 4], XL);                      \
-    FM_MFMA(CLS, ACC, wh[(Q) % 4], XH);                      \
+    if (FIRST) FM_MFMA0(CLS, ACC, wl[(Q) % 3], XH);          \
+    else FM_MFMA(CLS, ACC, wl[(Q) % 3], XH);                 \
+    FM_MFMA(CLS, ACC, wh[(Q) % 3], XL);                      \
+    FM_MFMA(CLS, ACC, wh[(Q) % 3], XH);                      \
     if (((Q)&7) == 3) sync_slot((((Q) >> 3) + 1) & 1, true); \
   }
 #define FM_STEP(Q, CLS, ACC, XH, XL) FM_STEP_(Q, CLS, ACC, XH, XL, false)
 #define FM_STEP0(Q, CLS, ACC, XH, XL, FIRST) FM_STEP_(Q, CLS, ACC, XH, XL, FIRST)
-  // DOUBLE step (round 4): pairs Q (even) and Q + 1 -- the same B operand into two different accumulators -- issued as
-  // l0 l1 | h0 h1 | h0 h1.  Three back-to-back MFMAs on ONE accumulator wait for each other (a wave alone on its SIMD
-  // has nothing to fill the latency with: conv_h2w.hip measured 2.1x for that pattern); two interleaved chains do not.
-  // Every accumulator still sees its own three products in the order l.h, h.l, h.h: the bits are the single step's.
-#define FM_STEP2_(Q, CLS, ACC0, ACC1, XH, XL, FIRST)                  \
-  {                                                                   \
-    if ((Q) + 2 < KP) FM_LDW((Q) + 2);                                \
-    if ((Q) + 3 < KP) FM_LDW((Q) + 3);                                \
-    if (FIRST) {                                                      \
-      FM_MFMA0(CLS, ACC0, wl[(Q) % 4], XH);                           \
-      FM_MFMA0(CLS, ACC1, wl[((Q) + 1) % 4], XH);                     \
-    } else {                                                          \
-      FM_MFMA(CLS, ACC0, wl[(Q) % 4], XH);                            \
-      FM_MFMA(CLS, ACC1, wl[((Q) + 1) % 4], XH);                      \
-    }                                                                 \
-    FM_MFMA(CLS, ACC0, wh[(Q) % 4], XL);                              \
-    FM_MFMA(CLS, ACC1, wh[((Q) + 1) % 4], XL);                        \
-    FM_MFMA(CLS, ACC0, wh[(Q) % 4], XH);                              \
-    FM_MFMA(CLS, ACC1, wh[((Q) + 1) % 4], XH);                        \
-    if (((Q)&7) == 2) sync_slot((((Q) >> 3) + 1) & 1, true);          \
-  }
-#define FM_STEP2(Q, CLS, ACC0, ACC1, XH, XL) FM_STEP2_(Q, CLS, ACC0, ACC1, XH, XL, false)
-  // the same with two B operands (two reduction blocks of ONE output tile into an even and an odd accumulator that are
-  // added afterwards: conv3's tiles, whose 16 blocks would otherwise be one chain of 48 dependent MFMAs)
-#define FM_STEP2B_(Q, CLS, ACC0, ACC1, XH0, XL0, XH1, XL1, FIRST)     \
-  {                                                                   \
-    if ((Q) + 2 < KP) FM_LDW((Q) + 2);                                \
-    if ((Q) + 3 < KP) FM_LDW((Q) + 3);                                \
-    if (FIRST) {                                                      \
-      FM_MFMA0(CLS, ACC0, wl[(Q) % 4], XH0);                          \
-      FM_MFMA0(CLS, ACC1, wl[((Q) + 1) % 4], XH1);                    \
-    } else {                                                          \
-      FM_MFMA(CLS, ACC0, wl[(Q) % 4], XH0);                           \
-      FM_MFMA(CLS, ACC1, wl[((Q) + 1) % 4], XH1);                     \
-    }                                                                 \
-    FM_MFMA(CLS, ACC0, wh[(Q) % 4], XL0);                             \
-    FM_MFMA(CLS, ACC1, wh[((Q) + 1) % 4], XL1);                       \
-    FM_MFMA(CLS, ACC0, wh[(Q) % 4], XH0);                             \
-    FM_MFMA(CLS, ACC1, wh[((Q) + 1) % 4], XH1);                       \
-    if (((Q)&7) == 2) sync_slot((((Q) >> 3) + 1) & 1, true);          \
-  }
 
   const long long ntiles = (P.n + 127) >> 7;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -897,19 +855,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
     }
 #pragma unroll 1
     for (int it = 0; it < 16; ++it) {
-      f32x16 acc, acco;   // even / odd reduction blocks (ascending within each), then even + odd
+      f32x16 acc;
 #pragma unroll
-      for (int kb = 0; kb < 16; kb += 2)
-        FM_STEP2B_(32 + kb, "v", acc, acco, x2h[kb], x2l[kb], x2h[kb + 1], x2l[kb + 1], kb == 0);
+      for (int kb = 0; kb < 16; ++kb) FM_STEP0(32 + kb, "v", acc, x2h[kb], x2l[kb], kb == 0);
       h8 fh[2], fl[2];
       FM_SETTLE_ACC("v", acc);
-      FM_SETTLE_ACC("v", acco);
-      acc = acc + acco;
       fm_tile_to_frags<false>(acc, &cst[fm::cB3 + 32 * it + 4 * g], &cst[fm::cS3 + 32 * it + 4 * g], nullptr, wt, inv3, s3, fh, fl);
       FM_SETTLE_IN4(fh[0], fl[0], fh[1], fl[1]);
 #pragma unroll
-      for (int r = 0; r < 32; r += 2)  // reduction block 2it (r < 16) / 2it+1 for output tiles r & 15, (r & 15) + 1
-        FM_STEP2(32 + 16 + r, "a", acc4[r & 15], acc4[(r & 15) + 1], fh[r >> 4], fl[r >> 4]);
+      for (int r = 0; r < 32; ++r)  // reduction block 2it (r < 16) / 2it+1 for output tile r & 15
+        FM_STEP(32 + 16 + r, "a", acc4[r & 15], fh[r >> 4], fl[r >> 4]);
       if (LOCAL && it == 14) gather_issue(std::integral_constant<int, 0>{});  // pmap rows of fold2/conv1's tile 0: one iteration of cover
     }
 
@@ -936,10 +891,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer is read: the next iteration's blocks may land
         if (it2 < 15) feat_issue(tile * 128, it2 + 1);
-        fm_static_for<48>([&](auto r_c) {  // reduction block 6 it2 + 2 (r >> 5) + ((r >> 4) & 1) for output tiles r & 15, + 1
-          constexpr int r = 2 * decltype(r_c)::value;
-          FM_STEP2(32 + 768 + r, "a", acc4[r & 15], acc4[(r & 15) + 1], fh6[2 * (r >> 5) + ((r >> 4) & 1)],
-                   fl6[2 * (r >> 5) + ((r >> 4) & 1)]);
+        fm_static_for<96>([&](auto r_c) {  // reduction block 6 it2 + 2 (r >> 5) + ((r >> 4) & 1) for output tile r & 15
+          constexpr int r = decltype(r_c)::value;
+          FM_STEP(32 + 768 + r, "a", acc4[r & 15], fh6[2 * (r >> 5) + ((r >> 4) & 1)], fl6[2 * (r >> 5) + ((r >> 4) & 1)]);
         });
       }
     }
@@ -958,8 +912,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const FusedDev P) {
       }
       FM_SETTLE_IN4(fh[0], fl[0], fh[1], fl[1]);
 #pragma unroll
-      for (int r = 0; r < 16; r += 2)
-        FM_STEP2_(QB + 16 * it + r, "v", acc5[r & 7], acc5[(r & 7) + 1], fh[r >> 3], fl[r >> 3], it == 0 && r < 8);
+      for (int r = 0; r < 16; ++r)
+        FM_STEP0(QB + 16 * it + r, "v", acc5[r & 7], fh[r >> 3], fl[r >> 3], it == 0 && r < 8);
     });
 
     // ---- fold2/conv2 epilogue + fold2/conv5 (256 -> 1): dot with w6 --------------------------------------

@@ -237,11 +237,10 @@ def fused_stream(img, meta, consts, pts, add4=None, feat_rows=None, featmax=None
     # phase A
     acc4 = np.zeros((16, 64, 16), f32)
     for it in range(16):
-        acc_eo = [np.zeros((64, 16), f32), np.zeros((64, 16), f32)]    # even / odd reduction blocks, then even + odd
+        acc = np.zeros((64, 16), f32)
         for kb in range(16):
             assert pair_coords(p, featf) == (1, it, kb)
-            acc_eo[kb & 1] = pair(acc_eo[kb & 1], *x2[kb])
-        acc = (acc_eo[0] + acc_eo[1]).astype(f32)
+            acc = pair(acc, *x2[kb])
         fr = tile_to_frags(acc, b3, inv3, s3, it)
         for r in range(32):
             assert pair_coords(p, featf) == (2, r & 15, 2 * it + (r >> 4))
