@@ -742,7 +742,7 @@ int fc_layer(const float* x, int B, int K, const float* w_kn, const float* wt_nk
              float* out, float* ws, hipStream_t st) {
   // the one-launch row form re-reads x (B x K floats) once per wave: right for one to three rows (launch-latency bound
   // layers), 4x the weight bytes in L2 traffic at eight -- a batched call takes the split-K stream kernel for every layer
-  if (wt_nk && B < kConvWideMinImages) DISN_TRY(gemv_rows_launch(x, B, K, wt_nk, bias, N, relu, out, st));
+  if (wt_nk && B < tune::conv_wide_min) DISN_TRY(gemv_rows_launch(x, B, K, wt_nk, bias, N, relu, out, st));   // (one threshold for every form switch: ADVICE r3)
   else DISN_TRY(gemv_launch(x, B, K, w_kn, bias, N, relu, out, ws, st));
   return 0;
 }

@@ -147,7 +147,7 @@ hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, co
 // row never depends on the other rows' data.
 int gemv_splits(int K, int N, int B) {
   const int colblocks = N / 256;
-  const int wgs = tune::gemv_wgs > 0 ? tune::gemv_wgs : (B >= kConvWideMinImages ? 1024 : 2048);
+  const int wgs = tune::gemv_wgs > 0 ? tune::gemv_wgs : (B >= tune::conv_wide_min ? 1024 : 2048);
   int s = (wgs + colblocks - 1) / colblocks;
   const int smax = K / 32 > 0 ? K / 32 : 1;
   if (s > smax) s = smax;

@@ -184,16 +184,20 @@ def get_loss(end_points, sdf_weight=10., regularization=True, mask_weight=4.,
         if not regularization:
             return 0.0
         # a function of the weights alone (140 M squares in float64 on the host: ~0.5 s): computed once per weight
-        # set of the session, not at every fetch (the key changes when the session's weights are replaced)
-        key = (id(sess.weights), wd)
-        cache = getattr(sess, '_regularization_cache', None)
+        # set, not at every fetch.  The cache lives ON the weight store (an id()-keyed cache on the session
+        # can outlive its store -- CPython reuses ids) and is keyed by the identities of the arrays it summed, so a
+        # replaced array invalidates it; an in-place edit of an array is the caller's to announce
+        # (`store._regularization_cache = None`), as with any cached function of mutable data.
+        store = sess.weights
+        names = [k for k in store.keys() if k.endswith('/weights')]
+        key = (wd, tuple(id(store[k]) for k in names))
+        cache = getattr(store, '_regularization_cache', None)
         if cache is None or cache[0] != key:
-            val = float(sum(wd * 0.5 * float(np.sum(np.asarray(v, np.float64) ** 2))
-                            for k, v in sess.weights.items() if k.endswith('/weights')))
-            cache = (key, val)
+            val = float(sum(wd * 0.5 * float(np.sum(np.asarray(store[k], np.float64) ** 2)) for k in names))
+            cache = (key, val, [store[k] for k in names])      # (the arrays are kept alive: their ids stay theirs)
             try:
-                sess._regularization_cache = cache
-            except AttributeError:      # a session type without instance attributes: no cache
+                store._regularization_cache = cache
+            except AttributeError:      # a plain dict of weights: no cache
                 pass
         return cache[1]
 

@@ -372,9 +372,10 @@ def is_v1_checkpoint(path: str) -> bool:
         return struct.unpack("<Q", f.read(8))[0] == TABLE_MAGIC
 
 
-def list_variables_v1(path: str, verify: bool = True) -> Dict[str, Dict[str, object]]:
-    """name -> {dtype, shape, slices} from the SavedTensorSliceMeta under key ''"""
-    buf = open(path, "rb").read()
+def list_variables_v1(path: str, verify: bool = True, _buf: Optional[bytes] = None) -> Dict[str, Dict[str, object]]:
+    """name -> {dtype, shape, slices} from the SavedTensorSliceMeta under key '' (`_buf`: the file's bytes when the
+    caller has read them already -- slim's vgg_16.ckpt is 550 MB: it is read ONCE)"""
+    buf = open(path, "rb").read() if _buf is None else _buf
     out: Dict[str, Dict[str, object]] = {}
     for k, v in _table_entries(buf, verify):
         if k != b"":
@@ -406,7 +407,7 @@ def load_checkpoint_v1(path: str, names: Optional[Iterable[str]] = None, verify:
     """Read tensors of a single-file V1 checkpoint by variable name (all, or the ``names`` given)."""
     buf = open(path, "rb").read()
     want = set(names) if names is not None else None
-    meta = list_variables_v1(path, verify)
+    meta = list_variables_v1(path, verify, _buf=buf)
     out: Dict[str, np.ndarray] = {}
     filled: Dict[str, int] = {}
     for k, v in _table_entries(buf, verify):

@@ -240,6 +240,12 @@ class Trainer:
                     n += 1
         self.adam_t = adam_step_from_checkpoint(arrays, self.beta2, self.adam_t, underflow_step)
         self.step_count = schedule_step_from_checkpoint(arrays)
+        if "batch" not in arrays and self.adam_t > 0:
+            # the reference's Saver leaves `batch` out (train/train_sdf.py:285-286), so its own resume restarts the
+            # learning-rate decay too -- say so instead of doing it silently; save(include_step=True) keeps it
+            import warnings
+            warnings.warn("restored a bundle without `batch` after %d Adam steps: the learning-rate schedule restarts at "
+                          "step 0 (the reference's behaviour); save with include_step=True to carry the step" % self.adam_t)
         return n
 
 
