@@ -785,6 +785,7 @@ int disn_conv3x3_h2(const float* in, int B, int H, int W, int Cin, const void* i
   if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 10 || (pool_out && ((H | W) & 1)))
     return DISN_E_SHAPE;
   if (tiling >= 5 && tiling <= 9 && !disn::conv_h2w_supported(H, W, Cin, Cout)) return DISN_E_SHAPE;
+  if ((tiling == 6 || tiling == 8) && Cout % 128) return DISN_E_SHAPE;   // variants 2, 4: four n-waves = 128 channels per workgroup
   if (tiling == 10 && (H > 14 || W > 14)) return DISN_E_SHAPE;
   if (ws_bytes < (size_t)B * 512) return DISN_E_WS;
   hipStream_t st = (hipStream_t)stream;

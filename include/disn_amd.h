@@ -382,15 +382,18 @@ int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, 
  * carries B images.
  * WHICH KERNELS RUN (selection rules; results of different forms agree to fp32 rounding -- all within 1e-5 of the
  * float64 oracle -- and are bit-identical only within one form):
- *   point MLPs  B <= 32 and N < 8192 (and the *_d* images present): the two-term f16 layers -- dense_h2.hip for
- *               B < 4 or N % 128 != 0, dense_h2w.hip for B >= 4 (disn_dense_h2's rule), the local fold2/conv1 of
- *               such a call in two K ranges; otherwise (B > 32 or N >= 8192) the three-term bf16 / f32-input GEMM
- *               chain of disn_dense.  disn_query / disn_sdf_mlp switch at the same N = 8192 per image.
+ *   point MLPs  B >= 4, N % 128 == 0, featmap == NULL (round 4; with w->g_fused and w->l_feat): the FUSED small-set
+ *               kernels -- split-form gather from the taps, mlp_fused_kernel<local, FEAT>, mlp_fused_kernel<global> with
+ *               image b's folded bias row: one launch per stream behind the gather, bit-identical to disn_encode +
+ *               disn_query_taps_fused.  Otherwise, B <= 32 and N < 8192 (and the *_d* images present): the two-term
+ *               f16 layers, one launch per layer -- dense_h2.hip for B < 4 or N % 128 != 0, dense_h2w.hip for B >= 4
+ *               (disn_dense_h2's rule); otherwise (B > 32 or N >= 8192) the three-term bf16 / f32-input GEMM chain of
+ *               disn_dense.  disn_query / disn_sdf_mlp switch at the same N = 8192 per image.
  *   convolutions / fc head  B < 4: conv_h2.hip + one-launch fc rows; B >= 4: conv_h2w.hip + the split-K fc stream
  *               kernel with fewer splits (disn_conv3x3_h2's rule).
- * Every activation scale is per image on all of these paths, so request b's outputs never depend on the other
- * requests of its call, on its position, or on B beyond the thresholds above (B < 4: bit for bit those of a B = 1
- * call; 4 <= B <= 32: bit for bit those of any other call of 4..32 requests). */
+ * Every activation scale is per image (per point inside the fused kernels) on all of these paths, so request b's
+ * outputs never depend on the other requests of its call, on its position, or on B beyond the thresholds above (B < 4:
+ * bit for bit those of a B = 1 call; B >= 4: bit for bit those of any other call of >= 4 requests of the same N). */
 size_t disn_encode_query_workspace_bytes(int B, int N);
 int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw,
                       const disn_mlp_weights_t* mw, const float* img, const float* trans_mat,
