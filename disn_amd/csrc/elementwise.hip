@@ -471,9 +471,19 @@ __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
         hh[e] = (_Float16)xs[e];
         ll[e] = (_Float16)(xs[e] - (float)hh[e]);
       }
-      unsigned char* row = reinterpret_cast<unsigned char*>(feat) + (pt * (size_t)feat_ld + (size_t)(c & ~7)) * 4 + ((c & 4) ? 8 : 0);
-      *reinterpret_cast<uint2*>(row) = *reinterpret_cast<const uint2*>(hh);
-      *reinterpret_cast<uint2*>(row + 16) = *reinterpret_cast<const uint2*>(ll);
+      // Lanes 2i, 2i + 1 hold the two halves (channels c .. c + 3, c + 4 .. c + 7) of ONE 8-channel group (c4_begin and
+      // c4_count are even, threads leave the loop in pairs): the even lane sends its l half and takes the partner's h
+      // half, the odd lane the other way round -- one 16-byte store per lane (h8 | l8), a wave's store instruction 1 KiB
+      // of contiguous bytes, instead of two 8-byte stores at half density
+      const uint2 hv = *reinterpret_cast<const uint2*>(hh), lv = *reinterpret_cast<const uint2*>(ll);
+      const bool odd = (c & 4) != 0;
+      const uint2 send = odd ? hv : lv;
+      uint2 recv;
+      recv.x = (unsigned)__shfl_xor((int)send.x, 1);
+      recv.y = (unsigned)__shfl_xor((int)send.y, 1);
+      const uint4 out = odd ? make_uint4(recv.x, recv.y, lv.x, lv.y) : make_uint4(hv.x, hv.y, recv.x, recv.y);
+      unsigned char* row = reinterpret_cast<unsigned char*>(feat) + (pt * (size_t)feat_ld + (size_t)(c & ~7)) * 4 + (odd ? 16 : 0);
+      *reinterpret_cast<uint4*>(row) = out;
     } else {
       *reinterpret_cast<float4*>(feat + pt * feat_ld + c) = o;
     }

@@ -18,7 +18,7 @@ last = collections.OrderedDict()
 for k, e in rows.items():
     if "MFMA" not in "".join(e.keys()):
         continue
-    if not any(s in e["name"] for s in ("conv_h2", "dense_h2", "conv1_1")):
+    if not any(s in e["name"] for s in ("conv_h2", "dense_h2", "conv1_1", "mlp_fused")):
         continue
     last[(e["name"], e["grid"])] = e          # the last dispatch of each (kernel, grid)
 print("# MFMA utilisation, last dispatch of each (kernel, grid); counters of ONE pass (profiled clocks are ~5 % below un-profiled)")

@@ -93,5 +93,14 @@ out = {"build": build, "counter_files": os.environ.get("PMC_BUILD", ""), "source
                              "local": hbm([i for i in fused if "<true" in fetch[i]["name"] or "Lb1" in fetch[i]["name"]][-1:]),
                              "note": "per 65536 points: weights re-streamed per 128-point tile stay in L2; the local "
                                      "stream adds 8 KB/point of pmap rows (L2 / MALL resident)"} if fused else None),
+       "small_set_b16": (lambda fe, gl, ga: {
+           "gather_split": dict(hbm(ga[-1:]), algorithmic_bytes=16 * 2048 * (16 * 5888 + 6144),
+                                note="16 x 2048 points: 94 208 B/point of (cached) tap pixels read, 6144 B/point of split rows written"),
+           "local_feat": dict(hbm(fe[-1:]), algorithmic_bytes=16 * 2048 * 6144 + 5308416,
+                              note="split rows read once + one pass over the 5.3 MB weight image (every workgroup re-reads it from L2)"),
+           "global": hbm([i for i in gl if i > fe[-1]][:1])} if fe else None)(
+           [i for i in fused if "true, false, true" in fetch[i]["name"] or "Lb1ELb0ELb1" in fetch[i]["name"]],
+           [i for i in fused if ("<false" in fetch[i]["name"] or "Lb0" in fetch[i]["name"]) and int(fetch[i]["grid"]) == 65536],
+           [i for i in g_taps if int(fetch[i]["grid"]) >= 4000000]),
        "write_calibration": {"factor": cal, "basis": "gather_kernel at N=262144 writes exactly 262144*5888 B"}}
 print(json.dumps(out, indent=1))

@@ -21,6 +21,15 @@ pts = torch.rand((1, 2048, 3), device="cuda") * 2 - 1
 for _ in range(int(os.environ.get("PROF_STEPS", "3"))):
     enc = eng.encode(img)
     out = eng.query(enc, pts, tm)
+# round 4: the fused small-set point MLP on the 16 x 2048 points of one call (here, between the steps and the gathers:
+# the "first 13 convolutions" / "last dispatch of ..." selections of tools/pmc_traffic.py keep their meaning)
+imgs16 = torch.from_numpy(rng.random((16, 137, 137, 3), dtype=np.float32)).cuda()
+pts16 = torch.rand((16, 2048, 3), device="cuda") * 2 - 1
+enc16 = eng.encode(imgs16)
+for _ in range(2):
+    ops.query_taps_fused(eng.weights.mlp, enc16.taps, enc16.embedding, tm.expand(16, -1, -1).contiguous(), pts16)
+torch.cuda.synchronize()
+del enc16, imgs16
 for n in (2048, 262144):
     p = torch.rand((1, n, 3), device="cuda") * 2 - 1
     xy = ops.project(p, tm)

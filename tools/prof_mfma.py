@@ -30,4 +30,20 @@ for M, rows in ((2048, 0), (16384, 2048), (32768, 2048)):
         for _ in range(3):
             ops.dense_h2(a1, img, b, N, True, a2=a2, rows_per_image=rows)
         torch.cuda.synchronize()
+# round 4: the fused small-set point MLP of a 16-step call (mlp_fused_kernel<local, FEAT>, <global>) and the fused
+# kernels of a 65536-point query (folded map)
+B = 16
+imgs = torch.from_numpy(rng.random((B, 137, 137, 3), dtype=np.float32)).cuda()
+pts = torch.from_numpy(rng.uniform(-1, 1, (B, 2048, 3)).astype(np.float32)).cuda()
+tm = torch.tensor([[[-68.453156, 5.5086656, -0.37556022], [-17.138561, -84.685486, -0.250198],
+                    [-47.284092, -3.6569588, 0.2493176], [101.133705, 101.34268, 1.4305686]]] * B, device="cuda")
+enc = eng.encode(imgs)
+for _ in range(3):
+    ops.query_taps_fused(eng.weights.mlp, enc.taps, enc.embedding, tm, pts)
+torch.cuda.synchronize()
+enc1 = eng.encode(imgs[:1])
+p64 = torch.from_numpy(rng.uniform(-1, 1, (1, 65536, 3)).astype(np.float32)).cuda()
+for _ in range(3):
+    eng.query(enc1, p64, tm[:1])
+torch.cuda.synchronize()
 print("done")
