@@ -32,6 +32,10 @@ if has ab; then
     DISN_AMD_LIB=disn_amd/csrc/libdisn_amd_tuning.so KNOBS=$k timeout 150 python tools/bench_knobs.py --steps 256 --warmup 32 --no-extras 2>/dev/null | tail -1 | cut -c1-200 | tee -a $OUT/bench_ab.txt
     DISN_AMD_LIB=disn_amd/csrc/libdisn_amd_tuning.so KNOBS=$k timeout 150 python tools/bench_knobs.py --steps 20 --warmup 5 --no-extras 2>/dev/null | tail -1 | cut -c1-200 | tee -a $OUT/bench_ab.txt
   done
+  for bt in 4 8; do for k in "fused_small=1" "fused_small=0"; do
+    echo "batch $bt x 2 in flight, knobs $k" | tee -a $OUT/bench_ab.txt
+    DISN_AMD_LIB=disn_amd/csrc/libdisn_amd_tuning.so KNOBS=$k timeout 150 python tools/bench_knobs.py --steps 256 --warmup 32 --no-extras --batch $bt 2>/dev/null | tail -1 | cut -c1-200 | tee -a $OUT/bench_ab.txt
+  done; done
   echo "balance 1" | tee -a $OUT/bench_ab.txt
   timeout 150 python bench.py --steps 20 --warmup 5 --no-extras --balance 1 2>/dev/null | tail -1 | cut -c1-200 | tee -a $OUT/bench_ab.txt
 fi
