@@ -382,13 +382,19 @@ def main():
     # every step of a call -- and of the calls in flight beside it -- has its own image, point set and camera:
     # a pool of 2 S SB distinct jobs, step k takes job k % pool
     POOL = 2 * S * SB
+    # the requests of the pool lie back to back in three device buffers (images, point sets, cameras): consecutive jobs
+    # of a call are then submitted without a concatenation (StepPipeline: zero-copy for contiguous requests)
+    pool_img = torch.empty((POOL, 137, 137, 3), dtype=torch.float32, device=dev)
+    pool_pts = torch.empty((POOL, N_POINTS, 3), dtype=torch.float32, device=dev)
+    pool_tm = torch.empty((POOL, 4, 3), dtype=torch.float32, device=dev)
     pool = []
     for k in range(POOL):
-        pimg = torch.from_numpy(rng.random((1, 137, 137, 3), dtype=np.float32) * np.float32(0.5 + 0.5 * rng.random())).to(dev)
-        ppts = torch.from_numpy((rng.random((1, N_POINTS, 3), dtype=np.float32) * 2 - 1).astype(np.float32)).to(dev)
-        ptm = torch.tensor([DEMO_TM], dtype=torch.float32, device=dev)
-        ptm[0, 3, :2] += float(k % 7) - 3.0                      # (shifts the projected points by a few pixels)
-        pool.append((pimg, ppts, ptm))
+        pool_img[k] = torch.from_numpy(rng.random((137, 137, 3), dtype=np.float32) * np.float32(0.5 + 0.5 * rng.random())).to(dev)
+        pool_pts[k] = torch.from_numpy((rng.random((N_POINTS, 3), dtype=np.float32) * 2 - 1).astype(np.float32)).to(dev)
+        ptm = torch.tensor(DEMO_TM, dtype=torch.float32, device=dev)
+        ptm[3, :2] += float(k % 7) - 3.0                         # (shifts the projected points by a few pixels)
+        pool_tm[k] = ptm
+        pool.append((pool_img[k:k + 1], pool_pts[k:k + 1], pool_tm[k:k + 1]))
     img, pts, tm = pool[0]
 
     def run_steps(k):

@@ -487,7 +487,21 @@ class StepPipeline:
 
         def cat(idx, pos):
             ts = [self.engines[0]._dev(jobs[k][pos]) for k in idx]
-            return ts[0] if len(ts) == 1 else torch.cat(ts, dim=0)
+            if len(ts) == 1:
+                return ts[0]
+            # requests that already lie back to back in one allocation (a client that keeps its request batch in one
+            # buffer; bench.py's job pool) are submitted as they are: no copy, no allocation, ~0.1 ms less host time per call
+            t0 = ts[0]
+            if t0.is_contiguous():
+                step = t0.numel() * t0.element_size()
+                if all(t.is_contiguous() and t.dtype == t0.dtype and t.shape == t0.shape and
+                       t.data_ptr() == t0.data_ptr() + i * step and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr()
+                       for i, t in enumerate(ts)):
+                    off = (t0.data_ptr() - t0.untyped_storage().data_ptr()) // t0.element_size()
+                    flat = torch.empty(0, dtype=t0.dtype, device=t0.device).set_(t0.untyped_storage(), off,
+                                                                                   (len(ts) * t0.shape[0],) + tuple(t0.shape[1:]))
+                    return flat
+            return torch.cat(ts, dim=0)
 
         # call g runs on context g % in_flight.  (Tried for short runs -- bench.py --steps 20 = 8 + 8 + 4: the full calls back
         # to back on one context and the remainder beside them, because two calls started together stay in phase and gain

@@ -7,7 +7,7 @@ rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
-                     re.sub(r"\(.*$", "", r["Kernel_Name"]).replace("disn::", "").replace("void ", ""), int(r["Grid_Size"])))
+                     re.sub(r"\(.*$", "", r["Kernel_Name"]).replace("disn::", "").replace("void ", ""), int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)))
 rows.sort()
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 starts = [i for i, r in enumerate(rows) if r[2].startswith("resize_kernel<1>")][-n:]
