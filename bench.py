@@ -298,6 +298,9 @@ def main():
     ap.add_argument("--balance", type=int, default=0,
                     help="--workload query: 1 = the K steps of a run are cut into calls of equal size (a multiple of "
                          "--in-flight calls, none longer than --batch) instead of full calls + a short last one")
+    ap.add_argument("--chained", type=int, default=0,
+                    help="--workload query: 1 = one host thread submits the calls in order and call g + 1's convolution stack "
+                         "starts behind call g's (two-stage pipeline: convolutions beside the previous call's tail)")
     ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--workload", choices=("query", "grid", "train"), default="query",
                     help="query: BASELINE.json metric (default); grid: configs 3/4 (dense grid + gather + marching "
@@ -400,7 +403,7 @@ def main():
     def run_steps(k):
         # rows A..H, every step, through the single overlapped entry (disn_encode_query): SB consecutive steps per
         # call, call j on engine context j % S (own HIP stream, own host thread); nothing cached between steps
-        return pipe.run([pool[i % POOL] for i in range(k)], balance=args.balance)
+        return pipe.run([pool[i % POOL] for i in range(k)], balance=args.balance, chained=bool(args.chained))
 
     # Set-up, untimed and independent of W: ~--spinup-s seconds of the same steps (GPU clocks, the caching allocator's
     # pools, every code path once), then the collector is parked -- a generation-2 collection of a process with torch

@@ -419,7 +419,7 @@ class StepPipeline:
         if chained is None:
             chained = False
         if self.batch > 1:
-            return self._run_batched(jobs, keep_encoded, balance)
+            return self._run_batched(jobs, keep_encoded, balance, chained)
         out = [None] * len(jobs)
         cur = torch.cuda.current_stream(self.device)
         if chained:
@@ -475,8 +475,12 @@ class StepPipeline:
         base, extra = divmod(njobs, n)
         return [base + (1 if i < extra else 0) for i in range(n)]
 
-    def _run_batched(self, jobs, keep_encoded, balance=False):
-        """groups of up to ``batch`` consecutive jobs -> one call each; group g runs on context g % in_flight"""
+    def _run_batched(self, jobs, keep_encoded, balance=False, chained=False):
+        """groups of up to ``batch`` consecutive jobs -> one call each; group g runs on context g % in_flight.
+        ``chained``: ONE host thread enqueues the calls in order and call g + 1's convolution stack starts behind call g's
+        (disn_ctx_pipeline): a two-stage pipeline -- the MFMA-bound convolutions of one call beside the tail (gather,
+        fused point-MLP kernels, HBM-bound fc head) of the previous one -- instead of calls that start together and stay
+        in phase (convolutions beside convolutions, tails beside tails)."""
         S, Bn = len(self.engines), self.batch
         groups, o = [], 0
         for n in self.call_sizes(len(jobs), Bn, S, balance):
@@ -532,6 +536,34 @@ class StepPipeline:
                         out[k] = sdf[o:o + b]
                     o += b
 
+        if chained and len(groups) > 1:
+            with torch.cuda.device(self.device):
+                if not hasattr(self, "_conv_done"):
+                    self._conv_done = [torch.cuda.Event() for _ in range(S + 1)]
+                    for e in self._conv_done:
+                        e.record()                       # creates the hipEvent_t handles
+                for st in self.streams:
+                    st.wait_stream(cur)
+                prev = None
+                for g, idx in enumerate(groups):
+                    i = g % S
+                    rec = self._conv_done[g % (S + 1)]
+                    ops.ctx_pipeline(self.engines[i]._ctx, prev, rec)
+                    args = [cat(idx, p) for p in range(len(jobs[idx[0]]))]
+                    with torch.cuda.stream(self.streams[i]):
+                        enc, sdf = self.engines[i].encode_query(*args)
+                    o = 0
+                    for k in idx:
+                        b = jobs[k][0].shape[0]
+                        out[k] = (Encoded(enc.resized[o:o + b], [t[o:o + b] for t in enc.taps], enc.embedding[o:o + b], None),
+                                  sdf[o:o + b]) if keep_encoded else sdf[o:o + b]
+                        o += b
+                    prev = rec
+                for eng in self.engines:
+                    ops.ctx_pipeline(eng._ctx, None, None)
+            for st in self.streams:
+                cur.wait_stream(st)
+            return out
         self._dispatch(work, min(S, len(groups)))
         for st in self.streams:
             cur.wait_stream(st)
