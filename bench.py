@@ -301,6 +301,8 @@ def main():
     ap.add_argument("--chained", type=int, default=0,
                     help="--workload query: 1 = one host thread submits the calls in order and call g + 1's convolution stack "
                          "starts behind call g's (two-stage pipeline: convolutions beside the previous call's tail)")
+    ap.add_argument("--spin-sync", type=int, default=1,
+                    help="--workload query: 1 = poll an event recorded behind the timed steps before torch.cuda.synchronize()")
     ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--workload", choices=("query", "grid", "train"), default="query",
                     help="query: BASELINE.json metric (default); grid: configs 3/4 (dense grid + gather + marching "
@@ -403,7 +405,14 @@ def main():
     def run_steps(k):
         # rows A..H, every step, through the single overlapped entry (disn_encode_query): SB consecutive steps per
         # call, call j on engine context j % S (own HIP stream, own host thread); nothing cached between steps
-        return pipe.run([pool[i % POOL] for i in range(k)], balance=args.balance, chained=bool(args.chained))
+        if args.balance or args.chained:
+            return pipe.run([pool[i % POOL] for i in range(k)], balance=args.balance, chained=bool(args.chained))
+        # step i takes job i % POOL; the jobs lie back to back in the pool's buffers and POOL is a multiple of SB: every
+        # call is handed its SB consecutive requests as one view (StepPipeline.run_calls: no per-request host work)
+        calls = [(pool_img[o % POOL:o % POOL + n], pool_pts[o % POOL:o % POOL + n], pool_tm[o % POOL:o % POOL + n])
+                 for o, n in zip(range(0, k, SB), StepPipeline.call_sizes(k, SB, S, False))]
+        res = pipe.run_calls(calls)
+        return [r[j:j + 1] for r in res for j in range(r.shape[0])]
 
     # Set-up, untimed and independent of W: ~--spinup-s seconds of the same steps (GPU clocks, the caching allocator's
     # pools, every code path once), then the collector is parked -- a generation-2 collection of a process with torch
@@ -429,6 +438,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     outs = run_steps(args.steps)
+    if args.spin_sync:      # hipDeviceSynchronize parks the host thread: poll an event first (same end point, less wake-up latency)
+        done_ev = torch.cuda.Event()
+        done_ev.record()
+        while not done_ev.query():
+            pass
     torch.cuda.synchronize()
     if launched:
         dist.barrier()

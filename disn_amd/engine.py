@@ -456,6 +456,29 @@ class StepPipeline:
             cur.wait_stream(st)                            # results are ordered before later work on the caller's stream
         return out
 
+    def run_calls(self, calls):
+        """calls: sequence of ALREADY batched requests (imgs [B,137,137,3], pts [B,N,3], trans_mat [B,4,3][, pts_rot]) --
+        one disn_encode_query call each, call g on context g % in_flight (own stream, own host thread) -> list of
+        pred_sdf [B,N].  What run() does after grouping and concatenating single requests, without the per-request host
+        work: for a client that keeps its request batches in device buffers."""
+        S = len(self.engines)
+        out = [None] * len(calls)
+        cur = torch.cuda.current_stream(self.device)
+
+        def work(i):
+            if self.trace is not None:
+                self.trace.append((i, "start", time.perf_counter()))
+            self.streams[i].wait_stream(cur)
+            for g in range(i, len(calls), S):
+                out[g] = self.engines[i].encode_query(*calls[g])[1]
+                if self.trace is not None:
+                    self.trace.append((i, g, time.perf_counter()))
+
+        self._dispatch(work, min(S, len(calls)))
+        for st in self.streams:
+            cur.wait_stream(st)
+        return out
+
     @staticmethod
     def call_sizes(njobs: int, batch: int, in_flight: int, balance: bool):
         """how many consecutive jobs go into each call.  Default: full calls of ``batch`` + a shorter last one.
