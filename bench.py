@@ -301,8 +301,6 @@ def main():
     ap.add_argument("--chained", type=int, default=0,
                     help="--workload query: 1 = one host thread submits the calls in order and call g + 1's convolution stack "
                          "starts behind call g's (two-stage pipeline: convolutions beside the previous call's tail)")
-    ap.add_argument("--spin-sync", type=int, default=1,
-                    help="--workload query: 1 = poll an event recorded behind the timed steps before torch.cuda.synchronize()")
     ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--workload", choices=("query", "grid", "train"), default="query",
                     help="query: BASELINE.json metric (default); grid: configs 3/4 (dense grid + gather + marching "
@@ -438,11 +436,6 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     outs = run_steps(args.steps)
-    if args.spin_sync:      # hipDeviceSynchronize parks the host thread: poll an event first (same end point, less wake-up latency)
-        done_ev = torch.cuda.Event()
-        done_ev.record()
-        while not done_ev.query():
-            pass
     torch.cuda.synchronize()
     if launched:
         dist.barrier()
