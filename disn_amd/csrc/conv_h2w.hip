@@ -302,10 +302,14 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   }
   CH2W_STAMP(13);
 
-  // ---- epilogue: bias, ReLU, fp32 NHWC store (32 lanes = 128 contiguous bytes of one pixel), 2x2 max pool of the
-  // lane's window, maximum of |out| for the next layer's scale.  Addresses: four wave-uniform bases (the window's
-  // four pixels) + one 32-bit lane offset per window, picked between the two lane halves' compile-time window
-  // positions -- no per-store 64-bit arithmetic; tiles inside the image take the branch without predicates ---------
+  // ---- epilogue: bias, ReLU, fp32 NHWC store, 2x2 max pool of the lane's window, maximum of |out| for the next
+  // layer's scale.  Round 4: the C layout hands lane (j, g) ONE channel of 16 pixels -- sixteen 4-byte stores per block,
+  // and a store instruction costs a wave alone ~60 cycles of in-order issue (the epilogue was ~9 k cycles of a 134 k-cycle
+  // tile).  Each wave now turns its block through a private LDS slice (16 ds_write_b32, 4 ds_read_b128; rows of 36 floats:
+  // conflict-free both ways) so that lane (j', g) holds FOUR consecutive channels 4 (j' & 7) .. of the four pixels of the
+  // ONE window q' = j' >> 3 of its half: four 16-byte stores (8 lanes = the 128 contiguous bytes of a pixel, 8 pixels per
+  // instruction) + one for the pooled window instead of twenty 4-byte ones.  The values are the same: bits unchanged.
+  if (WK == 2) __syncthreads();   // every wave is done with the exchange area: the slices below may overlap it
   const float bias_j = P.bias[n0 + j];
   const int WC = W * Cout;
   float* o00 = P.out + ((size_t)b * H * W + (size_t)y0 * W + x0) * Cout + n0;
@@ -316,35 +320,45 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   float* pb = P.pool_out ? P.pool_out + ((size_t)b * (H >> 1) * Wp + (size_t)(y0 >> 1) * Wp + (x0 >> 1)) * Cout + n0 : nullptr;
   const bool full = y0 + TH <= H && x0 + TW <= W;
   float vmax = 0.f;
+  constexpr int TROW = 36;                                  // floats per transposition row (16-byte aligned, 4 row mod 32 banks)
+  static_assert(NWAVES * 32 * TROW * 4 <= LDS_BYTES, "transposition slices");
+  float* tr = reinterpret_cast<float*>(lds) + wave * (32 * TROW);
+  const int qn = j >> 3, c4 = 4 * (j & 7);                  // this lane's window (quad) and channel group after the turn
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     if (mb < mb_lo || mb >= mb_hi) continue;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      // the window of this quad for lane half 0 / 1 (compile-time but for wm: MWV == 1 in all but one variant)
-      const int wA = (32 * (wm * MB + mb) + ch2::quad_row(q, 0)) >> 2, wB = (32 * (wm * MB + mb) + ch2::quad_row(q, 1)) >> 2;
-      const int wyA = wA / WPR, wxA = wA - wyA * WPR, wyB = wB / WPR, wxB = wB - wyB * WPR;
-      const int wy = g ? wyB : wyA, wx = g ? wxB : wxA;
-      const int off = (g ? 2 * wyB * WC + 2 * wxB * Cout : 2 * wyA * WC + 2 * wxA * Cout) + j;
-      float v[4];
+    for (int r = 0; r < 16; ++r) {
+      float t = fmaf(acc[mb][r], descale, bias_j);
+      t = P.relu ? fmaxf(t, 0.f) : t;
+      tr[(16 * g + r) * TROW + j] = t;                      // pixel 4 q + e of half g, channel j
+    }
+    __builtin_amdgcn_wave_barrier();   // (a wave's LDS operations execute in order; this only pins the compiler's order)
+    // window of (block mb, quad qn, half g): logical rows 32 (wm MB + mb) + quad_row(qn, g) .. + 3
+    const int w = (32 * (wm * MB + mb) + ch2::sigma(8 * qn + 4 * g)) >> 2;
+    const int wy = w / WPR, wx = w - wy * WPR;
+    const int off = 2 * wy * WC + 2 * wx * Cout + c4;
+    float4 v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = fmaf(acc[mb][4 * q + e], descale, bias_j);
-        v[e] = P.relu ? fmaxf(t, 0.f) : t;
-      }
-      const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-      if (full) {
-        o00[off] = v[0]; o01[off] = v[1]; o10[off] = v[2]; o11[off] = v[3];
-        vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-        if (pb) pb[(wy * Wp + wx) * Cout + j] = m4;
-      } else {
-        const int y = y0 + 2 * wy, x = x0 + 2 * wx;
-        if (y < H && x < W) { o00[off] = v[0]; vmax = fmaxf(vmax, fabsf(v[0])); }
-        if (y < H && x + 1 < W) { o01[off] = v[1]; vmax = fmaxf(vmax, fabsf(v[1])); }
-        if (y + 1 < H && x < W) { o10[off] = v[2]; vmax = fmaxf(vmax, fabsf(v[2])); }
-        if (y + 1 < H && x + 1 < W) { o11[off] = v[3]; vmax = fmaxf(vmax, fabsf(v[3])); }
-        if (pb && y + 1 < H && x + 1 < W) pb[(wy * Wp + wx) * Cout + j] = m4;
-      }
+    for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const float4*>(&tr[(16 * g + 4 * qn + e) * TROW + c4]);
+    __builtin_amdgcn_wave_barrier();
+    const float4 m4 = make_float4(fmaxf(fmaxf(v[0].x, v[1].x), fmaxf(v[2].x, v[3].x)), fmaxf(fmaxf(v[0].y, v[1].y), fmaxf(v[2].y, v[3].y)),
+                                  fmaxf(fmaxf(v[0].z, v[1].z), fmaxf(v[2].z, v[3].z)), fmaxf(fmaxf(v[0].w, v[1].w), fmaxf(v[2].w, v[3].w)));
+    auto amax4 = [](const float4& a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); };
+    if (full) {
+      *reinterpret_cast<float4*>(o00 + off) = v[0];
+      *reinterpret_cast<float4*>(o01 + off) = v[1];
+      *reinterpret_cast<float4*>(o10 + off) = v[2];
+      *reinterpret_cast<float4*>(o11 + off) = v[3];
+      vmax = fmaxf(vmax, fmaxf(fmaxf(amax4(v[0]), amax4(v[1])), fmaxf(amax4(v[2]), amax4(v[3]))));
+      if (pb) *reinterpret_cast<float4*>(pb + (wy * Wp + wx) * Cout + c4) = m4;
+    } else {
+      const int y = y0 + 2 * wy, x = x0 + 2 * wx;
+      if (y < H && x < W) { *reinterpret_cast<float4*>(o00 + off) = v[0]; vmax = fmaxf(vmax, amax4(v[0])); }
+      if (y < H && x + 1 < W) { *reinterpret_cast<float4*>(o01 + off) = v[1]; vmax = fmaxf(vmax, amax4(v[1])); }
+      if (y + 1 < H && x < W) { *reinterpret_cast<float4*>(o10 + off) = v[2]; vmax = fmaxf(vmax, amax4(v[2])); }
+      if (y + 1 < H && x + 1 < W) { *reinterpret_cast<float4*>(o11 + off) = v[3]; vmax = fmaxf(vmax, amax4(v[3])); }
+      if (pb && y + 1 < H && x + 1 < W) *reinterpret_cast<float4*>(pb + (wy * Wp + wx) * Cout + c4) = m4;
     }
   }
   if (P.out_amax) {  // 64 slots: same-address atomics serialise in L2 (~10 ns each)
