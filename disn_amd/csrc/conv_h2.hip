@@ -605,20 +605,49 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
     __syncthreads();
     vmax = 0.f;
   };
-  for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x, buf ^= 1) {
+  // Round 4: the window of tile t + 1 is REQUESTED (two 4-byte loads per thread) before tile t is computed and written
+  // into the other LDS buffer after it -- the global-load latency (1-2 us: as long as a tile's 432 FMAs per thread)
+  // no longer sits between two tiles.
+  auto tile_of = [&](long tl, int& b, int& y0, int& x0) {
     const int sx = (int)(tl % segs_x);
     const long by = tl / segs_x;
-    const int y0 = 2 * (int)(by % rows2), b = (int)(by / rows2);
-    if (out_amax && amax_stride && bcur >= 0 && b != bcur) flush(bcur);
-    bcur = b;
-    const int x0 = sx * 32;
+    y0 = 2 * (int)(by % rows2);
+    b = (int)(by / rows2);
+    x0 = sx * 32;
+  };
+  auto win_load = [&](long tl, float (&v)[2]) {   // window element (row r, pixel px, channel c), read in memory order
+    int b, y0, x0;
+    tile_of(tl, b, y0, x0);
     const float* img = in + (size_t)b * H * W * 3;
-    for (int i = tid; i < 4 * 34 * 3; i += 256) {  // window element (row r, pixel px, channel c), read in memory order
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + 256 * k;
       const int r = i / 102, rem = i - r * 102, px = rem / 3, c = rem - px * 3;
       const int yy = y0 - 1 + r, xx = x0 - 1 + px;
-      win[buf][(r * 3 + c) * PW + px] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[((size_t)yy * W + xx) * 3 + c] : 0.f;
+      v[k] = (i < 4 * 34 * 3 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[((size_t)yy * W + xx) * 3 + c] : 0.f;
     }
-    __syncthreads();  // one barrier per tile: the other buffer is being read by nobody (everyone passed this point)
+  };
+  auto win_store = [&](int bf, const float (&v)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + 256 * k;
+      const int r = i / 102, rem = i - r * 102, px = rem / 3, c = rem - px * 3;
+      if (i < 4 * 34 * 3) win[bf][(r * 3 + c) * PW + px] = v[k];
+    }
+  };
+  float nxt[2];
+  if ((long)blockIdx.x < ntile) {
+    win_load(blockIdx.x, nxt);
+    win_store(0, nxt);
+  }
+  __syncthreads();
+  for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x, buf ^= 1) {
+    int b, y0, x0;
+    tile_of(tl, b, y0, x0);
+    if (out_amax && amax_stride && bcur >= 0 && b != bcur) flush(bcur);
+    bcur = b;
+    const bool more = tl + gridDim.x < ntile;
+    if (more) win_load(tl + gridDim.x, nxt);
     float4 a[4] = {bv, bv, bv, bv};
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -649,6 +678,8 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
         vmax = fmaxf(fmaxf(fmaxf(vmax, fabsf(o.x)), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
       }
     }
+    if (more) win_store(buf ^ 1, nxt);
+    __syncthreads();  // one barrier per tile: the next window is complete, this one is read by nobody any more
   }
   if (out_amax && bcur >= 0) flush(amax_stride ? bcur : 0);
 }
