@@ -197,6 +197,9 @@ hipError_t image_colsum_launch(const float* x, int B, long N, int C, float* out,
 hipError_t outer_launch(const float* x, const float* dy, int B, int K, int N, float* c, const float* wcur,
                         float l2, hipStream_t st);
 // dx[b][k] = sum_n W[k][n] dy[b][n] (* (xact[b][k] > 0) when xact != nullptr)
+// both of the above in one pass over W (B <= 8: dy in LDS); same expressions and summation orders
+hipError_t fc_bwd_launch(const float* x, const float* dy, int B, int K, int N, const float* w, float l2, float* dw,
+                         const float* xact, float* dx, hipStream_t st);
 hipError_t gemv_t_launch(const float* w_kn, const float* dy, int B, int K, int N, const float* xact,
                          float* dx, hipStream_t st);
 

@@ -642,9 +642,8 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
     } else {
       const float* wg = P(V + 6) + (size_t)512 * 512;  // [1024][512]
       DISN_TRY(image_colsum_launch(t.d4, B, N, 512, t.dgbias, s.red_ws, st));
-      DISN_TRY(outer_launch(t.emb, t.dgbias, B, DISN_EMBED_DIM, 512, G(V + 6) + (size_t)512 * 512, wg,
-                            wd, st));
-      DISN_TRY(gemv_t_launch(wg, t.dgbias, B, DISN_EMBED_DIM, 512, nullptr, t.demb, st));
+      DISN_TRY(fc_bwd_launch(t.emb, t.dgbias, B, DISN_EMBED_DIM, 512, wg, wd, G(V + 6) + (size_t)512 * 512, nullptr,
+                             t.demb, st));
     }
     DISN_TRY(relu_bwd_colsum_launch(t.d3, h3, M, 512, 1, G(V + 5), s.red_ws, st));
     // fold1/conv3 (256 -> 512), conv2 (64 -> 256), conv1 (3 -> 64)
@@ -662,14 +661,11 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
       }
       float* r2 = t.red_aux;
       DISN_TRY(relu_bwd_colsum_launch(t.demb, nullptr, B, DISN_EMBED_DIM, 0, G(V_FC + 5), r2, as));
-      DISN_TRY(outer_launch(t.h7, t.demb, B, 4096, DISN_EMBED_DIM, G(V_FC + 4), P(V_FC + 4), wd, as));
-      DISN_TRY(gemv_t_launch(P(V_FC + 4), t.demb, B, 4096, DISN_EMBED_DIM, t.h7, t.dz7, as));
+      DISN_TRY(fc_bwd_launch(t.h7, t.demb, B, 4096, DISN_EMBED_DIM, P(V_FC + 4), wd, G(V_FC + 4), t.h7, t.dz7, as));
       DISN_TRY(relu_bwd_colsum_launch(t.dz7, nullptr, B, 4096, 0, G(V_FC + 3), r2, as));
-      DISN_TRY(outer_launch(t.h6, t.dz7, B, 4096, 4096, G(V_FC + 2), P(V_FC + 2), wd, as));
-      DISN_TRY(gemv_t_launch(P(V_FC + 2), t.dz7, B, 4096, 4096, t.h6, t.dz6, as));
+      DISN_TRY(fc_bwd_launch(t.h6, t.dz7, B, 4096, 4096, P(V_FC + 2), wd, G(V_FC + 2), t.h6, t.dz6, as));
       DISN_TRY(relu_bwd_colsum_launch(t.dz6, nullptr, B, 4096, 0, G(V_FC + 1), r2, as));
-      DISN_TRY(outer_launch(pool5, t.dz6, B, 25088, 4096, G(V_FC), P(V_FC), wd, as));
-      DISN_TRY(gemv_t_launch(P(V_FC), t.dz6, B, 25088, 4096, nullptr, t.dpool5, as));
+      DISN_TRY(fc_bwd_launch(pool5, t.dz6, B, 25088, 4096, P(V_FC), wd, G(V_FC), nullptr, t.dpool5, as));
       if (ctx) DISN_TRY(hipEventRecord(ctx->ev[4], as));
     }
   }
