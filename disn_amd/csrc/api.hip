@@ -111,7 +111,7 @@ int conv3x3_impl(const float* in, int B, int H, int W, int Cin, const float* w_p
 // ---- point MLP ----------------------------------------------------------------
 const int kChunk = 65536;  // points per MLP pass inside disn_query / disn_sdf_mlp
 
-const int kH2Imgs = 32;  // images per call the dense_h2 path keeps maximum slots for (32 x 2048 points = kChunk)
+const int kH2Imgs = 512;  // images per call the dense_h2 path keeps maximum slots for (512 x 128 points = kChunk)
 
 struct MlpWs {
   // local stream: e1l -> h256 -> h512a -> (with feat) h512b -> l5
@@ -251,69 +251,6 @@ int mlp_phase1_h2(const disn_mlp_weights_t* w, int n, const float* feat, int fea
   DISN_TRY(dense_h2_launch(&p4, 1, st));
   const DenseH2Prob p5 = h2_batched(h2_prob(s.h512b + o * 512, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5 + o * 256, nullptr, n), imgs, n);
   DISN_TRY(dense_h2_launch(&p5, 1, st));
-  return 0;
-}
-
-// The local fold2/conv1 of a BATCHED call (>= kConvWideMinImages images, dense_h2w.hip) in three K ranges of the one
-// packed matrix l_d4 (rows: 512 point features | 1472 feature columns | 64 zero rows), each started as soon as its
-// inputs exist -- on the auxiliary stream, under the convolutions still to come:
-//   range 0 -- [h512a | feat columns 0..383]   . W[0..896)     behind conv3_3 (gather of taps 0..2 = columns 0..447);
-//   range 1 -- feat columns 384..895           . W[896..1408)  behind conv4_3 (gather of tap 3 = columns 448..959);
-//   range 2 -- feat columns 896..1535          . W[1408..2048) behind conv5_3 (gather of tap 4 + the zero padding),
-//              + bias, ReLU, then fold2/conv2.
-// Ranges 0 and 1 leave / add to the fp32 partial product `pre` (no bias, no ReLU); 640 of the 2048 columns are all
-// that is left behind conv5_3.  Operand scales: an image's maxima of h512a and of each gather's columns (the
-// per-workgroup entries the three gathers leave in the slot set's tail, kGatherSlots apart); a range that reads
-// columns of two gathers takes both maxima.
-struct L4Plan { int n; int cut[4]; int tap[4]; int leg_end[3]; };   // n ranges; feature-column cuts; tap cuts; last conv layer + 1 of each leg
-constexpr L4Plan kL4Plan3 = {3, {0, 384, 896, 1536}, {0, 3, 4, 5}, {7, 10, 13}};
-constexpr L4Plan kL4Plan2 = {2, {0, 896, 1536, 0}, {0, 4, 5, 0}, {10, 13, 0}};   // conv4_3 / conv5_3 only (measured beside it, r03)
-// Measured (tools/bench_knobs.py l4_ranges=0/2/3, profiles/r03h_bench_l4.txt; points/s at --steps 20 / steady state /
-// one call at a time): one piece behind conv5_3 9.99 / 12.65 / 11.50 M, two ranges 10.45 / 12.26 / 11.69 M, three
-// 10.13 / 11.84 / 11.65 M -- the gathers running beside the convolutions cost those more than the shorter tail returns
-// once calls overlap anyway; two ranges are the best latency of a call and the default.
-inline const L4Plan& l4_plan() { return tune::l4_ranges == 3 ? kL4Plan3 : kL4Plan2; }
-constexpr int kGatherSlots = 144;                    // entries per gather: floats 576 + 144 r .. of a slot set
-
-int gather_entries(int n, int feat_ld, int r) {
-  const L4Plan& P = l4_plan();
-  const int g = project_gather_taps_amax_blocks(n, feat_ld, P.tap[r], P.tap[r + 1]);
-  return g < kGatherSlots ? g : kGatherSlots;
-}
-
-int mlp_l4_gather(float* const taps[5], const float* trans_mat, const float* pts, int B, int n, float* feat, int feat_ld,
-                  const MlpWs& s, int r, hipStream_t st) {
-  const L4Plan& P = l4_plan();
-  DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, n, P.tap[r], P.tap[r + 1], feat, st, feat_ld,
-                                      h2_slots(s, 0) + kFeatMaxSlot + kGatherSlots * r, 1024, kGatherSlots));
-  return 0;
-}
-
-int mlp_l4_range_h2(const disn_mlp_weights_t* w, int n, const float* feat, int feat_ld, const MlpWs& s, int imgs, int r,
-                    hipStream_t st) {
-  float* A = h2_slots(s, 0);
-  const L4Plan& P = l4_plan();
-  const int kf = P.cut[r + 1] - P.cut[r];             // feature columns of this range
-  const bool last = r == P.n - 1;
-  DenseH2Prob p{};
-  if (r == 0) {
-    p = h2_prob(s.h512a, 512 + kf, w->l_d4, s.zero512, 512, 0, A + 320, s.h512b, nullptr, n);
-    p.lda = 512; p.k1 = 512; p.a2 = feat; p.lda2 = feat_ld;
-    p.in_amax2 = A + kFeatMaxSlot; p.in_amax2_n = gather_entries(n, feat_ld, 0);
-  } else {
-    p = h2_prob(feat + P.cut[r], kf, w->l_d4, last ? w->l_b4 : s.zero512, 512, last ? 1 : 0,
-                A + kFeatMaxSlot + kGatherSlots * (r - 1), s.h512b, last ? A + 512 : nullptr, n);
-    p.lda = feat_ld; p.add_in = s.h512b; p.k_begin = 512 + P.cut[r];
-    p.in_amax_n = gather_entries(n, feat_ld, r - 1);
-    p.in_amax2 = A + kFeatMaxSlot + kGatherSlots * r; p.in_amax2_n = gather_entries(n, feat_ld, r);
-  }
-  p.Kimg = 2048;
-  p = h2_batched(p, imgs, n);
-  DISN_TRY(dense_h2_launch(&p, 1, st));
-  if (last) {
-    const DenseH2Prob p5 = h2_batched(h2_prob(s.h512b, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5, nullptr, n), imgs, n);
-    DISN_TRY(dense_h2_launch(&p5, 1, st));
-  }
   return 0;
 }
 
@@ -967,10 +904,6 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   const bool h2 = two && B <= kH2Imgs && mlp_h2(mw, N);   // small point sets: the dense_h2 layers, image by image
   const int feat_ld = h2 && !featmap ? kFeatPad : DISN_FEAT_DIM;
   const int hb = h2 && N % 64 == 0 ? B : 1;   // images per h2 launch
-  // a batched call (the form of conv_h2w.hip / dense_h2w.hip): the local fold2/conv1 in two K ranges, the first one and
-  // ranges and the taps' gathers started behind conv3_3 / conv4_3 / conv5_3 (see mlp_l4_range_h2)
-  const bool split_l4 = h2 && hb == B && B >= tune::conv_wide_min && N % 128 == 0 && !featmap && feat_ld == kFeatPad &&
-                        tune::l4_ranges >= 2;
   if (two) {
     DISN_TRY(hipEventRecord(ctx->ev[0], st));  // fork (orders aux behind the caller's inputs)
     DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
@@ -991,40 +924,20 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
       if ((rc = mlp_g4_pre(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws2, ctx->aux))) return rc;
     }
     DISN_TRY(hipEventRecord(ctx->ev[8], ctx->aux));
-    if (split_l4) {
-      // the convolutions in three legs; behind each leg the auxiliary stream gathers the taps that leg finished and
-      // runs the matching K range of the local fold2/conv1 (mlp_l4_range_h2) under the next leg
-      static const int leg_ev[3] = {5, 9, 7};
-      const L4Plan& P = l4_plan();
-      int i0 = 2;
-      for (int r = 0; r < P.n; ++r) {
-        const int ev = r == P.n - 1 ? 7 : leg_ev[r];
-        rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, i0, P.leg_end[r]);
-        if (rc) return rc;
-        i0 = P.leg_end[r];
-        DISN_TRY(hipEventRecord(ctx->ev[ev], st));
-        DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[ev], 0));
-        if ((rc = mlp_l4_gather(taps, trans_mat, pts, B, N, e.q.feat, feat_ld, e.q.mlp, r, ctx->aux))) return rc;
-        if ((rc = mlp_l4_range_h2(mw, N, e.q.feat, feat_ld, e.q.mlp, B, r, ctx->aux))) return rc;
-      }
-    } else {
-      rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 2, 13);
-    }
+    rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st, 2, 13);
     if (rc) return rc;
     // the gather from the taps on the caller's stream, BEFORE the fc head: alone it takes 14 us, under fc6's HBM
     // stream 65-70 us (r02q trace) -- and the local fold2 layers behind it are the critical path of the tail
     // The kernel also leaves max |feat| per image in the slots the local fold2/conv1 reads its scale from (cleared
     // by pt_embed on the auxiliary stream, hence the ev[8] wait first -- recorded a whole convolution stack ago).
-    gather_on_st = h2 && !featmap && !split_l4;
+    gather_on_st = h2 && !featmap;
     DISN_TRY(hipStreamWaitEvent(st, ctx->ev[8], 0));   // (recorded behind g4_pre, a whole convolution stack ago)
     if (gather_on_st)
       DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, st, feat_ld,
                                           h2_slots(e.q.mlp, 0) + kFeatMaxSlot, 1024));
     if (ctx->pipe_record) DISN_TRY(hipEventRecord(ctx->pipe_record, st));  // the next step's convolutions may start
-    if (!split_l4) {
-      DISN_TRY(hipEventRecord(ctx->ev[7], st));
-      DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
-    }
+    DISN_TRY(hipEventRecord(ctx->ev[7], st));
+    DISN_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev[7], 0));
     if (!h2 && (rc = mlp_fold1_local(mw, B * N, e.q.mlp, e.q.mlp.gemm_ws, ctx->aux))) return rc;
   } else {
     rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, featmap, e.vgg, &pool5, st);
@@ -1032,7 +945,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     if ((rc = mlp_phase0(mw, pts_rot, B * N, e.q.mlp, st))) return rc;
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
-  if (gather_on_st || split_l4) {
+  if (gather_on_st) {
     // done above
   } else if (featmap) {
     const size_t map_stride = (size_t)DISN_IMG_H * DISN_IMG_W * DISN_FEAT_DIM;
@@ -1043,9 +956,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   } else {  // no map: up-sample the taps at the touched pixels (bit-identical), all images in one launch
     DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, e.q.feat, ms, feat_ld));
   }
-  if (split_l4) {
-    // done above: gathers and the three K ranges are on the auxiliary stream
-  } else if (h2) {
+  if (h2) {
     for (int b = 0; b < B; b += hb) {
       const size_t o = (size_t)b * N;
       if ((rc = mlp_phase1_h2(mw, N, e.q.feat + o * feat_ld, feat_ld, e.q.mlp, b, o, hb, ms, gather_on_st))) return rc;

@@ -23,7 +23,7 @@ extern int conv_occ_min; // from this many workgroups per launch on
 extern int aux_cu_mode;  // > 0: disn_ctx_create puts the auxiliary stream on a CU subset (hipExtStreamCreateWithCUMask)
 extern int conv_img_major;  // 0 / 1: force conv_h2's tile order (n-tile-major / image-major); -1: by shape
 extern int conv_wide_min;  // images per call from which conv_h2_launch takes conv_h2w.hip (1 << 30: never)
-extern int l4_ranges;     // K ranges of the local fold2/conv1 of a batched call: 0 = one piece behind conv5_3, 2, 3 (api.hip, L4Plan)
+extern int l4_ranges;     // retired (round 4): the K ranges of the local fold2/conv1 of a batched call went with the fused small-set kernels
 extern int gather_l16;    // 1: project_gather_taps_kernel issues its 16 tap loads before using any (0, default: tap_pixel by tap_pixel --
                           // measured FASTER: 84 vs 105 us for 8 x 2048 points, profiles/r03h_gather_time.txt)
 extern int tn_interleave;  // -1: by form and tile count (default); 0 / 1: never / always interleaved row steps in the weight-gradient GEMM
