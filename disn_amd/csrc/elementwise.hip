@@ -503,128 +503,6 @@ __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
   }
 }
 
-// ---------------------------------------------------------------------------
-// Round 4: the split-form gather of a batched call with the per-point work done ONCE per point.
-// project_gather_taps_kernel derives, in each of a point's 368 threads, the projection (two IEEE divisions), the four
-// resampler corners and, per corner, the four tap pixels and lerp weights of the up-sample -- ~450 vector instructions
-// per 16-byte load group, two 64-bit index divisions among them: the kernel is VALU-bound (0.22 ms for 16 x 2048
-// points).  Here a workgroup of 384 threads takes 16 consecutive points (one image: n % 16 == 0): 320 threads compute the
-// (point, tap, corner) parameter sets -- tap-pixel offsets, lerp weights, corner weight, validity: 32 bytes each -- into
-// LDS, then thread t (one fixed channel quad 4 t of one fixed tap) walks the 16 points reading its tap's four sets
-// (broadcast reads) and does only what differs per channel: 16 loads, the lerps, the weighted sum, the split.  The
-// expressions and their order are the ones of tap_pixel / sample4: the rows are bit-identical to the split of
-// project_gather_taps_kernel's (tests/test_gpu_fused.py::test_split_form_gather_is_the_fp32_gather_split).
-// ---------------------------------------------------------------------------
-struct TapCorner {
-  int o00, o01, o10, o11;   // float offsets of the corner's four tap pixels (tl, tr, bl, br) within the image's tap
-  float xl, yl, w;          // lerp weights of the up-sample, resampler weight of the corner
-  unsigned valid;           // all ones: the corner lies in the map; 0: it contributes zeros
-};
-
-__global__ __launch_bounds__(384) void gather_taps_split_kernel(TapSet t, const float* __restrict__ trans_mat,
-                                                                const float* __restrict__ pts, int B, int n,
-                                                                unsigned char* __restrict__ feat,
-                                                                const float* __restrict__ split_amax) {
-  constexpr int PB = 16;
-  __shared__ __attribute__((aligned(16))) TapCorner prm[PB][5][4];
-  const int tid = threadIdx.x;
-  const int c = 4 * tid;                       // this thread's channel quad of the 1536-column row (1472 real)
-  const bool pad = c >= DISN_FEAT;
-  const int k = c < 64 ? 0 : (c < 192 ? 1 : (c < 448 ? 2 : (c < 960 ? 3 : 4)));
-  const int cl = pad ? 0 : c - (k == 0 ? 0 : (k == 1 ? 64 : (k == 2 ? 192 : (k == 3 ? 448 : 960))));
-  const long total = (long)B * n;
-  for (long p0 = (long)blockIdx.x * PB; p0 < total; p0 += (long)gridDim.x * PB) {
-    const int b = (int)(p0 / n);               // the 16 points belong to one image
-    if (tid < PB * 20) {                       // (point q, tap kk, corner cc in sample4's order ff, cc, fc, cf)
-      const int q = tid / 20, kc = tid - q * 20, kk = kc >> 2, cc = kc & 3;
-      const long pt = p0 + q;
-      float x, y;
-      project_point(trans_mat + (size_t)b * 12, pts[pt * 3], pts[pt * 3 + 1], pts[pt * 3 + 2], x, y);
-      const bool ok = x > -1.0f && y > -1.0f && x < (float)DISN_IMG && y < (float)DISN_IMG;
-      const float fx = floorf(x), fy = floorf(y);
-      const float cx = fx + 1.0f, cy = fy + 1.0f;
-      const float dx = cx - x, dy = cy - y;
-      const int ifx = ok ? (int)fx : 0, ify = ok ? (int)fy : 0, icx = ok ? (int)cx : 0, icy = ok ? (int)cy : 0;
-      const bool xf = ifx >= 0 && ifx < DISN_IMG, xc = icx >= 0 && icx < DISN_IMG;
-      const bool yf = ify >= 0 && ify < DISN_IMG, yc = icy >= 0 && icy < DISN_IMG;
-      const float w = cc == 0 ? dx * dy : (cc == 1 ? (1.0f - dx) * (1.0f - dy) : (cc == 2 ? dx * (1.0f - dy) : (1.0f - dx) * dy));
-      const bool valid = ok && (cc == 0 ? (xf && yf) : (cc == 1 ? (xc && yc) : (cc == 2 ? (xf && yc) : (xc && yf))));
-      const int oy = valid ? (cc == 0 || cc == 3 ? ify : icy) : 0, ox = valid ? (cc == 0 || cc == 2 ? ifx : icx) : 0;
-      // tap_pixel's coordinates
-      const int hw = 224 >> kk;
-      const int ch = kk == 0 ? 64 : (kk == 1 ? 128 : (kk == 2 ? 256 : 512));
-      const float sk = t.s[kk];
-      const float ty = (float)oy * sk, tx = (float)ox * sk;
-      const int ylo = (int)floorf(ty), xlo = (int)floorf(tx);
-      const int yhi = min(ylo + 1, hw - 1), xhi = min(xlo + 1, hw - 1);
-      TapCorner P;
-      P.o00 = (ylo * hw + xlo) * ch; P.o01 = (ylo * hw + xhi) * ch;
-      P.o10 = (yhi * hw + xlo) * ch; P.o11 = (yhi * hw + xhi) * ch;
-      P.yl = ty - (float)ylo; P.xl = tx - (float)xlo;
-      P.w = ok ? w : 0.f;
-      P.valid = valid ? 0xffffffffu : 0u;
-      prm[q][kk][cc] = P;
-    }
-    __syncthreads();
-    const float* tapb = t.p[k] + (size_t)b * t.stride[k] + cl;
-    const float sc = split_pow2_scale(feat_split_amax(split_amax[b]));
-    for (int q = 0; q < PB; ++q) {
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!pad) {
-        float4 vc[4];
-        float wc[4];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const TapCorner P = prm[q][k][cc];
-          const float4 tl = *reinterpret_cast<const float4*>(tapb + P.o00);
-          const float4 tr = *reinterpret_cast<const float4*>(tapb + P.o01);
-          const float4 bl = *reinterpret_cast<const float4*>(tapb + P.o10);
-          const float4 br = *reinterpret_cast<const float4*>(tapb + P.o11);
-          float4 v;
-#define DISN_LERP(f)                               \
-  {                                                \
-    const float top = tl.f + (tr.f - tl.f) * P.xl; \
-    const float bot = bl.f + (br.f - bl.f) * P.xl; \
-    v.f = __uint_as_float(__float_as_uint(top + (bot - top) * P.yl) & P.valid); \
-  }
-          DISN_LERP(x) DISN_LERP(y) DISN_LERP(z) DISN_LERP(w)
-#undef DISN_LERP
-          vc[cc] = v;
-          wc[cc] = P.w;
-        }
-#define DISN_ACC(f)             \
-  {                             \
-    float v = wc[0] * vc[0].f;  \
-    v = v + wc[1] * vc[1].f;    \
-    v = v + wc[2] * vc[2].f;    \
-    v = v + wc[3] * vc[3].f;    \
-    o.f = v;                    \
-  }
-        DISN_ACC(x) DISN_ACC(y) DISN_ACC(z) DISN_ACC(w)
-#undef DISN_ACC
-      }
-      const float xs[4] = {o.x * sc, o.y * sc, o.z * sc, o.w * sc};
-      _Float16 hh[4], ll[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        hh[e] = (_Float16)xs[e];
-        ll[e] = (_Float16)(xs[e] - (float)hh[e]);
-      }
-      // lanes 2i, 2i + 1 hold the halves of one 8-channel group: one 16-byte store each (h8 | l8), as
-      // project_gather_taps_kernel's split form
-      const uint2 hv = *reinterpret_cast<const uint2*>(hh), lv = *reinterpret_cast<const uint2*>(ll);
-      const bool odd = (tid & 1) != 0;
-      const uint2 send = odd ? hv : lv;
-      uint2 recv;
-      recv.x = (unsigned)__shfl_xor((int)send.x, 1);
-      recv.y = (unsigned)__shfl_xor((int)send.y, 1);
-      const uint4 out = odd ? make_uint4(recv.x, recv.y, lv.x, lv.y) : make_uint4(hv.x, hv.y, recv.x, recv.y);
-      *reinterpret_cast<uint4*>(feat + ((size_t)(p0 + q) * 1536 + (size_t)(c & ~7)) * 4 + (odd ? 16 : 0)) = out;
-    }
-    __syncthreads();   // the parameter sets are read: the next batch may overwrite them
-  }
-}
-
 // workgroups per image of the launch with maxima (1024 threads each) -- the count of entries the consumer reads.
 // All five taps: up to 448 entries (the free tail of an image's slot set, api.hip); a tap RANGE (the two gathers of a
 // batched call: taps 0..3 behind conv4_3, tap 4 behind conv5_3): up to 224, the two launches' entries side by side.
@@ -652,12 +530,6 @@ hipError_t project_gather_taps_launch(const float* const taps[5], const float* t
     t.stride[k] = (size_t)(224 >> k) * (224 >> k) * ch[k];
   }
   if (feat_ld <= 0) feat_ld = DISN_FEAT;
-  if (split_amax && !amax && tap_begin == 0 && tap_end == 5 && feat_ld == 1536 && n % 16 == 0 && !tune::gather_l16) {
-    const long batches = (long)B * n / 16;
-    hipLaunchKernelGGL(gather_taps_split_kernel, dim3((unsigned)(batches < 4096 ? batches : 4096)), dim3(384), 0, st, t,
-                       trans_mat, pts, B, n, reinterpret_cast<unsigned char*>(feat), split_amax);
-    return hipGetLastError();
-  }
   const int c4_begin = c4_off[tap_begin];
   const int c4_count = (tap_end == 5 && feat_ld > DISN_FEAT ? feat_ld / 4 : c4_off[tap_end]) - c4_begin;
   const size_t total = (size_t)B * n * c4_count;
