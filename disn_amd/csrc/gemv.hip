@@ -15,7 +15,8 @@ template <int NB>
 __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, int K,
                                                    const float* __restrict__ w, int N,
                                                    float* __restrict__ partial, int Btot, int b0) {
-  __shared__ float red[4][NB][256];
+  constexpr int RB = NB > 8 ? 8 : NB;       // batch rows per reduction round (sixteen rows: two rounds through 32 KB)
+  __shared__ float red[4][RB][256];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int S = gridDim.y, z = blockIdx.y;
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
 #pragma unroll
   for (int b = 0; b < NB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* wp = w + col;
-#pragma unroll 8
+#pragma unroll(NB > 8 ? 4 : 8)
   for (int k = kbeg + wave; k < kend; k += 4) {
     // streamed once: non-temporal, so the 411 MB of fc6 do not evict the activations from L2 / MALL
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -37,19 +38,23 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
       acc[b].x += xv * wv.x; acc[b].y += xv * wv.y; acc[b].z += xv * wv.z; acc[b].w += xv * wv.w;
     }
   }
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    red[wave][b][lane * 4 + 0] = acc[b].x;
-    red[wave][b][lane * 4 + 1] = acc[b].y;
-    red[wave][b][lane * 4 + 2] = acc[b].z;
-    red[wave][b][lane * 4 + 3] = acc[b].w;
-  }
-  __syncthreads();
   const int t = threadIdx.x;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const float v = (red[0][b][t] + red[1][b][t]) + (red[2][b][t] + red[3][b][t]);
-    partial[((size_t)z * Btot + b0 + b) * N + blockIdx.x * 256 + t] = v;
+  for (int r0 = 0; r0 < NB; r0 += RB) {
+    if (r0) __syncthreads();
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      red[wave][b][lane * 4 + 0] = acc[r0 + b].x;
+      red[wave][b][lane * 4 + 1] = acc[r0 + b].y;
+      red[wave][b][lane * 4 + 2] = acc[r0 + b].z;
+      red[wave][b][lane * 4 + 3] = acc[r0 + b].w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const float v = (red[0][b][t] + red[1][b][t]) + (red[2][b][t] + red[3][b][t]);
+      partial[((size_t)z * Btot + b0 + r0 + b) * N + blockIdx.x * 256 + t] = v;
+    }
   }
 }
 
@@ -163,7 +168,16 @@ hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const fl
                        int relu, float* out, float* ws, hipStream_t st) {
   const int S = gemv_splits(K, N, B);
   dim3 grid(N / 256, S);
-  for (int b0 = 0; b0 < B; b0 += 8) {
+  for (int b0 = 0; b0 < B;) {
+    // sixteen batch rows per pass where there are that many left (round 4: fc6's 411 MB once per 16-image call instead
+    // of twice -- every row's sum is the same instruction sequence whatever NB: the bits are the eight-row pass's)
+    if (B - b0 >= 16) {
+      hipLaunchKernelGGL((gemv_kernel<16>), grid, dim3(256), 0, st, x, K, w_kn, N, ws, B, b0);
+      const hipError_t e16 = hipGetLastError();
+      if (e16 != hipSuccess) return e16;
+      b0 += 16;
+      continue;
+    }
     const int nb = (B - b0) < 8 ? (B - b0) : 8;
     switch (nb) {
 #define DISN_GEMV_CASE(NB)                                                                  \
@@ -176,6 +190,7 @@ hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const fl
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    b0 += nb;
   }
   return splitk_reduce_launch(ws, S, B, N, bias, 0, relu, out, N, st);
 }
