@@ -48,7 +48,7 @@ if has prof; then
   for f in $(find /tmp/profm_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/bench_kernel_stats.csv; done
   # (a2) one call of eight steps at a time: the launch sequence of a batched call
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/profb4_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 16 --no-extras --in-flight 1 --batch 16 --spinup-s 0 > /tmp/profb4_$TAG.log 2>&1; echo "rocprof b4 exit $?")
-  python tools/trace_step.py $(find /tmp/profb4_$TAG -name "*kernel_trace.csv") resize_kernel 2>/dev/null | grep -v "at::native\|rocclr_copy" > $OUT/infer_call_b16_trace.txt; tail -2 $OUT/infer_call_b16_trace.txt
+  python tools/trace_step.py $(find /tmp/profb4_$TAG -name "*kernel_trace.csv") resize_kernel - 2 2>/dev/null | grep -v "at::native\|rocclr_copy" > $OUT/infer_call_b16_trace.txt; tail -2 $OUT/infer_call_b16_trace.txt
   # (b) one step at a time: the launch sequence of a step
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-extras --in-flight 1 --batch 1 > /tmp/prof_$TAG.log 2>&1; echo "rocprof exit $?")
   for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/bench_single_kernel_stats.csv; done
