@@ -667,10 +667,12 @@ hipError_t gemm_launch(const GemmParams& p, GemmMode mode, const GemmPlan& plan,
 }
 
 hipError_t splitk_reduce_launch(const float* ws, int S, int M, int N, const float* bias,
-                                int rows_per_bias, int relu, float* out, int ldc, hipStream_t st) {
+                                int rows_per_bias, int relu, float* out, int ldc, hipStream_t st, int force_sl) {
   const size_t total = (size_t)M * (N / 4);
-  // enough column groups to fill the chip -> 1 s-lane; otherwise spread S over 4 or 16 lanes
-  const int sl = (total >= 131072 || S < 4) ? 1 : ((total >= 16384 || S < 16) ? 4 : 16);
+  // enough column groups to fill the chip -> 1 s-lane; otherwise spread S over 4 or 16 lanes.  force_sl (1, 4, 16): the
+  // caller fixes the lane count -- and with it the summation order -- whatever M (the fc layers of a batched call: a
+  // row's bits must not depend on how many rows travel with it)
+  const int sl = force_sl ? force_sl : (total >= 131072 || S < 4) ? 1 : ((total >= 16384 || S < 16) ? 4 : 16);
   const int cg = 256 / sl;
   const unsigned blocks = (unsigned)((total + cg - 1) / cg);
   switch (sl) {

@@ -1,6 +1,8 @@
 // Small-batch fully-connected layers: out[b][n] = act(sum_k x[b][k] W[k][n] + bias[n]).
-// VGG fc6/fc7/fc8 at B <= 8 (models/CNN/vgg.py:198-214) and the per-image fold of the
+// VGG fc6/fc7/fc8 (models/CNN/vgg.py:198-214) and the per-image fold of the
 // global-feature block of sdfprediction/fold2/conv1 (models/sdfnet.py:78-84).
+// One to three rows (a step at a time): gemv_kernel<NB> (fc6) / gemv_rows_kernel (fc7, fc8, the fold); four rows and
+// more (a batched call): gemv_mfma_kernel, sixteen rows per pass on the fp32 matrix pipe.
 //
 // Bound: HBM (weight read): fc6 alone is 411 MB per forward.  Each wave streams whole
 // 1-KiB row segments of W (64 lanes x float4, coalesced), four waves of a block take
@@ -15,7 +17,7 @@ template <int NB>
 __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, int K,
                                                    const float* __restrict__ w, int N,
                                                    float* __restrict__ partial, int Btot, int b0) {
-  constexpr int RB = NB > 8 ? 8 : NB;       // batch rows per reduction round (sixteen rows: two rounds through 32 KB)
+  constexpr int RB = NB;
   __shared__ float red[4][RB][256];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -26,7 +28,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
 #pragma unroll
   for (int b = 0; b < NB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* wp = w + col;
-#pragma unroll(NB > 8 ? 4 : 8)
+#pragma unroll 8
   for (int k = kbeg + wave; k < kend; k += 4) {
     // streamed once: non-temporal, so the 411 MB of fc6 do not evict the activations from L2 / MALL
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -54,6 +56,95 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
     for (int b = 0; b < RB; ++b) {
       const float v = (red[0][b][t] + red[1][b][t]) + (red[2][b][t] + red[3][b][t]);
       partial[((size_t)z * Btot + b0 + r0 + b) * N + blockIdx.x * 256 + t] = v;
+    }
+  }
+}
+
+// Four batch rows and more (a batched call): the same split-K stream with the products on the fp32 matrix pipe.
+// v_mfma_f32_16x16x1_4B_f32 is four independent 16 x 16 x 1 outer products: block q = lane / 16 multiplies
+// A[q][i = lane % 16] (here: batch row i's x[k], the same in the four blocks) by B[q][j = lane % 16] -- and a lane's
+// float4 of a 1-KiB weight row segment (columns 4 lane .. 4 lane + 3) IS such a B operand for each of its four
+// components: a weight row costs one 16-byte load and four MFMAs (128 matrix-pipe cycles per SIMD) whatever the number of
+// batch rows up to sixteen, against 4 NB FMAs + NB scalar loads of gemv_kernel<NB> (sixteen rows: 96 us for fc6's 411 MB
+// where one row takes 65).  acc[c][r] of lane l: batch row 4 (l / 16) + r % 4, column 64 (r / 4) + 4 (l % 16) + c of the
+// workgroup's 256.  A wave takes FOUR consecutive k rows per step (x as one float4 per lane), the workgroup's four waves
+// consecutive steps; partial slabs and reduce pass as before.  Summation order of one output: k ascending inside a wave
+// (one product per MFMA), (w0 + w1) + (w2 + w3), then splitk_reduce_kernel: fixed by (K, N, S) -- never by the batch.
+__global__ __launch_bounds__(256) void gemv_mfma_kernel(const float* __restrict__ x, int K,
+                                                        const float* __restrict__ w, int N,
+                                                        float* __restrict__ partial, int Btot, int b0) {
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  __shared__ float red[4][8][4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int S = gridDim.y, z = blockIdx.y;
+  const int K4 = K >> 2;
+  const int kbeg = 4 * (int)(((long)K4 * z) / S), kend = 4 * (int)(((long)K4 * (z + 1)) / S);
+  const int col0 = blockIdx.x * 256;
+  const int row = lane & 15;
+  const bool live = b0 + row < Btot;
+  const float* xr = x + (size_t)(live ? b0 + row : b0) * K;
+  const float* wp = w + col0 + lane * 4;
+  v16f acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  // two register sets: the four row segments (and the x float4) of step i + 1 are requested before the sixteen MFMAs of
+  // step i are issued (left to itself the compiler waits for every load right behind its issue: one KiB in flight per wave)
+  float4 wv[2][4], xv[2];
+  auto load = [&](int k, float4 (&wq)[4], float4& xq) {
+    const int kk = k < kend ? k : kbeg;            // past the end: a valid address, the values are not used
+    xq = *reinterpret_cast<const float4*>(xr + kk);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wq[e] = nt_load4(wp + (size_t)(kk + e) * N);
+  };
+  auto mac = [&](const float4 (&wq)[4], float4 xq) {
+    if (!live) xq = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float xe[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[e], wq[e].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[e], wq[e].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[e], wq[e].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[e], wq[e].w, acc[3], 0, 0, 0);
+    }
+  };
+  const int k0 = kbeg + 4 * wave;
+  const int n = k0 < kend ? (kend - k0 + 15) >> 4 : 0;   // steps of this wave
+  load(k0, wv[0], xv[0]);
+  for (int i = 0; i + 1 < n; i += 2) {                   // the same loads in flight at the top from both entries
+    load(k0 + 16 * (i + 1), wv[1], xv[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mac(wv[0], xv[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    load(k0 + 16 * (i + 2), wv[0], xv[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mac(wv[1], xv[1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (n & 1) mac(wv[0], xv[0]);
+  // (w0 + w1) + (w2 + w3) through LDS, eight accumulator registers (two column blocks of 64) per round
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int r0 = 0; r0 < 16; r0 += 8) {
+    if (r0) __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) red[wave][rr][c][lane] = acc[c][r0 + rr];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int u = h * 256 + t, rr = u >> 6, l = u & 63;
+      float o[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = (red[0][rr][c][l] + red[1][rr][c][l]) + (red[2][rr][c][l] + red[3][rr][c][l]);
+      const int r = r0 + rr;
+      const int brow = b0 + 4 * (l >> 4) + (r & 3);
+      if (brow < Btot)
+        *reinterpret_cast<float4*>(partial + ((size_t)z * Btot + brow) * N + col0 + 64 * (r >> 2) + 4 * (l & 15)) =
+            make_float4(o[0], o[1], o[2], o[3]);
     }
   }
 }
@@ -168,16 +259,17 @@ hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const fl
                        int relu, float* out, float* ws, hipStream_t st) {
   const int S = gemv_splits(K, N, B);
   dim3 grid(N / 256, S);
-  for (int b0 = 0; b0 < B;) {
-    // sixteen batch rows per pass where there are that many left (round 4: fc6's 411 MB once per 16-image call instead
-    // of twice -- every row's sum is the same instruction sequence whatever NB: the bits are the eight-row pass's)
-    if (B - b0 >= 16) {
-      hipLaunchKernelGGL((gemv_kernel<16>), grid, dim3(256), 0, st, x, K, w_kn, N, ws, B, b0);
-      const hipError_t e16 = hipGetLastError();
-      if (e16 != hipSuccess) return e16;
-      b0 += 16;
-      continue;
+  if (B >= tune::conv_wide_min && K % 4 == 0) {   // a batched call: sixteen rows per pass on the matrix pipe
+    for (int b0 = 0; b0 < B; b0 += 16) {
+      hipLaunchKernelGGL(gemv_mfma_kernel, grid, dim3(256), 0, st, x, K, w_kn, N, ws, B, b0);
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
     }
+    // the lane count a call of four rows gets, for every B (sixteen rows of N = 4096 would otherwise cross the
+    // launcher's threshold and sum the slabs in another order than eight)
+    return splitk_reduce_launch(ws, S, B, N, bias, 0, relu, out, N, st, S < 4 ? 1 : (S < 16 ? 4 : 16));
+  }
+  for (int b0 = 0; b0 < B;) {
     const int nb = (B - b0) < 8 ? (B - b0) : 8;
     switch (nb) {
 #define DISN_GEMV_CASE(NB)                                                                  \

@@ -64,7 +64,7 @@ hipError_t gemm_launch(const GemmParams& p, GemmMode mode, const GemmPlan& plan,
 hipError_t pack_kn_launch(const float* w, int K, int N, int Kpad, float* packed, hipStream_t st);
 // out[m][n] = act(sum_s ws[s][m][n] + bias[row(m)][n])
 hipError_t splitk_reduce_launch(const float* ws, int S, int M, int N, const float* bias,
-                                int rows_per_bias, int relu, float* out, int ldc, hipStream_t st);
+                                int rows_per_bias, int relu, float* out, int ldc, hipStream_t st, int force_sl = 0);
 // the same for an NHWC conv output [B,H,W,N] (H, W even, ldc = N) + its 2x2 max pool -> pool_out
 hipError_t splitk_reduce_pool_launch(const float* ws, int S, int B, int H, int W, int N,
                                      const float* bias, int relu, float* out, float* pool_out,

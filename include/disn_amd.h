@@ -390,7 +390,7 @@ int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, 
  *               (disn_dense_h2's rule); otherwise (B > 32 or N >= 8192) the three-term bf16 / f32-input GEMM chain of
  *               disn_dense.  disn_query / disn_sdf_mlp switch at the same N = 8192 per image.
  *   convolutions / fc head  B < 4: conv_h2.hip + one-launch fc rows; B >= 4: conv_h2w.hip + the split-K fc stream
- *               kernel with fewer splits (disn_conv3x3_h2's rule).
+ *               with up to sixteen batch rows per pass on the fp32 matrix pipe (gemv_mfma_kernel; disn_conv3x3_h2's rule).
  * Every activation scale is per image (per point inside the fused kernels) on all of these paths, so request b's
  * outputs never depend on the other requests of its call, on its position, or on B beyond the thresholds above (B < 4:
  * bit for bit those of a B = 1 call; B >= 4: bit for bit those of any other call of >= 4 requests of the same N). */

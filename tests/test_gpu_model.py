@@ -542,8 +542,14 @@ def test_batched_calls_are_batch_invariant_and_within_the_bar():
         for i, k in enumerate(idx):
             got2[k] = sdf[i:i + 1].clone()
     torch.cuda.synchronize()
+    # ... and one call of all sixteen (bench.py's default call size: sixteen fc rows cross the split-K reduce's
+    # parallelism threshold -- the batched fc layers fix the reduce's lane count for every B)
+    sdf16 = eng.encode_query(torch.cat([j[0] for j in jobs]), torch.cat([j[1] for j in jobs]),
+                             torch.cat([j[2] for j in jobs]))[1]
+    torch.cuda.synchronize()
     for k in range(16):
         assert torch.equal(got[k], got2[k]), "job %d: bits depend on the call it travels in" % k
+        assert torch.equal(got[k], sdf16[k:k + 1]), "job %d: bits of a 16-request call differ from an 8-request call's" % k
     worst1 = worst64 = 0.0
     for k in (0, 7, 13):
         one = eng.encode_query(*jobs[k])[1]
