@@ -571,12 +571,19 @@ __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) voi
 // stores 16-byte channel quads (16 lanes = one pixel = 256 contiguous bytes); per-workgroup maximum -> the 64 slots the
 // first conv_h2 layer scales by.
 // ---------------------------------------------------------------------------------------------------
+// RT: row pairs per tile (tile = 2 RT rows x 32 pixels).  One row pair is ~0.4 us of FMAs behind a 1-2 us window load that one
+// tile of look-ahead cannot hide (72 us per 16 images, where the 205 MB of stores need ~45): RT = 4 puts 1.6 us of work behind
+// every window.
+template <int RT>
 __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                              const float* __restrict__ bias, int B, int H, int W,
                                                              int relu, float* __restrict__ out,
                                                              float* __restrict__ out_amax, int amax_stride) {
   constexpr int PW = 40;                                 // plane pitch in floats (36 used; 160 B keeps 16-byte alignment)
-  __shared__ __attribute__((aligned(16))) float win[2][4 * 3 * PW];   // [buffer][row 0..3][channel][pixel -1 .. 34]
+  constexpr int WR = 2 * RT + 2;                         // window rows
+  constexpr int WE = WR * 34 * 3;                        // window elements
+  constexpr int LQ = (WE + 255) / 256;                   // per thread
+  __shared__ __attribute__((aligned(16))) float win[2][WR * 3 * PW];   // [buffer][row][channel][pixel -1 .. 34]
   __shared__ __attribute__((aligned(16))) float wl[27 * 64];
   __shared__ float red[4];
   const int tid = threadIdx.x, c4 = tid & 15, pg = (tid >> 4) & 7, ry = tid >> 7;   // pixels 4 pg .. 4 pg + 3 of row ry
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
 #pragma unroll
   for (int k = 0; k < 27; ++k) wr[k] = *reinterpret_cast<const float4*>(&wl[k * 64 + 4 * c4]);
   const float4 bv = *reinterpret_cast<const float4*>(bias + 4 * c4);
-  const int segs_x = (W + 31) >> 5, rows2 = (H + 1) >> 1;
+  const int segs_x = (W + 31) >> 5, rows2 = (H + 2 * RT - 1) / (2 * RT);   // tiles per row band, row bands
   const long ntile = (long)B * rows2 * segs_x;
   float vmax = 0.f;
   int buf = 0, bcur = -1;
@@ -611,31 +618,31 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
   auto tile_of = [&](long tl, int& b, int& y0, int& x0) {
     const int sx = (int)(tl % segs_x);
     const long by = tl / segs_x;
-    y0 = 2 * (int)(by % rows2);
+    y0 = 2 * RT * (int)(by % rows2);
     b = (int)(by / rows2);
     x0 = sx * 32;
   };
-  auto win_load = [&](long tl, float (&v)[2]) {   // window element (row r, pixel px, channel c), read in memory order
+  auto win_load = [&](long tl, float (&v)[LQ]) {   // window element (row r, pixel px, channel c), read in memory order
     int b, y0, x0;
     tile_of(tl, b, y0, x0);
     const float* img = in + (size_t)b * H * W * 3;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < LQ; ++k) {
       const int i = tid + 256 * k;
       const int r = i / 102, rem = i - r * 102, px = rem / 3, c = rem - px * 3;
       const int yy = y0 - 1 + r, xx = x0 - 1 + px;
-      v[k] = (i < 4 * 34 * 3 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[((size_t)yy * W + xx) * 3 + c] : 0.f;
+      v[k] = (i < WE && yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[((size_t)yy * W + xx) * 3 + c] : 0.f;
     }
   };
-  auto win_store = [&](int bf, const float (&v)[2]) {
+  auto win_store = [&](int bf, const float (&v)[LQ]) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < LQ; ++k) {
       const int i = tid + 256 * k;
       const int r = i / 102, rem = i - r * 102, px = rem / 3, c = rem - px * 3;
-      if (i < 4 * 34 * 3) win[bf][(r * 3 + c) * PW + px] = v[k];
+      if (i < WE) win[bf][(r * 3 + c) * PW + px] = v[k];
     }
   };
-  float nxt[2];
+  float nxt[LQ];
   if ((long)blockIdx.x < ntile) {
     win_load(blockIdx.x, nxt);
     win_store(0, nxt);
@@ -648,12 +655,14 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
     bcur = b;
     const bool more = tl + gridDim.x < ntile;
     if (more) win_load(tl + gridDim.x, nxt);
+#pragma unroll 1
+    for (int q = 0; q < RT; ++q) {
     float4 a[4] = {bv, bv, bv, bv};
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float* pl = &win[buf][((ry + r) * 3 + c) * PW + 4 * pg];
+        const float* pl = &win[buf][((2 * q + ry + r) * 3 + c) * PW + 4 * pg];
         const float4 v0 = *reinterpret_cast<const float4*>(pl);        // window pixels 4 pg .. 4 pg + 3 (image x0 - 1 + ..)
         const float2 v1 = *reinterpret_cast<const float2*>(pl + 4);    // 4 pg + 4, 4 pg + 5
         const float v[6] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y};
@@ -667,7 +676,7 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
           }
         }
       }
-    const int y = y0 + ry;
+    const int y = y0 + 2 * q + ry;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       float4 o = a[p];
@@ -678,6 +687,7 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
         vmax = fmaxf(fmaxf(fmaxf(vmax, fabsf(o.x)), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
       }
     }
+    }
     if (more) win_store(buf ^ 1, nxt);
     __syncthreads();  // one barrier per tile: the next window is complete, this one is read by nobody any more
   }
@@ -687,10 +697,14 @@ __global__ __launch_bounds__(256) void conv1_1_direct_kernel(const float* __rest
 // w: the TF tensor [3][3][3][64] as is; out_amax: 64 slots (per image when amax_stride > 0) zeroed by the caller, or nullptr
 hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const float* w_hwio, const float* bias, int relu,
                                  float* out, float* out_amax, hipStream_t st, int amax_stride) {
-  const long ntile = (long)B * ((H + 1) / 2) * ((W + 31) / 32);
+  // a step at a time: two-row tiles (784 per image fill the chip); a batched call: eight-row tiles
+  const int rt = B >= tune::conv_wide_min ? (tune::conv11_rt > 0 ? tune::conv11_rt : 4) : 1;
+  const long ntile = (long)B * ((H + 2 * rt - 1) / (2 * rt)) * ((W + 31) / 32);
   const long cap = tune::conv11_wgs > 0 ? tune::conv11_wgs : 512;
-  const int grid = (int)(ntile < cap ? ntile : cap);  // two workgroups per CU, ~12 tiles each at eight 224 x 224 images
-  hipLaunchKernelGGL(conv1_1_direct_kernel, dim3(grid), dim3(256), 0, st, in, w_hwio, bias, B, H, W, relu, out, out_amax, amax_stride);
+  const int grid = (int)(ntile < cap ? ntile : cap);  // two workgroups per CU
+  if (rt == 4) hipLaunchKernelGGL(conv1_1_direct_kernel<4>, dim3(grid), dim3(256), 0, st, in, w_hwio, bias, B, H, W, relu, out, out_amax, amax_stride);
+  else if (rt == 2) hipLaunchKernelGGL(conv1_1_direct_kernel<2>, dim3(grid), dim3(256), 0, st, in, w_hwio, bias, B, H, W, relu, out, out_amax, amax_stride);
+  else hipLaunchKernelGGL(conv1_1_direct_kernel<1>, dim3(grid), dim3(256), 0, st, in, w_hwio, bias, B, H, W, relu, out, out_amax, amax_stride);
   return hipGetLastError();
 }
 
