@@ -197,7 +197,8 @@ def test_conv3x3_transpose_detecting_identity(ops):
 
 
 @pytest.mark.parametrize("B,K,N,relu", [(1, 25088, 4096, True), (3, 4096, 1024, False), (8, 1024, 512, False),
-                                        (9, 4096, 256, True)])
+                                        (9, 4096, 256, True), (16, 25088, 4096, True), (17, 4096, 4096, True),
+                                        (33, 1024, 512, False), (4, 1000, 256, False)])
 def test_fc_vs_oracle(ops, B, K, N, relu):
     rng = np.random.default_rng(K + N)
     x = np.maximum(rng.standard_normal((B, K)), 0).astype(np.float32)
@@ -208,6 +209,22 @@ def test_fc_vs_oracle(ops, B, K, N, relu):
         ref = np.maximum(ref, 0)
     got = host(ops.fc(dev(x), dev(w), dev(b), relu))
     report_close("fc %s" % ((B, K, N),), got, ref, atol=1e-5, rtol=1e-5)
+
+
+def test_fc_rows_of_a_batched_call_do_not_depend_on_the_batch(ops):
+    """four rows and more take gemv_mfma_kernel (sixteen rows per pass on the fp32 matrix pipe, gemv.hip): a row's bits
+    are those of ANY call of >= 4 rows -- other companions, another position, a second pass (row 16 ..), 4 / 16 / 20 rows"""
+    rng = np.random.default_rng(5)
+    K, N = 4096, 4096
+    x = np.maximum(rng.standard_normal((20, K)), 0).astype(np.float32)
+    w = dev((rng.standard_normal((K, N)) * np.sqrt(2.0 / K)).astype(np.float32))
+    b = dev(rng.standard_normal(N).astype(np.float32))
+    full = host(ops.fc(dev(x), w, b, True))
+    perm = rng.permutation(20)
+    got = host(ops.fc(dev(np.ascontiguousarray(x[perm])), w, b, True))
+    assert np.array_equal(got, full[perm])
+    assert np.array_equal(host(ops.fc(dev(np.ascontiguousarray(x[3:7])), w, b, True)), full[3:7])
+    assert np.array_equal(host(ops.fc(dev(np.ascontiguousarray(x[:16])), w, b, True)), full[:16])
 
 
 @pytest.mark.parametrize("B,K,N,relu", [(1, 25088, 4096, True), (3, 4096, 1024, False), (8, 1024, 512, False),
