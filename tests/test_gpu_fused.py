@@ -254,3 +254,33 @@ def test_batched_encode_query_runs_the_fused_small_set_kernels(eng_store, B, N):
         assert torch.equal(a, b)
     q = ops.query_taps_fused(eng.weights.mlp, enc2.taps, enc2.embedding, tms, pts)
     assert torch.equal(pred, q), float((pred - q).abs().max())
+
+
+def test_batched_call_with_a_degenerate_camera(eng_store):
+    """nulls on the fused small-set path: request 2 of a five-request call has an all-zero camera (0 / 0 -> NaN image
+    coordinates -> the resampler's zeros for every feature, models/model_normalization.py:172-190 through
+    tf.contrib.resampler's range test) and request 3 projects every point outside the image (clamped to the border as the
+    reference's tf.minimum / tf.maximum do).  Each request against the float64 oracle; the OTHER requests bit for bit
+    what they are in a call without the degenerate ones"""
+    eng, store = eng_store
+    B, N = 5, 256
+    rng = np.random.default_rng(99)
+    imgs = rng.random((B, 137, 137, 3), dtype=np.float32)
+    pts = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    tms = np.repeat(O.DEMO_TRANS_MAT, B, axis=0).copy()
+    tms_ok = tms.copy()
+    tms[2] = 0.0
+    tms[3, 3, :2] += 4000.0                            # far outside: coordinates clamp to 136
+    pred = eng.encode_query(torch.from_numpy(imgs).cuda(), torch.from_numpy(pts).cuda(), torch.from_numpy(tms).cuda())[1]
+    base = eng.encode_query(torch.from_numpy(imgs).cuda(), torch.from_numpy(pts).cuda(), torch.from_numpy(tms_ok).cuda())[1]
+    assert bool(torch.isfinite(pred).all())
+    for b in (0, 1, 4):
+        assert torch.equal(pred[b], base[b]), "request %d depends on its companions' cameras" % b
+    worst = 0.0
+    for b in range(B):
+        d = {"imgs": imgs[b:b + 1], "sample_pc": pts[b:b + 1], "sample_pc_rot": pts[b:b + 1], "trans_mat": tms[b:b + 1]}
+        ref = O.get_model(d, store.arrays, dtype=np.float64)["pred_sdf"][0, :, 0]
+        err = float(np.abs(pred[b].cpu().numpy() - ref).max())
+        worst = max(worst, err)
+        print("request %d: |pred| max %.3g, |gpu - f64| %.3g" % (b, float(np.abs(ref).max()), err))
+    assert worst <= 1e-5
