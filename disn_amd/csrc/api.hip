@@ -883,7 +883,10 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   // under the fc head; the global stream's one launch follows the folded bias and adds the local sums.
   bool conv_h2_all = x3_enabled();
   for (int i = 0; i < 13; ++i) conv_h2_all = conv_h2_all && vw->conv_w_h2[i] != nullptr;
-  if (two && conv_h2_all && !featmap && B >= tune::conv_wide_min && fused_small_ok(mw, B, N)) {
+  // (a call of one to three requests keeps the layer-by-layer dense_h2 form below 8192 points per request -- its bits
+  // are a B = 1 call's; from 8192 points on it takes the fused kernels too: 2.13 -> 1.40 ms for one request of 65536 points
+  // against the three-term GEMM chain this shape ran until round 4, tools/encode_query_forms_time.py)
+  if (two && conv_h2_all && !featmap && (B >= tune::conv_wide_min || N >= 8192) && fused_small_ok(mw, B, N)) {
     rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, nullptr, e.vgg, &pool5, st);
     if (rc) return rc;
     DISN_TRY(hipEventRecord(ctx->ev[7], st));

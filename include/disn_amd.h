@@ -382,13 +382,13 @@ int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, 
  * carries B images.
  * WHICH KERNELS RUN (selection rules; results of different forms agree to fp32 rounding -- all within 1e-5 of the
  * float64 oracle -- and are bit-identical only within one form):
- *   point MLPs  B >= 4, N % 128 == 0, featmap == NULL (round 4; with w->g_fused and w->l_feat): the FUSED small-set
+ *   point MLPs  B >= 4 or N >= 8192, N % 128 == 0, featmap == NULL (round 4; with w->g_fused and w->l_feat): the FUSED small-set
  *               kernels -- split-form gather from the taps, mlp_fused_kernel<local, FEAT>, mlp_fused_kernel<global> with
  *               image b's folded bias row: one launch per stream behind the gather, bit-identical to disn_encode +
  *               disn_query_taps_fused.  Otherwise, B <= 512 and N < 8192 (and the *_d* images present): the two-term
  *               f16 layers, one launch per layer -- dense_h2.hip for B < 4 or N % 128 != 0, dense_h2w.hip for B >= 4
- *               (disn_dense_h2's rule); otherwise (N >= 8192 per image with B < 4 or N % 128 != 0; more than 512
- *               requests of a few points each) the three-term bf16 / f32-input GEMM chain of disn_dense.  disn_query /
+ *               (disn_dense_h2's rule); otherwise (N >= 8192 per image with N % 128 != 0 or a feature map asked for; more
+ *               than 512 requests of a few points each) the three-term bf16 / f32-input GEMM chain of disn_dense.  disn_query /
  *               disn_sdf_mlp switch at the same N = 8192 per image.
  *   convolutions / fc head  B < 4: conv_h2.hip + one-launch fc rows; B >= 4: conv_h2w.hip + the split-K fc stream
  *               with up to sixteen batch rows per pass on the fp32 matrix pipe (gemv_mfma_kernel; disn_conv3x3_h2's rule).

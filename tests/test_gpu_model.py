@@ -565,8 +565,8 @@ def test_batched_calls_are_batch_invariant_and_within_the_bar():
 
 def test_kernel_selection_thresholds_stay_within_the_bar():
     """ADVICE r2 / include/disn_amd.h (disn_encode_query, WHICH KERNELS RUN): across the N = 8184 | 8192 boundary of a
-    single request the point MLPs switch between the two-term f16 layers and the three-term GEMM chain -- results of the
-    two sides agree to fp32 rounding, each within 1e-5 of the float64 oracle; the old B = 32 | 33 boundary is gone
+    single request the point MLPs switch between the layer-by-layer two-term f16 kernels and the fused small-set kernels
+    (until round 4: the three-term GEMM chain) -- results of the two sides agree to fp32 rounding, each within 1e-5 of the float64 oracle; the old B = 32 | 33 boundary is gone
     (round 4: calls of >= 4 requests with N % 128 == 0 run the fused small-set kernels whatever B): bit-identical"""
     from disn_amd.engine import SdfEngine
     from disn_amd.weights import WeightStore
@@ -576,7 +576,7 @@ def test_kernel_selection_thresholds_stay_within_the_bar():
     img, tm = torch.from_numpy(d["imgs"]).cuda(), torch.from_numpy(d["trans_mat"]).cuda()
     pts = torch.from_numpy(d["sample_pc"]).cuda()
     ref = O.get_model(d, store.arrays, dtype=np.float64)["pred_sdf"][0, :, 0]
-    big = eng.encode_query(img, pts, tm)[1][0].cpu().numpy()                      # N = 8192: GEMM chain
+    big = eng.encode_query(img, pts, tm)[1][0].cpu().numpy()                      # N = 8192: fused kernels
     small = eng.encode_query(img, pts[:, :8184].contiguous(), tm)[1][0].cpu().numpy()   # N = 8184: dense_h2
     print("N = 8192 vs float64 %.3g; N = 8184 vs float64 %.3g; the two forms on the shared points %.3g" % (
         np.abs(big - ref).max(), np.abs(small - ref[:8184]).max(), np.abs(big[:8184] - small).max()))
