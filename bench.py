@@ -883,6 +883,34 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:
                 parity = {"error": repr(e)}
+            # ... and on the trained-like stress set (heavy-tailed weights, log-normal channel gains, 1 % outlier channels
+            # x 1000, demo / white-background images: tests/golden/make_golden_stress.py) against the committed float64
+            # oracle run of tests/golden/stress_trained_like.npz -- the statistics the per-image / per-channel power-of-two
+            # operand scales exist for (VERDICT r3 #2c)
+            parity_tl = None
+            try:
+                gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+                sys.path.insert(0, gdir)
+                import make_golden_stress as MGS
+                gold = np.load(os.path.join(gdir, "stress_trained_like.npz"))
+                sin = MGS.stress_inputs()
+                eng_tl = SdfEngine(WeightStore(O.trained_like_weights(MGS.STRESS_SEED)), dev)
+                td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                one_f = [float(np.abs(eng_tl.encode_query(td(sin["imgs"][b:b + 1]), td(sin["pts_a"][b:b + 1]),
+                                                          td(sin["trans_mat"][b:b + 1]))[1].cpu().numpy().reshape(-1)
+                                      - gold["pred64_a"][b]).max()) for b in range(4)]
+                pb = eng_tl.encode_query(td(sin["imgs"]), td(sin["pts_a"]), td(sin["trans_mat"]))[1].cpu().numpy()
+                bat_f = [float(np.abs(pb[b].reshape(-1) - gold["pred64_a"][b]).max()) for b in range(4)]
+                parity_tl = {"weights": "oracle.trained_like_weights(%d)" % MGS.STRESS_SEED,
+                             "max_abs_pred": float(np.abs(gold["pred64_a"]).max()),
+                             "single_step_form": {"max_abs_gpu_minus_f64_per_image": one_f},
+                             "batched_call_form": {"images_per_call": 4, "max_abs_gpu_minus_f64_per_image": bat_f},
+                             "worst": max(one_f + bat_f), "bar": 1e-5,
+                             "reference": "tests/golden/stress_trained_like.npz (float64 oracle, nothing from the GPU)"}
+                del eng_tl
+                torch.cuda.empty_cache()
+            except Exception as e:
+                parity_tl = {"error": repr(e)}
             best, cores = (N_POINTS / med, nthreads)
             if one and N_POINTS / one > best:
                 best, cores = N_POINTS / one, 1
@@ -894,6 +922,7 @@ def main():
                                     "max_abs_gpu_minus_cpu_oracle": float(np.abs(out.cpu().numpy() - pred_cpu[..., 0]).max()),
                                     "max_abs_gpu_minus_cpu_oracle_note": "xavier weights of the timed line (|pred| ~ 0.02): see parity_he",
                                     "parity_he": parity,
+                                    "parity_trained_like": parity_tl,
                                     "sample": "%d full steps (encode + 2048 points) of the numpy/torch-CPU oracle after "
                                               "1 warm-up, median, with all threads (resize stages: row blocks on a thread pool) and with one: the faster is `value`; "
                                               "nproc=%d; %s" % (len(ts), os.cpu_count(), cpu_name)}
