@@ -381,10 +381,13 @@ static hipError_t conv_h2w_go(ConvH2Dev d, hipStream_t st) {
 }
 
 // k-waves of the batched form, by LAYER SHAPE only (the summation order must not depend on the batch): one where
-// M x N of a few images already fills the chip's 1024 SIMDs with 7-block waves, two from the 56-pixel layers on
+// M x N of a few images already fills the chip's 1024 SIMDs with 7-block waves, two from the 28-pixel layers on.
+// (Until r04j the 56-pixel layers had two as well: at 12 and 16 images per call the one-k-wave form with two workgroups
+// per CU is 6-8 % faster there -- 158 against 168 us for conv3_2 at 16 images, tools/conv_h2w_variants_time.py -- and
+// equal at 4 and 8 with the 64-channel patch variant below.)
 int conv_h2w_kwaves(int H, int W, int Cin, int Cout) {
   (void)Cin;
-  return (long)H * W * Cout > (long)112 * 112 * 64 ? 1 : 2;  // conv1_2, conv2_x: 1; conv3_x, conv4_x: 2
+  return (long)H * W * Cout >= (long)56 * 56 * 256 ? 1 : 2;  // conv1_2, conv2_x, conv3_x: 1; conv4_x: 2
 }
 
 bool conv_h2w_supported(int H, int W, int Cin, int Cout) {
@@ -398,8 +401,10 @@ hipError_t conv_h2w_launch(ConvH2Dev d, hipStream_t st, int variant) {
   if (variant == 0) {
     const int wk = conv_h2w_kwaves(d.H, d.W, d.Cin, d.Cout);
     if (wk == 1) {
-      if (d.Cout % 128 == 0) variant = 2;
-      else variant = d.W % 32 == 0 ? 1 : 3;
+      // 128-channel workgroups (two per CU) while they give >= ~200 workgroups, else the 64-channel 8 x 32 patches
+      const long wg128 = (long)d.B * ((d.H + 7) / 8) * ((d.W + 27) / 28) * (d.Cout / 128);
+      if (d.Cout % 128 == 0 && wg128 >= 200) variant = 2;
+      else variant = d.W % 32 == 0 || d.Cout % 128 == 0 ? 1 : 3;
     } else {
       // 128-channel workgroups of eight waves (two per SIMD) while they still give >= ~200 workgroups, else 64-channel ones
       const long wg128 = (long)d.B * ((d.H + 7) / 8) * ((d.W + 27) / 28) * (d.Cout / 128);

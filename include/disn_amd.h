@@ -81,7 +81,7 @@ int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w
  * walk K sequentially; variants 1..3 one k-wave, 4..5 two; H*W >= 784), 10 = the whole-image tiling of layers of at
  * most 14 x 14 pixels (one workgroup per image and 32-channel block, four k-waves).
  * SELECTION RULE of tiling 0 (also inside disn_vgg16_* / disn_encode*): calls of B >= 4 images take the batched form
- * for layers of 28 x 28 pixels and more (one k-wave where H*W*Cout > 112*112*64, else two -- by layer shape only) and
+ * for layers of 28 x 28 pixels and more (one k-wave where H*W*Cout >= 56*56*256 -- conv1_2 .. conv3_3 --, else two -- by layer shape only) and
  * four k-waves for the 14 x 14 layers (the whole-image tiling where B * Cout / 32 >= 200, two-row patches below:
  * same bits); everything else the single-image form.  The two forms sum K in different orders: results agree to fp32 rounding
  * (both within 2e-6 of the layer's scale of the float64 convolution), NOT bit for bit -- an image's bits depend on

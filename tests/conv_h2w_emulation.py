@@ -37,7 +37,7 @@ def geometry(variant):
 
 
 def kwaves(H, W, cout):
-    return 1 if H * W * cout > 112 * 112 * 64 else 2
+    return 1 if H * W * cout >= 56 * 56 * 256 else 2
 
 
 def arow(G, lane, wm, wk, mb):
