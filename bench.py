@@ -593,7 +593,7 @@ def main():
                                                  "traffic": (pmc.get("conv_family_per_step") or {}).get("hbm_bytes"),
                                                  "note": "the same chain on ONE image (a step run alone: conv_h2_kernel, K "
                                                          "parallel inside the workgroup)"},
-                                "per_launch": "profiles/r03*_conv_stack_b16_trace.txt (rocprofv3 kernel trace of the same call)"}
+                                "per_launch": "profiles/r0*_conv_stack_b16_trace.txt (rocprofv3 kernel trace of the same call; the latest round's file)"}
         except Exception as e:   # a failing extra must not cost the contract line
             line.setdefault("extras_failed", {})['roofline of the dominant kernel family'] = repr(e)
             print("[bench] extra failed: %s: %r" % ('roofline of the dominant kernel family', e), file=sys.stderr)
