@@ -218,6 +218,25 @@ def test_external_kat_tensorflow_resize_vectors():
         assert np.array_equal(O.resize_bilinear_legacy(x, oh, ow).ravel(), np.asarray(k[nm]["out"], np.float32)), nm
 
 
+def test_external_kat_tensorflow_conv2d_vectors():
+    """TensorFlow's own conv2d unit-test vectors (conv_ops_test.py: testConv2D1x1Filter, testConv2D2x2Filter): the
+    orientation of the convolution rows B of the path are built on -- cross-correlation, NHWC x HWIO, channel-minor"""
+    k = _external_kat()
+    for nm in ("conv2d_tf_1x1", "conv2d_tf_2x2"):
+        c = k[nm]
+        x = np.arange(1, 1 + int(np.prod(c["in_shape"])), dtype=np.float32).reshape(c["in_shape"])
+        w = np.arange(1, 1 + int(np.prod(c["filter_shape"])), dtype=np.float32).reshape(c["filter_shape"])
+        b = np.zeros(c["filter_shape"][-1], np.float32)
+        want = np.asarray(c["out"], np.float32)
+        for dt in (np.float32, np.float64):
+            got = O.conv2d_numpy(x, w, b, c["padding"], False, dtype=dt)
+            assert np.array_equal(np.asarray(got, np.float64).ravel(), want.astype(np.float64)), (nm, dt)
+        assert np.array_equal(np.asarray(O.conv2d(x, w, b, c["padding"], False)).ravel(), want), nm
+    mp = k["maxpool_tf_valid"]       # pooling_ops_test.py: the 2 x 2 / stride-2 pool of rows B (VALID drops the odd row / column)
+    x = np.arange(1, 1 + int(np.prod(mp["in_shape"])), dtype=np.float32).reshape(mp["in_shape"])
+    assert np.array_equal(O.max_pool_2x2(x).ravel(), np.asarray(mp["out"], np.float32))
+
+
 def test_external_kat_hand_derived_resampler_cases():
     k = _external_kat()
     m = np.asarray(k["resampler_2x2"]["map"], np.float32)[None, :, :, None]
