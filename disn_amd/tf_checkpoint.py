@@ -83,11 +83,9 @@ def crc32c(data, crc: int = 0) -> int:
         try:
             from ._lib import lib
             import ctypes as C
-            buf = (C.c_char * len(data)).from_buffer_copy(data) if not isinstance(data, np.ndarray) else None
-            if buf is None:
-                a = np.ascontiguousarray(data).view(np.uint8)
-                return int(lib().disn_crc32c(a.ctypes.data, a.size, crc))
-            return int(lib().disn_crc32c(C.addressof(buf), len(data), crc))
+            # no copy of the buffer (a 411 MB block of slim's vgg_16.ckpt): numpy views bytes / memoryview / ndarray in place
+            a = (np.ascontiguousarray(data) if isinstance(data, np.ndarray) else np.frombuffer(data, np.uint8)).view(np.uint8)
+            return int(lib().disn_crc32c(C.c_void_p(a.ctypes.data), a.size, crc))
         except Exception:  # library not built: fall back to the definition
             pass
     return _crc32c_py(bytes(data), crc)
@@ -123,9 +121,14 @@ def _get_varint(buf: bytes, pos: int) -> Tuple[int, int]:
         shift += 7
 
 
-def _pb_fields(buf: bytes) -> Iterable[Tuple[int, int, object]]:
-    """yield (field_number, wire_type, value) -- value is int for varint/fixed, bytes for len-delimited"""
+_PB_VIEW_MIN = 1 << 16
+
+
+def _pb_fields(buf) -> Iterable[Tuple[int, int, object]]:
+    """yield (field_number, wire_type, value) -- value is int for varint/fixed, bytes (a memoryview from 64 KiB on) for
+    len-delimited"""
     pos = 0
+    mv = memoryview(buf)
     while pos < len(buf):
         key, pos = _get_varint(buf, pos)
         fn, wt = key >> 3, key & 7
@@ -136,7 +139,9 @@ def _pb_fields(buf: bytes) -> Iterable[Tuple[int, int, object]]:
             pos += 8
         elif wt == 2:
             ln, pos = _get_varint(buf, pos)
-            v = bytes(buf[pos:pos + ln])
+            # small values (names, shapes, nested headers) as bytes; large ones (tensor payloads and the messages around
+            # them: fc6 of slim's VGG-16 is 411 MB, nested three deep) as views of the caller's buffer -- no copies
+            v = mv[pos:pos + ln] if ln >= _PB_VIEW_MIN else bytes(mv[pos:pos + ln])
             pos += ln
         elif wt == 5:
             v = struct.unpack_from("<I", buf, pos)[0]
@@ -202,19 +207,20 @@ def _decode_entry(buf: bytes) -> Dict[str, object]:
 
 
 # ---------------------------------------------------------------- table blocks
-def _read_block(buf: bytes, offset: int, size: int, verify: bool) -> bytes:
-    body = buf[offset:offset + size]
-    trailer = buf[offset + size:offset + size + BLOCK_TRAILER]
+def _read_block(buf, offset: int, size: int, verify: bool):
+    mv = memoryview(buf)
+    body = mv[offset:offset + size]                    # a view: the block is never copied
+    trailer = bytes(mv[offset + size:offset + size + BLOCK_TRAILER])
     if len(trailer) != BLOCK_TRAILER:
         raise ValueError("truncated table block")
     if trailer[0] != 0:
         raise NotImplementedError("compressed table block (type %d); TF bundles are written uncompressed" % trailer[0])
     if verify:
         want = struct.unpack("<I", trailer[1:])[0]
-        got = mask_crc(crc32c(bytes(body) + trailer[:1]))
+        got = mask_crc(crc32c(trailer[:1], crc32c(body)))    # the crc of body + type byte, chained
         if want != got:
             raise ValueError("table block crc mismatch at %d" % offset)
-    return bytes(body)
+    return body
 
 
 def _block_entries(block: bytes) -> List[Tuple[bytes, bytes]]:
@@ -227,9 +233,10 @@ def _block_entries(block: bytes) -> List[Tuple[bytes, bytes]]:
         shared, pos = _get_varint(block, pos)
         non_shared, pos = _get_varint(block, pos)
         vlen, pos = _get_varint(block, pos)
-        key = key[:shared] + block[pos:pos + non_shared]
+        key = key[:shared] + bytes(block[pos:pos + non_shared])
         pos += non_shared
-        out.append((key, block[pos:pos + vlen]))
+        val = block[pos:pos + vlen]                    # (a view when the block is one)
+        out.append((key, val if vlen >= _PB_VIEW_MIN else bytes(val)))
         pos += vlen
     return out
 
@@ -353,7 +360,9 @@ def _decode_tensor_proto(buf: bytes) -> Tuple[int, Tuple[int, ...], np.ndarray]:
         raise NotImplementedError("DataType %d" % dtype)
     dt = np.dtype(DT[dtype])
     if content is not None:
-        vals = np.frombuffer(content, dtype=dt.newbyteorder("<")).astype(dt)
+        vals = np.frombuffer(content, dtype=dt.newbyteorder("<"))
+        if vals.dtype != dt:                             # a big-endian host
+            vals = vals.astype(dt)
     else:
         field = {1: 5, 2: 6, 3: 7, 9: 10}[dtype]
         vals = np.concatenate(typed[field]).astype(dt) if typed[field] else np.zeros(0, dt)
@@ -588,9 +597,9 @@ def load_checkpoint(prefix: str, names: Optional[Iterable[str]] = None, verify: 
         n = int(np.prod(e["shape"], dtype=np.int64)) if e["shape"] else 1
         if n * dt.itemsize != int(e["size"]):
             raise ValueError("%s: size %d does not match shape %s" % (name, e["size"], e["shape"]))
-        if verify and mask_crc(crc32c(raw.tobytes())) != e["crc32c"]:
+        if verify and mask_crc(crc32c(raw)) != e["crc32c"]:          # over the mapped bytes in place
             raise ValueError("%s: tensor crc mismatch" % name)
-        out[name] = np.frombuffer(raw.tobytes(), dtype=dt.newbyteorder("<")).reshape(e["shape"]).astype(dt)
+        out[name] = np.array(np.frombuffer(raw, dtype=dt.newbyteorder("<")).reshape(e["shape"]), dtype=dt)   # the one copy
     return out
 
 
