@@ -24,13 +24,29 @@ from .weights import MLP_SCOPES, VGG_CONV_NAMES, WeightStore
 class DeviceWeights:
     """Uploads a WeightStore and re-packs the GEMM-shaped layers for the MFMA kernels."""
 
-    def __init__(self, store: WeightStore, device: torch.device, conv_h2: bool = True):
+    def __init__(self, store: WeightStore, device: torch.device, conv_h2: bool = True, equalise: bool = True):
+        """``equalise`` (default): upload the EQUALISED copy of the variables (WeightStore.equalised =
+        disn_equalise_weights: every hidden channel times a power of two, its consumers' rows divided by it -- the same
+        function, the same fp32 roundings, but channels of comparable magnitude, which the per-image operand scale of the
+        two-term f16 kernels needs on trained weights: DESIGN 4k).  Taps, the feature map and gathered features of an
+        engine built this way are in equalised units; ``tap_scale`` [1472] converts (SdfEngine.true_taps /
+        true_features / internal_features; the model_normalization surface does it for its end_points).
+        ``status``: what was done -- {'equalised', 'channel_gain_span_log2' (per layer), 'max_span_log2'}."""
         if not store.complete():
             raise ValueError("WeightStore is incomplete")
         self.device = device
         self.num_classes = store.num_classes
         self._keep: List[torch.Tensor] = []
         dev = lambda a: self._hold(torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device))
+        if equalise:
+            store, tap_scale, span = store.equalised()
+            self.status = {"equalised": True, "channel_gain_span_log2": [float(v) for v in span],
+                           "max_span_log2": float(span.max())}
+        else:
+            tap_scale = np.ones(ops.FEAT_DIM, np.float32)
+            self.status = {"equalised": False, "channel_gain_span_log2": None, "max_span_log2": None}
+        self.equalised = bool(equalise)
+        self.tap_scale = dev(tap_scale)                      # [1472]: internal = true * tap_scale
 
         # ---- VGG-16 --------------------------------------------------------------------
         v = VggWeights()
@@ -146,7 +162,7 @@ class SdfEngine:
     layer-by-layer GEMM chain (three-term bf16 products); same math, fp32-rounding-level difference."""
 
     def __init__(self, store: Optional[WeightStore], device: Optional[torch.device] = None, fused: bool = True,
-                 conv_h2: bool = True, weights: Optional[DeviceWeights] = None):
+                 conv_h2: bool = True, weights: Optional[DeviceWeights] = None, equalise: bool = True):
         """``weights``: share the device weights of another engine (``store`` is then ignored): several engine
         contexts -- each with its own workspaces and auxiliary stream -- over one copy of the ~0.85 GB of device weights
         (fc6..fc8 as [K][N] 495 MB, fc7 / fc8 transposed 84 MB, the convolutions in three packed forms 206 MB, the
@@ -158,7 +174,8 @@ class SdfEngine:
         self.device = torch.device(device)
         self.fused = bool(fused)
         with torch.cuda.device(self.device):
-            self.weights = weights if weights is not None else DeviceWeights(store, self.device, conv_h2=conv_h2)
+            self.weights = weights if weights is not None else DeviceWeights(store, self.device, conv_h2=conv_h2,
+                                                                             equalise=equalise)
             self._ctx = ops.ctx_create()      # aux HIP stream + events for the overlapped encoder
         self._ws: Dict[str, torch.Tensor] = {}
 
@@ -186,6 +203,28 @@ class SdfEngine:
                 return a
             return a.to(self.device, torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    # equalised <-> true units (DeviceWeights(equalise=True): Encoded.taps / .featmap and everything gathered from them
+    # carry the power-of-two channel factors weights.tap_scale; identity copies for an engine built with equalise=False)
+    def true_taps(self, enc: "Encoded") -> List[torch.Tensor]:
+        """the five taps in the reference's units (end_points of slim vgg_16: models/model_normalization.py:76-78)"""
+        with torch.cuda.device(self.device):
+            o, out = 0, []
+            for t in enc.taps:
+                c = t.shape[-1]
+                out.append(ops.scale_channels(t, self.weights.tap_scale[o:o + c], invert=True))
+                o += c
+        return out
+
+    def true_features(self, feat: torch.Tensor) -> torch.Tensor:
+        """[..., 1472] gathered features / feature map: internal -> the reference's units ('point_img_feat')"""
+        with torch.cuda.device(self.device):
+            return ops.scale_channels(feat, self.weights.tap_scale, invert=True)
+
+    def internal_features(self, feat: torch.Tensor) -> torch.Tensor:
+        """[..., 1472] features in the reference's units (fed 'point_img_feat') -> what this engine's MLP weights expect"""
+        with torch.cuda.device(self.device):
+            return ops.scale_channels(self._dev(feat), self.weights.tap_scale)
 
     # rows A, B, C, E
     def encode(self, imgs) -> Encoded:
@@ -431,16 +470,18 @@ class StepPipeline:
                 for st in self.streams:
                     st.wait_stream(cur)
                 prev = None
-                for k, job in enumerate(jobs):
-                    i = k % S
-                    rec = self._conv_done[k % (S + 1)]
-                    ops.ctx_pipeline(self.engines[i]._ctx, prev, rec)
-                    with torch.cuda.stream(self.streams[i]):
-                        enc, sdf = self.engines[i].encode_query(*job)
-                    out[k] = (enc, sdf) if keep_encoded else sdf
-                    prev = rec
-                for eng in self.engines:
-                    ops.ctx_pipeline(eng._ctx, None, None)
+                try:
+                    for k, job in enumerate(jobs):
+                        i = k % S
+                        rec = self._conv_done[k % (S + 1)]
+                        ops.ctx_pipeline(self.engines[i]._ctx, prev, rec)
+                        with torch.cuda.stream(self.streams[i]):
+                            enc, sdf = self.engines[i].encode_query(*job)
+                        out[k] = (enc, sdf) if keep_encoded else sdf
+                        prev = rec
+                finally:                                 # a call that raised must not leave stale event handles behind
+                    for eng in self.engines:
+                        ops.ctx_pipeline(eng._ctx, None, None)
             for st in self.streams:
                 cur.wait_stream(st)
             return out
@@ -535,14 +576,17 @@ class StepPipeline:
         # little from each other; no better, 4.13 vs 4.05-4.13 ms: profiles/r03o_bench_pack20.txt.)
         mine = [[g for g in range(len(groups)) if g % S == i] for i in range(S)]
 
+        def check_one_shape(idx):
+            if len({tuple(jobs[k][1].shape) for k in idx}) != 1:
+                raise ValueError("jobs of one batch must have point sets of one shape")
+
         def work(i):
             if self.trace is not None:           # host-side pacing: this context's host thread is running
                 self.trace.append((i, "start", time.perf_counter()))
             self.streams[i].wait_stream(cur)
             for g in mine[i]:
                 idx = groups[g]
-                if len({tuple(jobs[k][1].shape) for k in idx}) != 1:
-                    raise ValueError("jobs of one batch must have point sets of one shape")
+                check_one_shape(idx)
                 args = [cat(idx, p) for p in range(len(jobs[idx[0]]))]
                 if self.trace is not None:       # ... the call's inputs are assembled
                     self.trace.append((i, "call %d" % g, time.perf_counter()))
@@ -568,22 +612,28 @@ class StepPipeline:
                 for st in self.streams:
                     st.wait_stream(cur)
                 prev = None
-                for g, idx in enumerate(groups):
-                    i = g % S
-                    rec = self._conv_done[g % (S + 1)]
-                    ops.ctx_pipeline(self.engines[i]._ctx, prev, rec)
-                    args = [cat(idx, p) for p in range(len(jobs[idx[0]]))]
-                    with torch.cuda.stream(self.streams[i]):
-                        enc, sdf = self.engines[i].encode_query(*args)
-                    o = 0
-                    for k in idx:
-                        b = jobs[k][0].shape[0]
-                        out[k] = (Encoded(enc.resized[o:o + b], [t[o:o + b] for t in enc.taps], enc.embedding[o:o + b], None),
-                                  sdf[o:o + b]) if keep_encoded else sdf[o:o + b]
-                        o += b
-                    prev = rec
-                for eng in self.engines:
-                    ops.ctx_pipeline(eng._ctx, None, None)
+                try:
+                    for g, idx in enumerate(groups):
+                        i = g % S
+                        check_one_shape(idx)
+                        rec = self._conv_done[g % (S + 1)]
+                        ops.ctx_pipeline(self.engines[i]._ctx, prev, rec)
+                        # the call's inputs are assembled WITH stream i current: a real copy (torch.cat of separately
+                        # allocated requests, the H2D copy of a numpy feed) is then ordered before the call that reads
+                        # it and its temporaries belong to stream i's allocator pool
+                        with torch.cuda.stream(self.streams[i]):
+                            args = [cat(idx, p) for p in range(len(jobs[idx[0]]))]
+                            enc, sdf = self.engines[i].encode_query(*args)
+                        o = 0
+                        for k in idx:
+                            b = jobs[k][0].shape[0]
+                            out[k] = (Encoded(enc.resized[o:o + b], [t[o:o + b] for t in enc.taps], enc.embedding[o:o + b], None),
+                                      sdf[o:o + b]) if keep_encoded else sdf[o:o + b]
+                            o += b
+                        prev = rec
+                finally:                                 # a call that raised must not leave stale event handles behind
+                    for eng in self.engines:
+                        ops.ctx_pipeline(eng._ctx, None, None)
             for st in self.streams:
                 cur.wait_stream(st)
             return out

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import report_close
+from conftest import internal_arrays, report_close
 from oracle import disn_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -101,10 +101,12 @@ def test_vgg_taps_vs_oracle():
     enc = eng.encode(imgs)
     resized, emb64, maps, eps = O.encode(imgs, store.arrays, dtype=np.float64)
     assert np.array_equal(enc.resized.cpu().numpy(), resized)
-    for t, nm in zip(enc.taps, O.TAP_NAMES):
+    # (the engine computes in equalised units -- DeviceWeights(equalise=True): true_taps / true_features convert)
+    assert eng.weights.status["equalised"]
+    for t, nm in zip(eng.true_taps(enc), O.TAP_NAMES):
         report_close(nm, t.cpu().numpy(), eps["vgg_16/%s/%s" % (nm[:5], nm)], ATOL, RTOL)
     report_close("embedding", enc.embedding.cpu().numpy(), emb64, ATOL, RTOL)
-    fm = enc.featmap.cpu().numpy()
+    fm = eng.true_features(enc.featmap).cpu().numpy()
     ref_fm = np.concatenate(maps, axis=3)
     report_close("featmap", fm, ref_fm, ATOL, RTOL)
 
@@ -212,7 +214,7 @@ def test_full_size_grid_properties():
     from disn_amd import ops
     pts = torch.cat([ops.grid_points(sp, R, int(k), int(k) + 1, "cuda") for k in idx])[None]
     xy = O.get_img_points(pts.cpu().numpy(), O.DEMO_TRANS_MAT)
-    fm = enc.featmap.cpu().numpy()
+    fm = eng.true_features(enc.featmap).cpu().numpy()
     feat = O.resampler(fm, xy)[:, :, None, :]
     emb = enc.embedding.cpu().numpy()
     ref = (O.get_sdf_basic2(pts.cpu().numpy(), emb, store.arrays, dtype=np.float64)
@@ -326,11 +328,12 @@ def test_vgg_stack_equals_standalone_layer_chain(conv_h2):
         x = enc.resized
         tap = 0
         pool_after = {1, 3, 6, 9, 12}
+        W_int = internal_arrays(store)          # the variables as the engine uploaded them (equalised copy)
         for i, nm in enumerate(VGG_CONV_NAMES):
-            w = store[nm + "/weights"]
+            w = W_int[nm + "/weights"]
             kh, kw, ci, co = w.shape
             wd = torch.from_numpy(np.ascontiguousarray(w.reshape(kh * kw * ci, co))).cuda()
-            bias = torch.from_numpy(store[nm + "/biases"]).cuda()
+            bias = torch.from_numpy(W_int[nm + "/biases"]).cuda()
             pooled = None
             if conv_h2:
                 if ci == 3:
@@ -506,6 +509,38 @@ def test_batched_pipeline_equals_single_image_steps(batch, npts, njobs):
     for k, job in enumerate(jobs):
         ref = one.encode_query(*job)[1]
         assert torch.equal(got[k], ref), "job %d differs from its single-image run" % k
+
+
+def test_chained_batched_pipeline_on_separately_allocated_jobs():
+    """ADVICE r4: run(jobs, chained=True) with batch > 1 assembles each call's inputs with torch.cat / an H2D copy;
+    those copies must run on the stream of the context that reads them.  Jobs are separately allocated device tensors
+    (a real cat) and, for a second run, numpy feeds (a real H2D copy); both runs are repeated so that the allocator
+    gets the chance to hand a temporary out again.  Every job must equal the non-chained batched run bit for bit."""
+    from disn_amd.engine import StepPipeline
+    from disn_amd.weights import WeightStore
+    pipe = StepPipeline(WeightStore.random_init(6, mode="he"), in_flight=2, batch=3)
+    jobs = _pipeline_jobs(8, 1024)
+    ref = pipe.run(jobs)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        got = pipe.run(jobs, chained=True)
+        torch.cuda.synchronize()
+        for k in range(len(jobs)):
+            assert torch.equal(got[k], ref[k]), "device jobs, repeat %d, job %d" % (rep, k)
+    host_jobs = [tuple(t.cpu().numpy() for t in job) for job in jobs]
+    for rep in range(2):
+        got = pipe.run(host_jobs, chained=True)
+        torch.cuda.synchronize()
+        for k in range(len(jobs)):
+            assert torch.equal(got[k], ref[k]), "numpy jobs, repeat %d, job %d" % (rep, k)
+    # one shape per call is checked on the chained path too, and a raising call leaves no stale pipeline events behind
+    bad = list(jobs)
+    bad[1] = (bad[1][0], bad[1][1][:, :512].contiguous(), bad[1][2])
+    with pytest.raises(ValueError):
+        pipe.run(bad, chained=True)
+    got = pipe.run(jobs)
+    torch.cuda.synchronize()
+    assert all(torch.equal(got[k], ref[k]) for k in range(len(jobs)))
 
 
 def _pipeline_jobs(njobs, npts, seed0=60):
