@@ -279,6 +279,53 @@ def grid_bench(args, torch, dist, dev, world, rank, launched, shared_gpu, backen
     }
 
 
+def dry_run(args, torch, dist, world, rank, launched):
+    """the protocol of a run without its GPU work: what the driver's `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N [--workload grid|train]`
+    goes through before and after the timed region -- env ranks, process group, barrier, K 'steps', barrier, MAX of the
+    ranks' times, ONE JSON line from rank 0 -- with the compute replaced by nothing.  Backend gloo unless nccl is asked
+    for (no device here); the shard arithmetic of the grid workload is the real one (disn_amd/parallel.py)."""
+    backend = "gloo" if args.dist_backend in ("auto", "gloo") else args.dist_backend
+    if launched:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if launched:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if launched:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    extra = {}
+    if args.workload == "grid":
+        from disn_amd import parallel
+        total = (args.grid_res + 1) ** 3
+        lo, hi = parallel.shard_range(total, world, rank)
+        sizes = torch.tensor([hi - lo], dtype=torch.int64)
+        if launched:
+            dist.all_reduce(sizes)
+        assert int(sizes.item()) == total, "the ranks' flat-index slices do not tile the grid"
+        extra = {"grid_points": total, "slice_rank0": [lo, hi], "exchange": args.exchange}
+    metric = {"query": "SDF point queries/sec (VGG-16 encode + 2048-point two-stream query per step, 137x137 image)",
+              "grid": "dense-grid SDF points/sec end to end (encode + (R+1)^3 grid + exchange + marching cubes)",
+              "train": "training samples/sec (train_sdf.py step)"}[args.workload]
+    line = {"metric": metric, "value": None, "unit": {"query": "points/s", "grid": "points/s", "train": "samples/s"}[args.workload],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / max(1, args.steps),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DRY RUN of --workload %s: launch / rendezvous / timing protocol only, no GPU work" % args.workload,
+                       "parallelism": "%d ranks over %s" % (world, backend if launched else "none: single process")},
+            "dry_run": True, **extra}
+    if rank == 0:
+        print(json.dumps(line))
+    if launched:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,6 +364,10 @@ def main():
                     help="dense-grid / large queries through the layer-by-layer GEMM chain instead of the fused kernels")
     ap.add_argument("--dist-backend", choices=("auto", "nccl", "gloo"), default="auto",
                     help="auto: nccl (= RCCL); gloo when ranks must share a GPU (RCCL rejects duplicate devices)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: exercise the launch path only (self-launch -> torch.distributed.run -> rendezvous on "
+                         "127.0.0.1 -> barrier / max-over-ranks timing -> ONE contract line from rank 0 with value null and "
+                         "dry_run true); runs on a box without a GPU with --dist-backend gloo (tests/test_parallel.py)")
     ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step")
     ap.add_argument("--train-dtype", choices=("f32", "f32_mfma", "bf16"), default="f32",
                     help="--workload train: f32 = the reference's precision (forward / data-gradient GEMMs as "
@@ -338,6 +389,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     shared_gpu, backend = False, "nccl"
+    if args.dry_run:
+        return dry_run(args, torch, dist, world, rank, launched)
     if launched:       # also with one rank: same RCCL init / barrier / all-reduce sequence as N ranks
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -909,8 +962,43 @@ def main():
                              "reference": "tests/golden/stress_trained_like.npz (float64 oracle, nothing from the GPU)"}
                 del eng_tl
                 torch.cuda.empty_cache()
+                # ... and a slice of the SWEEP (tests/golden/make_golden_sweep.py: 8 seeds x sigma {1, 1.5, 2} x outliers
+                # {1e3, 1e4} x 8 images; tests/test_gpu_sweep.py runs 12 / all 48 sets): three weight sets here, one per
+                # sigma, requests one at a time (images 0 and 4) and as one 16-request call -- the DISTRIBUTION of
+                # max |gpu - f64| per request, not one worst case (VERDICT r4 #1a)
+                import make_golden_sweep as MSW
+                gs = np.load(os.path.join(gdir, "stress_sweep.npz"))
+                sw = MSW.sweep_inputs()
+                errs, per_set = {"single": [], "batch16": []}, []
+                for (seed_, sg_, og_) in ((MSW.SEEDS[2], 1.0, 1e4), (MSW.SEEDS[1], 1.5, 1e3), (MSW.SEEDS[0], 2.0, 1e4)):
+                    i_ = MSW.SETS.index((seed_, sg_, og_))
+                    eng_s = SdfEngine(WeightStore(O.trained_like_weights(seed_, sigma=sg_, outlier_gain=og_)), dev)
+                    e1 = [float(np.abs(eng_s.encode_query(td(sw["imgs"][b:b + 1]), td(sw["pts"][b, 0][None]),
+                                                          td(sw["trans_mat"][b:b + 1]))[1][0].cpu().numpy()
+                                       - gs["pred64_%02d" % i_][b, 0]).max()) for b in (0, 4)]
+                    p16 = eng_s.encode_query(td(np.concatenate([sw["imgs"], sw["imgs"]])),
+                                             td(np.concatenate([sw["pts"][:, 0], sw["pts"][:, 1]])),
+                                             td(np.concatenate([sw["trans_mat"], sw["trans_mat"]])))[1].cpu().numpy()
+                    e16 = [float(np.abs(p16[k] - gs["pred64_%02d" % i_][k % 8, k // 8]).max()) for k in range(16)]
+                    errs["single"] += e1
+                    errs["batch16"] += e16
+                    per_set.append({"seed": seed_, "sigma": sg_, "outlier_gain": og_,
+                                    "channel_gain_span_log2": eng_s.weights.status["max_span_log2"],
+                                    "single_worst": max(e1), "batch16_worst": max(e16),
+                                    "oracle32_minus_f64": float(gs["o32_%02d" % i_])})
+                    del eng_s
+                    torch.cuda.empty_cache()
+                dist_ = lambda v: {"n": len(v), "min": float(np.min(v)), "median": float(np.median(v)),
+                                   "p90": float(np.sort(v)[int(0.9 * (len(v) - 1))]), "max": float(np.max(v))}
+                parity_tl["sweep"] = {"sets": per_set, "single_step_form": dist_(errs["single"]),
+                                      "batched_call_form_16": dist_(errs["batch16"]),
+                                      "worst": max(errs["single"] + errs["batch16"]), "bar": 1e-5,
+                                      "equalised_weights": True,
+                                      "reference": "tests/golden/stress_sweep.npz (float64 oracle); the full sweep: "
+                                                   "tests/test_gpu_sweep.py, profiles/r05*_sweep_*.json"}
+                parity_tl["worst"] = max(parity_tl["worst"], parity_tl["sweep"]["worst"])
             except Exception as e:
-                parity_tl = {"error": repr(e)}
+                parity_tl = {"error": repr(e)} if parity_tl is None else dict(parity_tl, sweep_error=repr(e))
             best, cores = (N_POINTS / med, nthreads)
             if one and N_POINTS / one > best:
                 best, cores = N_POINTS / one, 1

@@ -14,7 +14,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # DISN_AMD_LIB: tools/ only -- points the binding at a tuning build (csrc/build.py --tuning), never set by the product
 LIB_PATH = os.environ.get("DISN_AMD_LIB") or os.path.join(HERE, "csrc", "libdisn_amd.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -61,6 +61,11 @@ CAM_FIELDS = tuple("%s_%s%d" % (t, k, i) for t in "srt" for i in (1, 2, 3) for k
 
 class CamWeights(C.Structure):  # disn_cam_weights_t: s_w1, s_b1, s_w2, ... t_b3
     _fields_ = [(n, C.c_void_p) for n in CAM_FIELDS]
+
+
+class EqWeights(C.Structure):  # disn_eq_weights_t (HOST pointers, modified in place)
+    _fields_ = [("conv_w", C.c_void_p * 13), ("conv_b", C.c_void_p * 13), ("fc6_w", C.c_void_p),
+                ("mlp_w", (C.c_void_p * 6) * 2), ("mlp_b", (C.c_void_p * 6) * 2), ("num_classes", C.c_int)]
 
 
 NUM_VARS = 56
@@ -140,6 +145,8 @@ SIGNATURES = {
     "disn_query_grid_ctx": (I, [P, C.POINTER(MlpWeights), P, P, P, C.POINTER(C.c_double * 6), I, L, L, F, P,
                                 P, Z, P]),
     "disn_crc32c": (C.c_uint32, [P, Z, C.c_uint32]),
+    "disn_equalise_weights": (I, [C.POINTER(EqWeights), P, P]),
+    "disn_scale_channels": (I, [P, L, I, P, I, P, P]),
     "disn_dense_bf16_workspace_bytes": (Z, [I, I, I]),
     "disn_dense_bf16": (I, [P, I, I, P, I, I, I, P, P, I, I, I, P, P, Z, P]),
     "disn_conv3x3_bf16_workspace_bytes": (Z, [I, I, I, I, I]),

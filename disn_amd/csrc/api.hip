@@ -560,6 +560,15 @@ int disn_fc_t(const float* x, int B, int K, const float* wt_nk, const float* bia
   return 0;
 }
 
+int disn_scale_channels(const float* in, int64_t rows, int C, const float* scale, int invert, float* out,
+                        void* stream) {
+  if (!in || !scale || !out || rows < 0 || C <= 0) return DISN_E_ARG;
+  if (C % 4) return DISN_E_SHAPE;
+  if (rows == 0) return 0;
+  DISN_TRY(scale_channels_launch(in, rows, C, scale, invert, out, (hipStream_t)stream));
+  return 0;
+}
+
 int disn_get_loss(const float* pred, const float* gt, int64_t M, float sdf_weight, float mask_weight, float* out5,
                   void* stream) {
   if (!pred || !gt || !out5 || M <= 0 || sdf_weight == 0.0f) return DISN_E_ARG;
@@ -699,18 +708,30 @@ int gbias_layer(const disn_mlp_weights_t* w, const float* embedding, int B, floa
   return fc_layer(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_w4_global_t, w->g_b4, 512, 0, gbias, ws, st);
 }
 
+// Point sets of a fused-small call are padded to a multiple of 128 points per image INSIDE the library (round 5; pad
+// points (0, 0, 0) as test/create_sdf.py:241,256 pads its last split, their results discarded): whether a request runs
+// the fused kernels no longer depends on N % 128.  The fused kernels scale per POINT and the feature scale
+// of an image comes from its taps, so the real points' bits do not depend on the pad points.
+inline int pad128(int N) { return (N + 127) & ~127; }
+
 struct EncQueryWs {
   VggWs vgg;
   QueryWs q;
+  float *pad_pts, *pad_rot, *pad_sdf;   // [B][pad128(N)][3] x 2, [B][pad128(N)]
   size_t total;
 };
 
 EncQueryWs encq_layout(void* ws, int B, int N, int num_classes) {
   EncQueryWs e;
+  const int Np = (long)B * pad128(N) <= kChunk ? pad128(N) : N;
   e.vgg = vgg_layout(ws, B, num_classes);
   char* base = ws ? static_cast<char*>(ws) + e.vgg.total : nullptr;
-  e.q = query_layout(base, B, B * N, true, false, true);
-  e.total = e.vgg.total + e.q.total;
+  e.q = query_layout(base, B, B * Np, true, false, true);
+  Bump b(base ? base + e.q.total : nullptr);
+  e.pad_pts = b.take((size_t)B * Np * 3 * sizeof(float));
+  e.pad_rot = b.take((size_t)B * Np * 3 * sizeof(float));
+  e.pad_sdf = b.take((size_t)B * Np * sizeof(float));
+  e.total = e.vgg.total + e.q.total + ((b.off + 255) & ~size_t(255));
   return e;
 }
 
@@ -858,6 +879,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     if (!taps[i]) return DISN_E_ARG;
   if ((long)B * N > kChunk || vw->num_classes != DISN_EMBED_DIM) return DISN_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  const int N0 = N;
   const EncQueryWs e = encq_layout(ws, B, N, vw->num_classes);
   if (e.total > ws_bytes) return DISN_E_WS;
   // Two streams.  `st` (the caller's): resize, conv stack, fc6..fc8, the folded global bias, then the
@@ -886,7 +908,17 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   // (a call of one to three requests keeps the layer-by-layer dense_h2 form below 8192 points per request -- its bits
   // are a B = 1 call's; from 8192 points on it takes the fused kernels too: 2.13 -> 1.40 ms for one request of 65536 points
   // against the three-term GEMM chain this shape ran until round 4, tools/encode_query_forms_time.py)
-  if (two && conv_h2_all && !featmap && (B >= tune::conv_wide_min || N >= 8192) && fused_small_ok(mw, B, N)) {
+  const int Np = pad128(N);
+  if (two && conv_h2_all && !featmap && (B >= tune::conv_wide_min || N >= 8192) && fused_small_ok(mw, B, Np)) {
+    float* sdf_out = sdf;
+    if (Np != N) {   // pad the point sets (both streams run behind the fork / the convolutions anyway)
+      DISN_TRY(restride_rows_launch(pts, B, N, e.pad_pts, Np, 3, st));
+      if (pts_rot != pts) DISN_TRY(restride_rows_launch(pts_rot, B, N, e.pad_rot, Np, 3, st));
+      pts_rot = pts_rot != pts ? e.pad_rot : e.pad_pts;
+      pts = e.pad_pts;
+      sdf = e.pad_sdf;
+      N = Np;
+    }
     rc = vgg_features(vw, img, B, resized224 ? resized224 : e.vgg.resized, taps, nullptr, e.vgg, &pool5, st);
     if (rc) return rc;
     DISN_TRY(hipEventRecord(ctx->ev[7], st));
@@ -902,7 +934,9 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
     { const int grc = gbias_layer(mw, embedding, B, e.q.gbias, e.q.gemv_ws, st); if (grc) return grc; }
     DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
-    return fused_small_global(mw, e.q.gbias, pts_rot, B, N, e.q.mlp.l5, sdf, 1.0f, st);
+    if ((rc = fused_small_global(mw, e.q.gbias, pts_rot, B, N, e.q.mlp.l5, sdf, 1.0f, st))) return rc;
+    if (sdf != sdf_out) DISN_TRY(restride_rows_launch(sdf, B, N, sdf_out, N0, 1, st));
+    return 0;
   }
   const bool h2 = two && B <= kH2Imgs && mlp_h2(mw, N);   // small point sets: the dense_h2 layers, image by image
   const int feat_ld = h2 && !featmap ? kFeatPad : DISN_FEAT_DIM;
@@ -1187,7 +1221,7 @@ int disn_mlp_fused_feat_pack(const float* w2, const float* w3, const float* w4, 
 
 namespace {
 struct TapsFusedWs {
-  float *gbias, *gemv_ws, *feat, *slots, *featmax, *lsum;
+  float *gbias, *gemv_ws, *feat, *slots, *featmax, *lsum, *pad_pts, *pad_rot, *pad_sdf;
   size_t total;
 };
 TapsFusedWs taps_fused_layout(void* ws, int B, int N) {
@@ -1199,14 +1233,17 @@ TapsFusedWs taps_fused_layout(void* ws, int B, int N) {
   f.slots = b.take((size_t)5 * B * 64 * sizeof(float));
   f.featmax = b.take((size_t)B * sizeof(float));
   f.lsum = b.take((size_t)B * N * sizeof(float));
+  f.pad_pts = b.take((size_t)B * N * 3 * sizeof(float));
+  f.pad_rot = b.take((size_t)B * N * 3 * sizeof(float));
+  f.pad_sdf = b.take((size_t)B * N * sizeof(float));
   f.total = (b.off + 255) & ~size_t(255);
   return f;
 }
 }  // namespace
 
 size_t disn_query_taps_fused_workspace_bytes(int B, int N) {
-  if (B <= 0 || N <= 0 || N % 128 || (long)B * N > kChunk) return 0;
-  return taps_fused_layout(nullptr, B, N).total;
+  if (B <= 0 || N <= 0 || (long)B * pad128(N) > kChunk) return 0;
+  return taps_fused_layout(nullptr, B, pad128(N)).total;
 }
 
 int disn_query_taps_fused(const disn_mlp_weights_t* w, const float* const taps[5], const float* embedding,
@@ -1217,10 +1254,20 @@ int disn_query_taps_fused(const disn_mlp_weights_t* w, const float* const taps[5
     return DISN_E_ARG;
   for (int i = 0; i < 5; ++i)
     if (!taps[i]) return DISN_E_ARG;
-  if (N % 128 || (long)B * N > kChunk) return DISN_E_SHAPE;
+  const int N0 = N, Np = pad128(N);
+  if ((long)B * Np > kChunk) return DISN_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const TapsFusedWs f = taps_fused_layout(ws, B, N);
+  const TapsFusedWs f = taps_fused_layout(ws, B, Np);
   if (f.total > ws_bytes) return DISN_E_WS;
+  float* sdf_out = sdf;
+  if (Np != N) {   // pad points (0, 0, 0) in, the first N results out (see pad128)
+    DISN_TRY(restride_rows_launch(pts, B, N, f.pad_pts, Np, 3, st));
+    if (pts_rot != pts) DISN_TRY(restride_rows_launch(pts_rot, B, N, f.pad_rot, Np, 3, st));
+    pts_rot = pts_rot != pts ? f.pad_rot : f.pad_pts;
+    pts = f.pad_pts;
+    sdf = f.pad_sdf;
+    N = Np;
+  }
   // the taps' exact maxima, per image (inside disn_encode_query they come out of the convolutions' epilogues: the
   // same numbers, hence the same split scale and the same bits)
   static const int hw[5] = {224, 112, 56, 28, 14}, ch[5] = {64, 128, 256, 512, 512};
@@ -1235,7 +1282,9 @@ int disn_query_taps_fused(const disn_mlp_weights_t* w, const float* const taps[5
   int rc = fused_small_local(w, tp, slots, 64, trans_mat, pts, pts_rot, B, N, f.feat, f.featmax, f.lsum, st);
   if (rc) return rc;
   { const int grc = gbias_layer(w, embedding, B, f.gbias, f.gemv_ws, st); if (grc) return grc; }
-  return fused_small_global(w, f.gbias, pts_rot, B, N, f.lsum, sdf, 1.0f, st);
+  if ((rc = fused_small_global(w, f.gbias, pts_rot, B, N, f.lsum, sdf, 1.0f, st))) return rc;
+  if (sdf != sdf_out) DISN_TRY(restride_rows_launch(sdf, B, N, sdf_out, N0, 1, st));
+  return 0;
 }
 
 int disn_amax(const float* x, int64_t n, float* out, void* stream) {

@@ -67,6 +67,9 @@ namespace disn {
 __device__ __forceinline__ void h2_colmax_chunk(const float* __restrict__ p, long base, int mid, int inner,
                                                 float* __restrict__ cmax_inner, float* __restrict__ cmax_mid,
                                                 unsigned* tab_i, unsigned* tab_m) {
+  // more than 1024 columns (a 4096-wide dense layer): no LDS table for that index, one global atomic per
+  // element instead -- pack time only
+  const bool big_i = inner > 1024, big_m = mid > 1024;
   for (int i = threadIdx.x; i < 1024; i += 256) { tab_i[i] = 0u; tab_m[i] = 0u; }
   __syncthreads();
 #pragma unroll
@@ -77,14 +80,22 @@ __device__ __forceinline__ void h2_colmax_chunk(const float* __restrict__ p, lon
     if (cmax_inner) {
       const int c0 = (int)(e % inner);  // inner % 4 == 0: the four elements are four consecutive columns
 #pragma unroll
-      for (int q = 0; q < 4; ++q) atomicMax(&tab_i[c0 + q], __float_as_uint(a[q]));
+      for (int q = 0; q < 4; ++q) {
+        if (big_i) atomicMax(reinterpret_cast<unsigned*>(cmax_inner) + c0 + q, __float_as_uint(a[q]));
+        else atomicMax(&tab_i[c0 + q], __float_as_uint(a[q]));
+      }
     }
-    if (cmax_mid) atomicMax(&tab_m[(int)((e / inner) % mid)], __float_as_uint(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]))));
+    if (cmax_mid) {
+      const unsigned m4 = __float_as_uint(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+      const int r = (int)((e / inner) % mid);
+      if (big_m) atomicMax(reinterpret_cast<unsigned*>(cmax_mid) + r, m4);
+      else atomicMax(&tab_m[r], m4);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 1024; i += 256) {
-    if (cmax_inner && i < inner && tab_i[i]) atomicMax(reinterpret_cast<unsigned*>(cmax_inner) + i, tab_i[i]);
-    if (cmax_mid && i < mid && tab_m[i]) atomicMax(reinterpret_cast<unsigned*>(cmax_mid) + i, tab_m[i]);
+    if (cmax_inner && !big_i && i < inner && tab_i[i]) atomicMax(reinterpret_cast<unsigned*>(cmax_inner) + i, tab_i[i]);
+    if (cmax_mid && !big_m && i < mid && tab_m[i]) atomicMax(reinterpret_cast<unsigned*>(cmax_mid) + i, tab_m[i]);
   }
 }
 
@@ -238,7 +249,7 @@ hipError_t conv_h2_pack_multi_launch(const ConvH2PackJobs& jobs, hipStream_t st)
 hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, float* scratch, hipStream_t st,
                                int taps, int flip_t) {
   (void)scratch;
-  if (Cin > 1024 * 4 || Cout > 1024 || ((size_t)taps * Cin * Cout) % 4096) return hipErrorInvalidValue;
+  if (((size_t)taps * Cin * Cout) % 4096) return hipErrorInvalidValue;   // (Cin, Cout multiples of 64: always true)
   unsigned char* img = static_cast<unsigned char*>(image);
   float* cmax = reinterpret_cast<float*>(img + (size_t)Cin * taps * Cout * 4) + Cout;
   hipError_t e = hipMemsetAsync(cmax, 0, (size_t)Cout * sizeof(float), st);
@@ -247,7 +258,7 @@ hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, f
   // image's columns are its MID index
   const unsigned grid = (unsigned)(((size_t)taps * Cin * Cout) / 4096);
   if (flip_t) {
-    if (Cout > 1024 || Cin % 4) return hipErrorInvalidValue;
+    if (Cin % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(h2_colmax_kernel, dim3(grid), dim3(256), 0, st, w, Cout, Cin, (float*)nullptr, cmax);
   } else {
     hipLaunchKernelGGL(h2_colmax_kernel, dim3(grid), dim3(256), 0, st, w, Cin, Cout, cmax, (float*)nullptr);

@@ -669,4 +669,46 @@ hipError_t scale_div_launch(const float* in, float divisor, int64_t n, float* ou
   return hipGetLastError();
 }
 
+// rows of B images re-strided: dst[b][r][0..w) = src[b][r][0..w) for r < min(rs, rd), zeros for the rows rs .. rd - 1
+// (pad points (0, 0, 0) -- what test/create_sdf.py:241,256 appends -- in; the first N results out)
+__global__ __launch_bounds__(256) void restride_rows_kernel(const float* __restrict__ src, int rs, float* __restrict__ dst,
+                                                            int rd, int w, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t per = (int64_t)rd * w;
+    const int64_t b = i / per, e = i - b * per;
+    const int r = (int)(e / w);
+    dst[i] = r < rs ? src[(b * rs + r) * w + (e - (int64_t)r * w)] : 0.0f;
+  }
+}
+
+hipError_t restride_rows_launch(const float* src, int B, int rs, float* dst, int rd, int w, hipStream_t st) {
+  const int64_t n = (int64_t)B * rd * w;
+  hipLaunchKernelGGL(restride_rows_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, src, rs, dst, rd, w, n);
+  return hipGetLastError();
+}
+
+// equalised <-> true units of taps / gathered features (disn_equalise_weights): out[r][c] = in[r][c] * scale[c] or
+// in[r][c] / scale[c]; the factors are powers of two, both forms exact.  C % 4 == 0 (64 .. 1472): float4 per thread
+__global__ __launch_bounds__(256) void scale_channels_kernel(const float* __restrict__ in, int64_t n4, int C4,
+                                                             const float* __restrict__ scale, int invert,
+                                                             float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    const float4 s = reinterpret_cast<const float4*>(scale)[c4];
+    float4 r;
+    if (invert) { r.x = v.x / s.x; r.y = v.y / s.y; r.z = v.z / s.z; r.w = v.w / s.w; }
+    else { r.x = v.x * s.x; r.y = v.y * s.y; r.z = v.z * s.z; r.w = v.w * s.w; }
+    reinterpret_cast<float4*>(out)[i] = r;
+  }
+}
+
+hipError_t scale_channels_launch(const float* in, int64_t rows, int C, const float* scale, int invert, float* out,
+                                 hipStream_t st) {
+  const int64_t n4 = rows * (C / 4);
+  hipLaunchKernelGGL(scale_channels_kernel, dim3(grid_for((size_t)n4)), dim3(256), 0, st, in, n4, C / 4, scale, invert,
+                     out);
+  return hipGetLastError();
+}
+
 }  // namespace disn

@@ -115,6 +115,9 @@ hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, co
 hipError_t resize_bilinear_launch(const float* in, int B, int Hin, int Win, int C, float* out,
                                   int Hout, int Wout, int out_cstride, int out_coff,
                                   hipStream_t st, int max_blocks = 0, float* zero = nullptr, int nzero = 0);
+hipError_t restride_rows_launch(const float* src, int B, int rs, float* dst, int rd, int w, hipStream_t st);
+hipError_t scale_channels_launch(const float* in, int64_t rows, int C, const float* scale, int invert, float* out,
+                                 hipStream_t st);
 hipError_t maxpool2x2_launch(const float* in, int B, int H, int W, int C, float* out,
                              hipStream_t st);
 hipError_t project_launch(const float* pts, const float* trans_mat, int B, int N, float* xy,

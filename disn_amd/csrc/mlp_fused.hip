@@ -81,6 +81,7 @@ constexpr size_t kImageBytesFeat = (size_t)kPairsFeat * 2048;   // 5 308 416
 // rows of fold2/conv1 (FEAT form); [11] max_f c_4[f]; from float 64 on c_2[256], c_3[512], c_4[512], c_5[256]
 constexpr int mS2 = 64, mS3 = mS2 + 256, mS4 = mS3 + 512, mS5 = mS4 + 512, kMetaFloats = mS5 + 256;
 constexpr float kInvSw = 1.0f / 8192.0f;   // every column of W~ is packed with the scale 2^13
+constexpr float kColFloor = 1.0f / 1048576.0f;   // 2^-20: columns below that fraction of the layer's largest are not equalised further
 // constants of one stream in LDS (floats)
 constexpr int cW1 = 0, cB1 = 192, cB2 = 256, cB3 = 512, cB4 = 1024, cB5 = 1536, cW6 = 1792, cB6 = 2048;
 constexpr int cS2 = 2052, cS3 = cS2 + 256, cS4 = cS3 + 512, cS5 = cS4 + 512;
@@ -119,10 +120,29 @@ __global__ __launch_bounds__(256) void fm_meta_kernel(const float* __restrict__ 
     const int N = layer == 0 ? 256 : (layer == 3 ? 256 : 512);
     float* c = meta + fm_meta_off(layer);
     float l1p = 0.f, l1f = 0.f, cmax = 0.f;
+    // column maxima first (parked in c[]), then the layer's largest: a nearly dead column (maximum 2^-40 of its
+    // neighbours', with an ordinary bias) must not get c ~ 2^40 -- b c would dominate the activation bounds and flush
+    // every other feature of the tile, and the next layer's rows W / c would fall below f16's floor.  The
+    // factor of a column is that of max(its maximum, 2^-20 of the layer's largest): columns within 2^20 of the largest
+    // are equalised exactly as before, the others keep |W~| < 1 (still >= 19 bits beside a 2^20-fold bias term)
+    float mloc = 0.f;
     for (int f = threadIdx.x; f < N; f += 256) {
       float m = 0.f;
       for (int k = 0; k < Kall; ++k) m = fmaxf(m, fabsf(w[(size_t)k * N + f]) * (k < K ? rrow[k] : 1.0f));
-      const float cf = pow2_scale_for(m, 0);   // m cf in [1, 2); 1 for an all-zero column
+      c[f] = m;
+      mloc = fmaxf(mloc, m);
+    }
+    __syncthreads();
+    red[threadIdx.x] = mloc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+      __syncthreads();
+    }
+    const float mfloor = red[0] * fm::kColFloor;
+    __syncthreads();
+    for (int f = threadIdx.x; f < N; f += 256) {
+      const float cf = pow2_scale_for(fmaxf(c[f], mfloor), 0);   // m cf in [1, 2) (< 1 below the floor); 1 for an all-zero layer
       c[f] = cf;
       cmax = fmaxf(cmax, cf);
       float a = 0.f, af = 0.f;

@@ -115,8 +115,9 @@ def get_model(ref_dict, num_point, is_training, bn=False, bn_decay=None, img_siz
     sample_img_points = get_img_points(ref_sample_pc, ref_trans_mat)
 
     # row F (:172-190): point_img_feat [B,N,1,1472]
-    def feat_fn(sess, e, xy):
-        return ops.gather(sess.engine.featmap_of(e), xy).reshape(xy.shape[0], xy.shape[1], 1, FEAT_DIM)
+    def feat_fn(sess, e, xy):   # (the engine's feature map is in equalised units: the end point is not)
+        f = ops.gather(sess.engine.featmap_of(e), xy)
+        return sess.engine.true_features(f).reshape(xy.shape[0], xy.shape[1], 1, FEAT_DIM)
 
     point_img_feat = SymTensor('point_img_feat', (B, N, 1, FEAT_DIM), feat_fn, (enc, sample_img_points))
 
@@ -159,7 +160,8 @@ def get_decoder(num_point, input_pls, feature_pls, bn=False, bn_decay=None, wd=N
     def fn(sess, e, f, p):
         eng = sess.engine
         e, f, p = eng._dev(e), eng._dev(f), eng._dev(p)
-        out = ops.sdf_mlp(eng.weights.mlp, p, e.reshape(e.shape[0], -1), f.reshape(p.shape[0], p.shape[1], FEAT_DIM))
+        f = eng.internal_features(f.reshape(p.shape[0], p.shape[1], FEAT_DIM))
+        out = ops.sdf_mlp(eng.weights.mlp, p, e.reshape(e.shape[0], -1), f)
         return out.reshape(out.shape[0], out.shape[1], 1)
 
     return SymTensor('multi_pred_sdf', (shp[0], shp[1], 1), fn, (emb, feat, pc_rot))

@@ -394,6 +394,21 @@ def gather(featmap: torch.Tensor, xy: torch.Tensor, out: Optional[torch.Tensor] 
     return out
 
 
+def scale_channels(x: torch.Tensor, scale: torch.Tensor, invert: bool = False,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [..., C] * scale [C] (or / scale): equalised <-> true units of taps / gathered features
+    (disn_scale_channels; exact for the powers of two of disn_equalise_weights)"""
+    x, scale = _chk(x, "x"), _chk(scale, "scale")
+    Cc = x.shape[-1]
+    if scale.numel() != Cc:
+        raise ValueError("scale_channels: %d factors for %d channels" % (scale.numel(), Cc))
+    if out is None:
+        out = torch.empty_like(x)
+    check("disn_scale_channels", lib().disn_scale_channels(x.data_ptr(), x.numel() // Cc, Cc, scale.data_ptr(),
+                                                           int(bool(invert)), out.data_ptr(), _stream()))
+    return out
+
+
 def gather_taps(taps: Sequence[torch.Tensor], trans_mat: torch.Tensor, pts: torch.Tensor,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """rows D + E + F without the feature map (disn_gather_taps): taps x pts [B,N,3] -> feat [B,N,1472]"""
@@ -464,8 +479,9 @@ def mlp_fused_feat_pack(w2: torch.Tensor, w3: torch.Tensor, w4: torch.Tensor, w5
 def query_taps_fused(w: MlpWeights, taps: Sequence[torch.Tensor], embedding: torch.Tensor, trans_mat: torch.Tensor,
                      pts: torch.Tensor, pts_rot: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """disn_query_taps_fused: rows D..H of B images x N points (N % 128 == 0, B * N <= 65536) from the five taps
-    through the fused small-set kernels (split-form gather + one launch per MLP stream)"""
+    """disn_query_taps_fused: rows D..H of B images x N points (any N: padded to a multiple of 128 inside the library;
+    B * padded N <= 65536) from the five taps through the fused small-set kernels (split-form gather + one launch per
+    MLP stream)"""
     pts = _chk(pts, "pts")
     pts_rot = pts if pts_rot is None else _chk(pts_rot, "pts_rot")
     B, N, _ = pts.shape
@@ -473,7 +489,7 @@ def query_taps_fused(w: MlpWeights, taps: Sequence[torch.Tensor], embedding: tor
         out = torch.empty((B, N), dtype=torch.float32, device=pts.device)
     need = lib().disn_query_taps_fused_workspace_bytes(B, N)
     if need == 0:
-        raise ValueError("query_taps_fused: N must be a multiple of 128 and B * N <= 65536, got B %d N %d" % (B, N))
+        raise ValueError("query_taps_fused: B * N (N rounded up to a multiple of 128) must be <= 65536, got B %d N %d" % (B, N))
     if ws is None or ws.numel() < need:
         ws = _ws(need, pts.device)
     tp = (C.c_void_p * 5)(*[_chk(t, "tap").data_ptr() for t in taps])

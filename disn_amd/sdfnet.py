@@ -60,8 +60,8 @@ def get_sdf_basic2_imgfeat_twostream(src_pc, point_feat, is_training, batch_size
         eng = sess.engine
         pc, feat = eng._dev(pc), eng._dev(feat)
         emb = torch.zeros((pc.shape[0], 1024), dtype=torch.float32, device=pc.device)
-        _, _, l = ops.sdf_mlp(eng.weights.mlp, pc, emb, feat.reshape(pc.shape[0], pc.shape[1], FEAT_DIM),
-                              want_streams=True)
+        feat = eng.internal_features(feat.reshape(pc.shape[0], pc.shape[1], FEAT_DIM))   # end-point units -> the engine's
+        _, _, l = ops.sdf_mlp(eng.weights.mlp, pc, emb, feat, want_streams=True)
         return l.reshape(l.shape[0], -1, 1)
 
     return SymTensor('pred_sdf_value_local', (shp[0], shp[1], 1), fn, (src_pc, point_feat))

@@ -150,6 +150,43 @@ class WeightStore:
         prefix = tfc.get_checkpoint_state(directory)
         return None if prefix is None else cls.load_tf(prefix, num_classes)
 
+    # -- equalised inference copy (include/disn_amd.h, disn_equalise_weights) -----------------------------------
+    def equalised(self) -> Tuple["WeightStore", np.ndarray, np.ndarray]:
+        """-> (store', tap_scale [1472], span_log2 [23]): a COPY of the variables with every hidden channel multiplied
+        by a power of two and its consumers' rows divided by it (the library's host routine; exact: the network
+        function and every fp32 rounding are unchanged, models/model_normalization.py:74-78,171-204).  What the
+        inference engine uploads: the channels of every hidden tensor then have comparable magnitudes, which the
+        per-image operand scale of the two-term f16 kernels needs on trained weights.  Taps / gathered features
+        computed with store' are in equalised units: true = value / tap_scale[channel]."""
+        import ctypes as C
+        from ._lib import EqWeights, lib
+        if not self.complete():
+            raise ValueError("WeightStore is incomplete")
+        out = WeightStore(num_classes=self.num_classes)
+        # fc7 / fc8 (and every bias the routine does not touch) are shared, not copied: it never writes them
+        touched = set(n + sfx for n in VGG_CONV_NAMES for sfx in ("/weights", "/biases"))
+        touched.add("vgg_16/fc6/weights")
+        touched.update("%s/%s/%s" % (s, l, leaf) for s in MLP_SCOPES for l in MLP_LAYERS for leaf in ("weights", "biases"))
+        for k, a in self.arrays.items():
+            out.arrays[k] = np.array(a, dtype=np.float32, order="C", copy=True) if k in touched else a
+        w = EqWeights()
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        for i, nm in enumerate(VGG_CONV_NAMES):
+            w.conv_w[i] = ptr(out.arrays[nm + "/weights"])
+            w.conv_b[i] = ptr(out.arrays[nm + "/biases"])
+        w.fc6_w = ptr(out.arrays["vgg_16/fc6/weights"])
+        for s, scope in enumerate(MLP_SCOPES):
+            for l, layer in enumerate(MLP_LAYERS):
+                w.mlp_w[s][l] = ptr(out.arrays["%s/%s/weights" % (scope, layer)])
+                w.mlp_b[s][l] = ptr(out.arrays["%s/%s/biases" % (scope, layer)])
+        w.num_classes = self.num_classes
+        tap_scale = np.ones(FEAT_DIM, np.float32)
+        span = np.zeros(23, np.float32)
+        rc = lib().disn_equalise_weights(C.byref(w), ptr(tap_scale), ptr(span))
+        if rc:
+            raise RuntimeError("disn_equalise_weights failed (status %d)" % rc)
+        return out, tap_scale, span
+
     def __getitem__(self, k: str) -> np.ndarray:
         return self.arrays[k]
 

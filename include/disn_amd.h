@@ -38,7 +38,7 @@ extern "C" {
 #define DISN_E_WS (-3)    /* workspace too small */
 
 /* ABI version of this header; disn_abi_version() returns the library's. */
-#define DISN_ABI_VERSION 8
+#define DISN_ABI_VERSION 9
 int disn_abi_version(void);
 
 /* ---------------------------------------------------------------------- *
@@ -382,13 +382,17 @@ int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, 
  * carries B images.
  * WHICH KERNELS RUN (selection rules; results of different forms agree to fp32 rounding -- all within 1e-5 of the
  * float64 oracle -- and are bit-identical only within one form):
- *   point MLPs  B >= 4 or N >= 8192, N % 128 == 0, featmap == NULL (round 4; with w->g_fused and w->l_feat): the FUSED small-set
- *               kernels -- split-form gather from the taps, mlp_fused_kernel<local, FEAT>, mlp_fused_kernel<global> with
- *               image b's folded bias row: one launch per stream behind the gather, bit-identical to disn_encode +
- *               disn_query_taps_fused.  Otherwise, B <= 512 and N < 8192 (and the *_d* images present): the two-term
- *               f16 layers, one launch per layer -- dense_h2.hip for B < 4 or N % 128 != 0, dense_h2w.hip for B >= 4
- *               (disn_dense_h2's rule); otherwise (N >= 8192 per image with N % 128 != 0 or a feature map asked for; more
- *               than 512 requests of a few points each) the three-term bf16 / f32-input GEMM chain of disn_dense.  disn_query /
+ *   point MLPs  B >= 4 or N >= 8192, featmap == NULL (with w->g_fused and w->l_feat): the FUSED small-set kernels --
+ *               split-form gather from the taps, mlp_fused_kernel<local, FEAT>, mlp_fused_kernel<global> with image b's
+ *               folded bias row: one launch per stream behind the gather, bit-identical to disn_encode +
+ *               disn_query_taps_fused.  ANY N (round 5): the library pads every point set to a multiple of 128 points
+ *               with (0, 0, 0) -- what test/create_sdf.py:241,256 pads its last split with -- and discards those results;
+ *               the fused kernels scale per point, so the real points' bits do not depend on the padding (only when the
+ *               padded B * N exceeds 65536 does such a call fall through to the next rule).
+ *               Otherwise, B <= 512 and N < 8192 (and the *_d* images present): the two-term f16 layers, one launch per
+ *               layer -- dense_h2.hip (B < 4, or B >= 4 with a feature map asked for and N % 128 != 0), dense_h2w.hip
+ *               (B >= 4, N % 128 == 0; disn_dense_h2's rule); otherwise (a feature map asked for at N >= 8192; more than
+ *               512 requests of a few points each) the three-term bf16 / f32-input GEMM chain of disn_dense.  disn_query /
  *               disn_sdf_mlp switch at the same N = 8192 per image.
  *   convolutions / fc head  B < 4: conv_h2.hip + one-launch fc rows; B >= 4: conv_h2w.hip + the split-K fc stream
  *               with up to sixteen batch rows per pass on the fp32 matrix pipe (gemv_mfma_kernel; disn_conv3x3_h2's rule).
@@ -638,6 +642,51 @@ typedef struct disn_cam_weights {
 } disn_cam_weights_t;
 int disn_cam_head(const disn_cam_weights_t* w, const float* embedding, const float* K_host, int B,
                   float* rotation, float* translation, float* RT, float* trans_mat, void* stream);
+
+/* ---------------------------------------------------------------------- *
+ * Host utility (ABI 9): EQUALISED inference weights.  An exact power-of-two *
+ * re-parametrisation of the hidden channels of the network                  *
+ * (models/model_normalization.py:74-78,171-204; models/sdfnet.py:71-88,     *
+ * 173-186), applied IN PLACE to a host COPY of the variables in their TF    *
+ * layouts before they are uploaded / packed (the training state and         *
+ * checkpoints keep the true values).  Channel f of every hidden layer is    *
+ * multiplied by c[f] = the power of two (<= 2^16) that brings the largest   *
+ * entry of its weight column (rows already divided by the producer's        *
+ * factors) to the binade of the layer's MEDIAN column; every consumer row   *
+ * of that channel (next convolution, fc6, the tap rows of                   *
+ * sdfprediction_imgfeat/fold2/conv1, the next MLP layer) is divided by it.  *
+ * ReLU / max-pool / resize / resampler commute with a positive per-channel  *
+ * factor and powers of two are exact: the network function and every fp32   *
+ * rounding are unchanged; what changes is that the channels of a hidden     *
+ * tensor have comparable magnitudes, which the per-image power-of-two       *
+ * operand scale of the two-term f16 kernels needs (22 bits down to 2^-17 of *
+ * the tensor maximum; trained channel gains may span more: DESIGN 4k).      *
+ * Layers: 13 convolutions, then fold1/conv1..fold2/conv2 of both streams;   *
+ * fc6..fc8 and fold2/conv5 produce no equalised channels.                   *
+ * With such weights the TAPS a library call returns (and everything         *
+ * gathered from them) are in equalised units: true = value / tap_scale[ch]  *
+ * (disn_scale_channels), ch = the 1472 concatenated tap channels.           *
+ * span_log2 (optional, 23 floats): log2(largest / smallest factor) of each  *
+ * layer = the spread of channel gains the weights carried.  Columns more    *
+ * than 2^16 BELOW the median are scaled up by 2^16 only (a nearly dead      *
+ * column with an ordinary bias must not become the tensor's maximum); they  *
+ * keep a residual gain -- still exact, full precision down to 2^-33.        *
+ * ---------------------------------------------------------------------- */
+typedef struct disn_eq_weights {
+  float* conv_w[13]; /* HOST, [3,3,Cin,Cout], modified in place */
+  float* conv_b[13];
+  float* fc6_w;      /* HOST, [7,7,512,4096]: rows divided by conv5_3's factors; NULL = not present */
+  float* mlp_w[2][6]; /* [0]: sdfprediction, [1]: sdfprediction_imgfeat; fold1/conv1..3, fold2/conv1, conv2, conv5 */
+  float* mlp_b[2][6];
+  int num_classes;   /* embedding width (1024): sdfprediction/fold2/conv1 has 512 + num_classes rows */
+} disn_eq_weights_t;
+int disn_equalise_weights(const disn_eq_weights_t* w, float* tap_scale_host, float* span_log2_host);
+
+/* out[r][c] = in[r][c] * scale[c] (invert = 0) or in[r][c] / scale[c] (invert != 0; IEEE divide -- exact for the
+ * powers of two of disn_equalise_weights): rows x C floats, device pointers, in == out allowed.  Converts taps
+ * (C = the tap's channels, scale = tap_scale + the tap's offset) or gathered features (C = 1472) between equalised and
+ * true units. */
+int disn_scale_channels(const float* in, int64_t rows, int C, const float* scale, int invert, float* out, void* stream);
 
 /* Host utility: Wavefront .obj writer ("v x y z" / "f a b c", 1-based) for HOST arrays; the
  * reference's output artefact (test/create_sdf.py:311).  Returns 0, or DISN_E_ARG on I/O error. */

@@ -41,6 +41,20 @@ def kat():
         return {k: z[k] for k in z.files}
 
 
+_INTERNAL = {}
+
+
+def internal_arrays(store):
+    """the variables in the units an SdfEngine built from `store` computes in (WeightStore.equalised: hidden channels
+    times powers of two, consumers' rows divided -- the same function): what an oracle continuation has to use when it
+    starts from the engine's OWN taps / feature map (cached per store)"""
+    key = id(store)
+    if key not in _INTERNAL:
+        _INTERNAL.clear()                      # (one store at a time: the copies are ~0.5 GB)
+        _INTERNAL[key] = (store, store.equalised()[0].arrays)
+    return _INTERNAL[key][1]
+
+
 def report_close(name, got, ref, atol, rtol=0.0):
     """assert |got-ref| <= atol + rtol*|ref| with a diagnostic that localises GEMM bugs."""
     got = np.asarray(got, np.float64)

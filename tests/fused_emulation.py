@@ -85,7 +85,9 @@ def pack_image(w2, w3, w4p, w5):
         r = np.ones(w.shape[0], np.float32)
         r[:K] = rrow[:K]
         wr = (w * r[:, None]).astype(np.float32)
-        c = np.array([pow2_scale_for(float(m), 0) for m in np.abs(wr).max(axis=0)], np.float32)
+        cm = np.abs(wr).max(axis=0)
+        cm = np.maximum(cm, np.float32(cm.max() * np.float32(2.0 ** -20)))   # fm::kColFloor: a dead column is not blown up
+        c = np.array([pow2_scale_for(float(m), 0) for m in cm], np.float32)
         meta[ISW_OFF[i]:ISW_OFF[i] + w.shape[1]] = c
         l1p = (np.abs(wr[:K]).sum(axis=0, dtype=np.float32) * c).max()
         if i == 1:

@@ -36,7 +36,8 @@ def case(M, K, N, seed, positive=True):
 
 @pytest.mark.parametrize("M,K,N,relu", [(2048, 64, 256, True), (2048, 256, 512, True), (2048, 512, 512, False),
                                         (2048, 512, 256, True), (777, 256, 512, True), (33, 512, 256, True),
-                                        (5000, 64, 256, True), (1, 512, 512, False), (4096, 1024, 512, True)])
+                                        (5000, 64, 256, True), (1, 512, 512, False), (4096, 1024, 512, True),
+                                        (96, 128, 2048, True), (64, 4096, 4096, True)])   # > 1024 columns / rows: ADVICE r4
 def test_layer_shapes_vs_float64(ops, M, K, N, relu):
     a, w, b = case(M, K, N, M + K + N)
     ref = a.astype(np.float64) @ w.astype(np.float64) + b

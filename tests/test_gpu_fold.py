@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import report_close
+from conftest import internal_arrays, report_close
 from oracle import disn_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -25,7 +25,9 @@ def test_fold_local_vs_float64(eng_store):
     eng, store = eng_store
     rng = np.random.default_rng(1)
     enc = eng.encode(rng.random((2, 137, 137, 3), dtype=np.float32))
-    w = store["sdfprediction_imgfeat/fold2/conv1/weights"][0, 0].astype(np.float64)
+    # (the engine's feature map AND its fold2/conv1 -- rows and columns -- are in equalised units: the oracle product is
+    # formed from the same copy of the variables)
+    w = internal_arrays(store)["sdfprediction_imgfeat/fold2/conv1/weights"][0, 0].astype(np.float64)
     for b in range(2):
         pm = eng.pmap_of(enc, b).cpu().numpy()
         ref = enc.featmap[b].reshape(-1, 1472).cpu().numpy().astype(np.float64) @ w[512:]
@@ -54,7 +56,7 @@ def test_query_folded_vs_unfolded_and_oracle(eng_store, B, N):
     idx = np.arange(0, N, max(1, N // 300))
     sub = pts[:, idx]
     xy = O.get_img_points(sub, tms)
-    feat = O.resampler(enc.featmap.cpu().numpy(), xy)[:, :, None, :]
+    feat = O.resampler(eng.true_features(enc.featmap).cpu().numpy(), xy)[:, :, None, :]
     ref = (O.get_sdf_basic2(sub, enc.embedding.cpu().numpy(), store.arrays, dtype=np.float64)
            + O.get_sdf_basic2_imgfeat_twostream(sub, feat, store.arrays, dtype=np.float64))[..., 0]
     report_close("folded vs oracle", f[:, torch.from_numpy(idx).cuda()].cpu().numpy(), ref, ATOL, RTOL)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, report_close
+from conftest import ROOT, internal_arrays, report_close
 from oracle import disn_oracle as O
 from tests import fused_emulation as E
 
@@ -52,8 +52,9 @@ def test_device_pack_equals_the_layout_restatement(eng_store, scope):
 def _oracle(store, enc, pts, tms):
     xy = O.get_img_points(pts, tms)
     feat = O.resampler(enc.featmap.cpu().numpy(), xy)[:, :, None, :]
-    return (O.get_sdf_basic2(pts, enc.embedding.cpu().numpy(), store.arrays, dtype=np.float64)
-            + O.get_sdf_basic2_imgfeat_twostream(pts, feat, store.arrays, dtype=np.float64))[..., 0]
+    W = internal_arrays(store)     # the engine's own feature map is in ITS units (the equalised copy of the variables)
+    return (O.get_sdf_basic2(pts, enc.embedding.cpu().numpy(), W, dtype=np.float64)
+            + O.get_sdf_basic2_imgfeat_twostream(pts, feat, W, dtype=np.float64))[..., 0]
 
 
 @pytest.mark.parametrize("B,N", [(1, 1), (1, 127), (1, 4097), (2, 1000), (1, 70001)])
@@ -196,8 +197,9 @@ def _oracle_taps(store, enc, pts, tms):
     fm = np.concatenate([O.resize_bilinear_legacy(t.cpu().numpy(), 137, 137) for t in enc.taps], axis=3)
     xy = O.get_img_points(pts, tms)
     feat = O.resampler(fm, xy)[:, :, None, :]
-    return (O.get_sdf_basic2(pts, enc.embedding.cpu().numpy(), store.arrays, dtype=np.float64)
-            + O.get_sdf_basic2_imgfeat_twostream(pts, feat, store.arrays, dtype=np.float64))[..., 0]
+    W = internal_arrays(store)     # the engine's own taps are in ITS units (the equalised copy of the variables)
+    return (O.get_sdf_basic2(pts, enc.embedding.cpu().numpy(), W, dtype=np.float64)
+            + O.get_sdf_basic2_imgfeat_twostream(pts, feat, W, dtype=np.float64))[..., 0]
 
 
 @pytest.mark.parametrize("B,N", [(1, 128), (2, 256), (3, 1152), (4, 2048), (5, 640), (16, 2048)])
@@ -254,6 +256,39 @@ def test_batched_encode_query_runs_the_fused_small_set_kernels(eng_store, B, N):
         assert torch.equal(a, b)
     q = ops.query_taps_fused(eng.weights.mlp, enc2.taps, enc2.embedding, tms, pts)
     assert torch.equal(pred, q), float((pred - q).abs().max())
+
+
+@pytest.mark.parametrize("B,N", [(5, 1000), (4, 1), (1, 9000)])
+def test_ragged_point_sets_are_padded_inside_the_library(eng_store, B, N):
+    """a batched call (or a single request of >= 8192 points) whose N is not a multiple of 128 runs
+    the fused small-set kernels all the same -- the library pads every point set with (0, 0, 0) (test/create_sdf.py:241,256)
+    and drops those results.  Bit for bit the caller-padded call's first N results, through disn_encode_query and
+    through disn_query_taps_fused; within the bar of the float64 oracle."""
+    from disn_amd import ops
+    eng, store = eng_store
+    rng = np.random.default_rng(B * 17 + N)
+    Np = (N + 127) // 128 * 128
+    imgs = torch.from_numpy(rng.random((B, 137, 137, 3), dtype=np.float32)).cuda()
+    pts = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    padded = np.zeros((B, Np, 3), np.float32)
+    padded[:, :N] = pts
+    tms = np.stack([O.DEMO_TRANS_MAT[0] if b % 2 == 0 else O.synth_trans_mat(40 + 25 * b, 20, 0.8) for b in range(B)])
+    dp, dpp, dt = torch.from_numpy(pts).cuda(), torch.from_numpy(padded).cuda(), torch.from_numpy(tms).cuda()
+    enc, a = eng.encode_query(imgs, dp, dt)
+    _, b = eng.encode_query(imgs, dpp, dt)
+    assert a.shape == (B, N)
+    assert torch.equal(a, b[:, :N]), float((a - b[:, :N]).abs().max())
+    q = ops.query_taps_fused(eng.weights.mlp, enc.taps, enc.embedding, dt, dp)
+    assert torch.equal(q, a)
+    rot = torch.from_numpy((pts * np.float32(0.5)).astype(np.float32)).cuda()         # pts_rot != pts: its own pad buffer
+    padrot = torch.zeros((B, Np, 3), device="cuda")
+    padrot[:, :N] = rot
+    r1 = eng.encode_query(imgs, dp, dt, pts_rot=rot)[1]
+    r2 = eng.encode_query(imgs, dpp, dt, pts_rot=padrot)[1]
+    assert torch.equal(r1, r2[:, :N])
+    d = {"imgs": imgs[:1].cpu().numpy(), "sample_pc": pts[:1, :256], "sample_pc_rot": pts[:1, :256], "trans_mat": tms[:1]}
+    ref = O.get_model(d, store.arrays, dtype=np.float64)["pred_sdf"][0, :, 0]
+    report_close("padded call vs float64", a[0, :256].cpu().numpy(), ref[:min(N, 256)], 1e-5)
 
 
 def test_batched_call_with_a_degenerate_camera(eng_store):

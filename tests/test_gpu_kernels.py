@@ -263,7 +263,8 @@ def _mlp_weights(mode="he"):
     from disn_amd.engine import DeviceWeights
     from disn_amd.weights import WeightStore
     store = WeightStore.random_init(0, mode=mode)
-    return store, DeviceWeights(store, torch.device("cuda", 0))
+    # (kernel-level tests feed their own features: the variables as they are, not the engine's equalised copy)
+    return store, DeviceWeights(store, torch.device("cuda", 0), equalise=False)
 
 
 def test_sdf_mlp_vs_oracle(ops):

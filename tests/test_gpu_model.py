@@ -388,7 +388,9 @@ def test_batched_images_equal_single_images():
     for b in range(B):
         e1 = eng.encode(imgs[b:b + 1])
         report_close("embedding[%d]" % b, enc.embedding[b].cpu().numpy(), e1.embedding[0].cpu().numpy(), ATOL, RTOL)
-        report_close("featmap[%d]" % b, enc.featmap[b].cpu().numpy(), e1.featmap[0].cpu().numpy(), ATOL, RTOL)
+        # (in the reference's units: the tolerance is an absolute one)
+        report_close("featmap[%d]" % b, eng.true_features(enc.featmap[b]).cpu().numpy(),
+                     eng.true_features(e1.featmap[0]).cpu().numpy(), ATOL, RTOL)
     batch = cs.create_sdf(eng, imgs, tms, sps, R)
     assert batch.shape == (B, (R + 1) ** 3)
     for b in range(B):

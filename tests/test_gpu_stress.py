@@ -59,7 +59,7 @@ def test_batched_form_on_trained_like_statistics(stress):
         worst = max(worst, _report("batched call, image %d" % b, pred[b].cpu().numpy().reshape(-1), g["pred64_a"][b]))
     assert worst <= PRED_ATOL
     stride = int(g["tap_stride"])
-    for t, nm in zip(enc.taps, O.TAP_NAMES):
+    for t, nm in zip(s["eng"].true_taps(enc), O.TAP_NAMES):     # (the engine computes in equalised units)
         got = t.cpu().numpy()[[0, 3]].reshape(2, -1)[:, ::stride].astype(np.float64)
         for i in range(2):
             scale = float(g["tapmax_" + nm][i])

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, name), "library does not export %s" % name
     from disn_amd import _lib
     assert set(_lib.SIGNATURES) == declared, (set(_lib.SIGNATURES) ^ declared)
-    assert _lib.lib().disn_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.lib().disn_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_code_object_targets_gfx950():
@@ -219,3 +219,75 @@ def test_product_library_has_no_tuning_knobs():
     for f in os.listdir(csrc):
         if f.endswith((".hip", ".cpp", ".hpp")):
             assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_equalised_weights_are_the_same_network():
+    """disn_equalise_weights (WeightStore.equalised; host routine, no GPU): every hidden channel times a power of two,
+    its consumers' rows divided by it (models/model_normalization.py:74-78,171-204, models/sdfnet.py:71-88,173-186).
+    (1) the float32 oracle returns the SAME BITS for pred_sdf / the embedding on the equalised copy -- powers of two
+    commute with every fp32 rounding on the way; (2) taps / gathered features differ by exactly tap_scale; (3) on
+    trained-like statistics (sigma = 2 channel gains, 1 % outliers x 10^4) every tap's channel maxima collapse from a
+    span of > 2^20 to a few binades; (4) a second pass finds nothing left to do; (5) the original store is untouched
+    and the tensors the routine never writes are shared, not copied."""
+    from disn_amd.weights import WeightStore
+    from oracle import disn_oracle as O
+    for label, W in (("he", O.init_weights(3, "he")),
+                     ("trained-like", O.trained_like_weights(3, sigma=2.0, outlier_gain=1e4))):
+        st = WeightStore(W)
+        before = {k: v.copy() for k, v in st.arrays.items() if "conv1_2" in k or "fold2/conv1" in k}
+        eq, ts, span = st.equalised()
+        assert all(np.array_equal(before[k], st.arrays[k]) for k in before)
+        assert st.arrays["vgg_16/fc7/weights"] is eq.arrays["vgg_16/fc7/weights"]
+        assert not np.shares_memory(st.arrays["vgg_16/fc6/weights"], eq.arrays["vgg_16/fc6/weights"])
+        assert ts.shape == (1472,) and span.shape == (23,)
+        m, e = np.frexp(ts)
+        assert np.all(m == 0.5), "tap factors must be powers of two"
+        feed = O.synth_inputs(3, 1, 64)
+        a, b = O.get_model(feed, st.arrays), O.get_model(feed, eq.arrays)
+        assert np.array_equal(a["pred_sdf"], b["pred_sdf"]) and np.array_equal(a["img_embedding"], b["img_embedding"])
+        fa, fb = a["point_img_feat"][0, :, 0, :], b["point_img_feat"][0, :, 0, :]
+        assert np.array_equal(fa, fb / ts)
+        if label == "he":
+            assert span.max() <= 6
+        else:
+            assert span.max() >= 20
+            ca, cb = np.abs(fa).max(0), np.abs(fb).max(0)
+            for o, c in ((0, 64), (64, 128), (192, 256), (448, 512), (960, 512)):
+                live = ca[o:o + c] > 0
+                sa = np.log2(ca[o:o + c][live].max() / ca[o:o + c][live].min())
+                sb = np.log2(cb[o:o + c][live].max() / cb[o:o + c][live].min())
+                print("tap channels %4d..%4d: log2 span of the channel maxima %.1f -> %.1f" % (o, o + c, sa, sb))
+                assert sb <= sa
+            assert np.log2(cb[cb > 0].max() / np.median(cb[cb > 0])) <= 8
+        eq2, ts2, span2 = eq.equalised()
+        assert span2.max() <= 1 and np.all((ts2 == 1.0) | (ts2 == 0.5) | (ts2 == 2.0))
+
+
+def test_equalisation_does_not_blow_up_a_dead_column():
+    """a hidden channel whose weight column is 2^-40 of its neighbours' (a dead feature with an ordinary bias) is scaled
+    up by at most 2^16: its bias must not become the tensor's maximum (ADVICE r4 on the fused images, same rule here)"""
+    from disn_amd.weights import WeightStore
+    st = WeightStore.random_init(1, mode="he")
+    w = st.arrays["vgg_16/conv3/conv3_2/weights"]
+    w[:, :, :, 7] *= np.float32(2.0 ** -40)
+    eq, ts, span = st.equalised()
+    c7 = eq.arrays["vgg_16/conv3/conv3_2/biases"][7] / st.arrays["vgg_16/conv3/conv3_2/biases"][7]
+    assert c7 == 2.0 ** 16
+    nxt = eq.arrays["vgg_16/conv3/conv3_3/weights"][:, :, 7, :] * np.float32(2.0 ** 16)
+    ref = st.arrays["vgg_16/conv3/conv3_3/weights"][:, :, 7, :]
+    c_out = eq.arrays["vgg_16/conv3/conv3_3/biases"] / st.arrays["vgg_16/conv3/conv3_3/biases"]
+    assert np.array_equal(nxt, ref * c_out[None, None, :])
+    assert h_status(eq) == 0
+
+
+def h_status(store):
+    """disn_equalise_weights argument validation"""
+    import ctypes as C
+    from disn_amd import _lib
+    w = _lib.EqWeights()
+    assert _lib.lib().disn_equalise_weights(C.byref(w), None, None) == -1
+    ts = np.ones(1472, np.float32)
+    assert _lib.lib().disn_equalise_weights(C.byref(w), ts.ctypes.data_as(C.c_void_p), None) == -1   # null tensors
+    assert _lib.lib().disn_scale_channels(None, 1, 64, None, 0, None, None) == -1
+    assert _lib.lib().disn_scale_channels(1, 1, 6, 1, 0, 1, None) == -2
+    return 0

@@ -170,3 +170,31 @@ def test_gradient_reducer_gloo_world2_matches_single_process():
         w, m, v = T.adam_step(w, g, m, v, t, 1e-2)
     assert np.array_equal(results[0], results[1])              # replicas stay bit-identical
     assert np.allclose(results[0], w, rtol=0, atol=1e-12)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("workload", ["grid", "train", "query"])
+def test_bench_launch_path_dry_run_world_2(workload):
+    """the argument path the driver would use for the scaling runs -- `python bench.py --gpus N
+    --workload W` self-launching `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    ...`, RANK / WORLD_SIZE from the environment, rendezvous, barrier, max-over-ranks time, ONE contract line from rank
+    0 -- exercised on the CPU over gloo with the compute left out (bench.py --dry-run); for the grid workload the ranks'
+    flat-index slices must tile the 257^3 grid"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", workload, "--dry-run",
+                        "--dist-backend", "gloo", "--steps", "3", "--warmup", "1"], capture_output=True, text=True,
+                       timeout=500, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in line
+    assert line["dry_run"] is True and line["value"] is None and line["n_gpus"] == 2 and line["steps"] == 3
+    assert "workload" in line["config"] and "model" not in line["config"]
+    if workload == "grid":
+        assert line["grid_points"] == 257 ** 3 and line["slice_rank0"] == [0, (257 ** 3 + 1) // 2]

@@ -1,0 +1,63 @@
+"""error of the encoder's stages by form on sweep set 4 (needs tools/_diag_set04.npz: float64 intermediates on the
+equalised variables, /tmp/gen_diag.py): taps (batched | single conv kernels) and the fc head (matrix-pipe | VALU split-K)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_golden_sweep as MS   # noqa: E402
+from disn_amd import ops   # noqa: E402
+from disn_amd.engine import SdfEngine   # noqa: E402
+from disn_amd.weights import WeightStore   # noqa: E402
+from oracle import disn_oracle as O   # noqa: E402
+
+g = np.load(os.path.join(ROOT, "tools", "_diag_set04.npz"))
+s = MS.sweep_inputs()
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+seed, sigma, outlier = MS.SETS[4]
+store = WeightStore(O.trained_like_weights(seed, sigma=sigma, outlier_gain=outlier))
+eq = store.equalised()[0]
+eng = SdfEngine(store)
+imgs = dev(s["imgs"])
+enc_b = eng.encode(torch.cat([imgs, imgs]))
+singles = [eng.encode(imgs[b:b + 1]) for b in range(8)]
+for k, nm in enumerate(O.TAP_NAMES):
+    ref = g["tap64_" + nm]
+    tb = enc_b.taps[k][:8, ::3, ::3, :].cpu().numpy().astype(np.float64)
+    ts = torch.cat([e.taps[k] for e in singles])[:, ::3, ::3, :].cpu().numpy().astype(np.float64)
+    sc = np.abs(ref).reshape(8, -1).max(1)
+    eb = np.abs(tb - ref).reshape(8, -1).max(1) / sc
+    es = np.abs(ts - ref).reshape(8, -1).max(1) / sc
+    rb = np.sqrt(((tb - ref) ** 2).reshape(8, -1).mean(1)) / sc
+    rs = np.sqrt(((ts - ref) ** 2).reshape(8, -1).mean(1)) / sc
+    print("%s: max err / tap max  batched %s | single %s ;  rms/max batched %.2e single %.2e" % (
+        nm, " ".join("%.1e" % v for v in eb), " ".join("%.1e" % v for v in es), rb.mean(), rs.mean()))
+# the fc head alone, from the float64 pool5 rounded to fp32
+W = eq.arrays
+fcw = [dev(W["vgg_16/%s/weights" % n].reshape(-1, W["vgg_16/%s/weights" % n].shape[3])) for n in ("fc6", "fc7", "fc8")]
+fcb = [dev(W["vgg_16/%s/biases" % n]) for n in ("fc6", "fc7", "fc8")]
+def head(x):
+    h = ops.fc(x, fcw[0], fcb[0], True)
+    h = ops.fc(h, fcw[1], fcb[1], True)
+    return ops.fc(h, fcw[2], fcb[2], False)
+p5 = dev(g["pool5_64"].reshape(8, -1))
+e64 = g["emb64"]
+sc = np.abs(e64).max(1)
+m = head(torch.cat([p5, p5]))[:8].cpu().numpy()
+v = torch.cat([head(p5[b:b + 1]) for b in range(8)]).cpu().numpy()
+print("fc head alone (exact pool5): err / |emb| max   16 rows (matrix pipe) %s | 1 row (VALU) %s" % (
+    " ".join("%.1e" % x for x in np.abs(m - e64).max(1) / sc), " ".join("%.1e" % x for x in np.abs(v - e64).max(1) / sc)))
+# the GPU's own pool5 of each conv form through each fc form
+for cn, tap in (("batched conv", enc_b.taps[4][:8].contiguous()), ("single conv ", torch.cat([e.taps[4] for e in singles]))):
+    p = ops.maxpool2x2(tap).reshape(8, -1).contiguous()
+    m = head(torch.cat([p, p]))[:8].cpu().numpy()
+    v = torch.cat([head(p[b:b + 1]) for b in range(8)]).cpu().numpy()
+    print("%s: emb err / max   fc 16 rows %s | fc 1 row %s" % (cn, " ".join("%.1e" % x for x in np.abs(m - e64).max(1) / sc),
+                                                                " ".join("%.1e" % x for x in np.abs(v - e64).max(1) / sc)))
+print("engine embeddings: batched %s | single %s" % (
+    " ".join("%.1e" % x for x in np.abs(enc_b.embedding[:8].cpu().numpy() - e64).max(1) / sc),
+    " ".join("%.1e" % x for x in np.abs(torch.cat([e.embedding for e in singles]).cpu().numpy() - e64).max(1) / sc)))
