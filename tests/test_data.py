@@ -2,6 +2,8 @@
 epoch order, the producer thread.  CPU only; a synthetic dataset is written as .npz files."""
 import types
 
+import os
+
 import numpy as np
 import pytest
 
@@ -290,3 +292,56 @@ def test_loader_reads_reference_style_h5_files(tmp_path, monkeypatch):
     monkeypatch.setattr(builtins, "__import__", no_h5py)
     got = D._load(path, ["c", "z", "missing"])
     assert sorted(got) == ["c", "z"] and np.array_equal(got["z"], want["z"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 5: files WRITTEN BY libhdf5 (tests/golden/h5/, generated by tests/golden/make_h5_fixtures.py with the h5py 3.3.0 /
+# HDF5 1.10.6 of this image's conda tree: the reference's own create_dataset calls, preprocessing/create_point_sdf_grid.py
+# :154-158 and preprocessing/create_img_h5.py:188-200, plus the other layouts h5py produces) -- the reader against files
+# it did not shape itself
+# ---------------------------------------------------------------------------------------------------------------
+H5_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "h5")
+H5_SHA256 = {   # the committed fixtures (sha256 of the bytes libhdf5 wrote)
+    "ori_sample.h5": None, "img_00.h5": None, "layouts.h5": None}
+
+
+def test_hdf5_reader_reads_libhdf5_written_files():
+    import hashlib
+    from disn_amd.hdf5_lite import Hdf5File
+    exp = np.load(os.path.join(H5_DIR, "expected.npz"))
+    seen = set()
+    for key in exp.files:
+        fn, name = key.split(":")
+        f = Hdf5File(os.path.join(H5_DIR, fn))
+        got = np.asarray(f[name])
+        want = exp[key]
+        assert got.dtype == want.dtype and got.shape == want.shape, (key, got.dtype, got.shape)
+        assert np.array_equal(got, want), key
+        seen.add(fn)
+    assert seen == set(H5_SHA256)
+    sums = {fn: hashlib.sha256(open(os.path.join(H5_DIR, fn), "rb").read()).hexdigest() for fn in H5_SHA256}
+    recorded = dict(reversed(l.split()) for l in open(os.path.join(H5_DIR, "SHA256SUMS")).read().splitlines() if l.strip())
+    assert sums == {fn: recorded[fn] for fn in H5_SHA256}, "fixture bytes changed: re-run make_h5_fixtures.py and update SHA256SUMS"
+    # top-level listing as h5py's keys()
+    assert sorted(Hdf5File(os.path.join(H5_DIR, "ori_sample.h5")).keys()) == ["norm_params", "pc_sdf_original", "pc_sdf_sample", "sdf_params"]
+
+
+def test_loader_reads_the_libhdf5_written_reference_files(monkeypatch):
+    """data_sdf._load (data/data_sdf_h5_queue.py:121-186's h5py reads) on the libhdf5-written files, h5py absent"""
+    import builtins
+    import disn_amd.data_sdf as D
+    real = builtins.__import__
+
+    def no_h5py(name, *a, **k):
+        if name == "h5py":
+            raise ImportError("h5py is not installed")
+        return real(name, *a, **k)
+
+    monkeypatch.setattr(builtins, "__import__", no_h5py)
+    exp = np.load(os.path.join(H5_DIR, "expected.npz"))
+    got = D._load(os.path.join(H5_DIR, "ori_sample.h5"), ("pc_sdf_original", "pc_sdf_sample", "norm_params", "sdf_params"))
+    for k in ("pc_sdf_original", "pc_sdf_sample", "norm_params", "sdf_params"):
+        assert np.array_equal(np.asarray(got[k]), exp["ori_sample.h5:" + k]), k
+    img = D._load(os.path.join(H5_DIR, "img_00.h5"), ("img_arr", "trans_mat", "K", "RT"))
+    assert np.array_equal(np.asarray(img["img_arr"]), exp["img_00.h5:img_arr"]) and img["img_arr"].dtype == np.uint8
+    assert np.array_equal(np.asarray(img["trans_mat"]), exp["img_00.h5:trans_mat"])
