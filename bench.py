@@ -364,6 +364,10 @@ def main():
                     help="dense-grid / large queries through the layer-by-layer GEMM chain instead of the fused kernels")
     ap.add_argument("--dist-backend", choices=("auto", "nccl", "gloo"), default="auto",
                     help="auto: nccl (= RCCL); gloo when ranks must share a GPU (RCCL rejects duplicate devices)")
+    ap.add_argument("--strict", action="store_true",
+                    help="--workload query: disn_vgg_weights_t.conv_form = 1 -- the single-image convolution kernels for calls "
+                         "of any size (a request's taps are bit for bit those of the request alone; every request "
+                         "of the trained-like sweep within 1e-5 of the float64 oracle) at about a third less throughput")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercise the launch path only (self-launch -> torch.distributed.run -> rendezvous on "
                          "127.0.0.1 -> barrier / max-over-ranks timing -> ONE contract line from rank 0 with value null and "
@@ -435,7 +439,7 @@ def main():
     store = WeightStore.random_init(0, mode="xavier")          # "random-init weights" (create_sdf.py:184-192)
     S = max(1, args.in_flight)
     SB = max(1, args.batch)
-    pipe = StepPipeline(store, dev, in_flight=S, batch=SB)
+    pipe = StepPipeline(store, dev, in_flight=S, batch=SB, strict=args.strict)
     eng = pipe.engines[0]
     rng = np.random.default_rng(1000 + rank)
     # every step of a call -- and of the calls in flight beside it -- has its own image, point set and camera:
@@ -540,7 +544,9 @@ def main():
                  "gather / projection / resize / fc: fp32 FMA)",
         "data": "synthetic", "steps_per_call": SB, "calls_in_flight": S,
         "config": {"workload": "BASELINE config 2: VGG-16 encode + 2048 random query points, img_feat_twostream, "
-                               "fp32, random-init (xavier) weights, nothing cached between steps",
+                               "fp32, random-init (xavier) weights, nothing cached between steps" + (
+                                   " [--strict: single-image convolution kernels for every call size]" if args.strict else ""),
+                   "strict": bool(args.strict),
                    "images_per_step_per_gpu": 1, "points_per_step_per_gpu": N_POINTS,
                    "steps_per_call": SB, "calls_in_flight": S, "spinup_s": args.spinup_s,
                    "distinct_jobs": POOL, "max_abs_diff_of_a_repeated_job": rep_diff,
@@ -576,6 +582,32 @@ def main():
         except Exception as e:   # a failing extra must not cost the contract line
             line.setdefault("extras_failed", {})['one step at a time'] = repr(e)
             print("[bench] extra failed: %s: %r" % ('one step at a time', e), file=sys.stderr)
+        # ---- strict mode (conv_form = 1): the same submission through the single-image convolution kernels -------
+        try:
+            if not args.strict and SB >= 4:
+                pipe_s = StepPipeline(store, dev, in_flight=S, batch=SB, strict=True)
+                ncall = 4 * S
+                calls_s = [(pool_img[(g * SB) % POOL:(g * SB) % POOL + SB], pool_pts[(g * SB) % POOL:(g * SB) % POOL + SB],
+                            pool_tm[(g * SB) % POOL:(g * SB) % POOL + SB]) for g in range(ncall)]
+                pipe_s.run_calls(calls_s)
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                res_s = pipe_s.run_calls(calls_s)
+                torch.cuda.synchronize()
+                dts = time.perf_counter() - ts
+                d_fast = float((res_s[0] - torch.cat(outs[:SB])).abs().max()) if len(outs) >= SB else None
+                line["strict_mode"] = {"points_per_s": ncall * SB * N_POINTS / dts, "ms_per_step": 1e3 * dts / (ncall * SB),
+                                       "steps": ncall * SB, "max_abs_diff_to_the_default_form": d_fast,
+                                       "note": "disn_vgg_weights_t.conv_form = 1 (StepPipeline(strict=True), --strict): the "
+                                               "single-image convolution kernels (k-wave tree) for every call size; a request's "
+                                               "taps are bit for bit those of the request alone.  Accuracy of both "
+                                               "modes: cpu_baseline.parity_trained_like.sweep"}
+                pipe_s.close()
+                del pipe_s, res_s
+                torch.cuda.empty_cache()
+        except Exception as e:   # a failing extra must not cost the contract line
+            line.setdefault("extras_failed", {})['strict mode'] = repr(e)
+            print("[bench] extra failed: %s: %r" % ('strict mode', e), file=sys.stderr)
         # ---- roofline of the dominant kernel family: the 13 convolution launches of one step ----------------
         try:
             # Timed as the step runs them: ONE disn_vgg16_conv_stack call = resize + conv1_1_direct_kernel + 12
@@ -969,7 +1001,7 @@ def main():
                 import make_golden_sweep as MSW
                 gs = np.load(os.path.join(gdir, "stress_sweep.npz"))
                 sw = MSW.sweep_inputs()
-                errs, per_set = {"single": [], "batch16": []}, []
+                errs, per_set = {"single": [], "batch16": [], "strict16": []}, []
                 for (seed_, sg_, og_) in ((MSW.SEEDS[2], 1.0, 1e4), (MSW.SEEDS[1], 1.5, 1e3), (MSW.SEEDS[0], 2.0, 1e4)):
                     i_ = MSW.SETS.index((seed_, sg_, og_))
                     eng_s = SdfEngine(WeightStore(O.trained_like_weights(seed_, sigma=sg_, outlier_gain=og_)), dev)
@@ -980,11 +1012,18 @@ def main():
                                              td(np.concatenate([sw["pts"][:, 0], sw["pts"][:, 1]])),
                                              td(np.concatenate([sw["trans_mat"], sw["trans_mat"]])))[1].cpu().numpy()
                     e16 = [float(np.abs(p16[k] - gs["pred64_%02d" % i_][k % 8, k // 8]).max()) for k in range(16)]
+                    eng_st = SdfEngine(None, dev, weights=eng_s.weights, strict=True)
+                    ps16 = eng_st.encode_query(td(np.concatenate([sw["imgs"], sw["imgs"]])),
+                                               td(np.concatenate([sw["pts"][:, 0], sw["pts"][:, 1]])),
+                                               td(np.concatenate([sw["trans_mat"], sw["trans_mat"]])))[1].cpu().numpy()
+                    es16 = [float(np.abs(ps16[k] - gs["pred64_%02d" % i_][k % 8, k // 8]).max()) for k in range(16)]
+                    del eng_st
                     errs["single"] += e1
                     errs["batch16"] += e16
+                    errs["strict16"] += es16
                     per_set.append({"seed": seed_, "sigma": sg_, "outlier_gain": og_,
                                     "channel_gain_span_log2": eng_s.weights.status["max_span_log2"],
-                                    "single_worst": max(e1), "batch16_worst": max(e16),
+                                    "single_worst": max(e1), "batch16_worst": max(e16), "strict16_worst": max(es16),
                                     "oracle32_minus_f64": float(gs["o32_%02d" % i_])})
                     del eng_s
                     torch.cuda.empty_cache()
@@ -992,6 +1031,7 @@ def main():
                                    "p90": float(np.sort(v)[int(0.9 * (len(v) - 1))]), "max": float(np.max(v))}
                 parity_tl["sweep"] = {"sets": per_set, "single_step_form": dist_(errs["single"]),
                                       "batched_call_form_16": dist_(errs["batch16"]),
+                                      "strict_call_form_16": dist_(errs["strict16"]),
                                       "worst": max(errs["single"] + errs["batch16"]), "bar": 1e-5,
                                       "equalised_weights": True,
                                       "reference": "tests/golden/stress_sweep.npz (float64 oracle); the full sweep: "

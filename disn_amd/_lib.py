@@ -36,7 +36,8 @@ class VggWeights(C.Structure):  # disn_vgg_weights_t
                 ("fc_w", C.c_void_p * 3), ("fc_b", C.c_void_p * 3), ("num_classes", C.c_int),
                 ("conv_w_x3", C.c_void_p * 13),   # optional three-term bf16 images (disn_pack_kn_x3)
                 ("conv_w_h2", C.c_void_p * 13),   # optional two-term f16 images (disn_pack_conv_h2)
-                ("fc_w_t", C.c_void_p * 3)]       # optional transposed fc matrices [N][K]
+                ("fc_w_t", C.c_void_p * 3),       # optional transposed fc matrices [N][K]
+                ("conv_form", C.c_int)]           # 1: single-image convolution kernels for every call size ("strict")
 
 
 MLP_FIELDS = ("g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3", "g_w4_point", "g_w4_global", "g_b4",

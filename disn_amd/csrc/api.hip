@@ -204,32 +204,33 @@ DenseH2Prob h2_prob(const float* a, int K, const void* img, const float* bias, i
 float* h2_slots(const MlpWs& s, int b) { return s.amax + (size_t)b * 1024; }
 constexpr int kFeatMaxSlot = 576;  // floats 576 .. 1023 of a set: up to 448 per-workgroup maxima of the gather
 
-DenseH2Prob h2_batched(DenseH2Prob p, int imgs, int n) {
+DenseH2Prob h2_batched(DenseH2Prob p, int imgs, int n, bool no_wide = false) {
   if (imgs > 1) { p.M = imgs * n; p.amax_rows = n; p.amax_stride = 1024; }
+  p.no_wide = no_wide ? 1 : 0;   // "strict" (disn_vgg_weights_t.conv_form = 1): never the batched form of dense_h2w.hip
   return p;
 }
 
 // fold1 of BOTH streams: embedding (+ its maxima per image, + clearing the later layers' slots and the zero bias
 // row), then conv2 and conv3 of the two streams as two paired launches
 int mlp_fold1_h2(const disn_mlp_weights_t* w, const float* pts_rot, int n, const MlpWs& s, int b, size_t o, int imgs,
-                 hipStream_t st) {
+                 hipStream_t st, bool nw = false) {
   float* A = h2_slots(s, b);
   DISN_TRY(pt_embed_launch(pts_rot, (int64_t)imgs * n, w->g_w1, w->g_b1, w->l_w1, w->l_b1, s.e1g + o * 64, s.e1l + o * 64, st,
                            A, b == 0 ? s.zero512 : nullptr, b == 0 ? 512 : 0, imgs));
-  DenseH2Prob p2[2] = {h2_batched(h2_prob(s.e1g + o * 64, 64, w->g_d2, w->g_b2, 256, 1, A + 0, s.g256 + o * 256, A + 128, n), imgs, n),
-                       h2_batched(h2_prob(s.e1l + o * 64, 64, w->l_d2, w->l_b2, 256, 1, A + 64, s.h256 + o * 256, A + 192, n), imgs, n)};
+  DenseH2Prob p2[2] = {h2_batched(h2_prob(s.e1g + o * 64, 64, w->g_d2, w->g_b2, 256, 1, A + 0, s.g256 + o * 256, A + 128, n), imgs, n, nw),
+                       h2_batched(h2_prob(s.e1l + o * 64, 64, w->l_d2, w->l_b2, 256, 1, A + 64, s.h256 + o * 256, A + 192, n), imgs, n, nw)};
   DISN_TRY(dense_h2_launch(p2, 2, st));
-  DenseH2Prob p3[2] = {h2_batched(h2_prob(s.g256 + o * 256, 256, w->g_d3, w->g_b3, 512, 1, A + 128, s.g512 + o * 512, A + 256, n), imgs, n),
-                       h2_batched(h2_prob(s.h256 + o * 256, 256, w->l_d3, w->l_b3, 512, 1, A + 192, s.h512a + o * 512, A + 320, n), imgs, n)};
+  DenseH2Prob p3[2] = {h2_batched(h2_prob(s.g256 + o * 256, 256, w->g_d3, w->g_b3, 512, 1, A + 128, s.g512 + o * 512, A + 256, n), imgs, n, nw),
+                       h2_batched(h2_prob(s.h256 + o * 256, 256, w->l_d3, w->l_b3, 512, 1, A + 192, s.h512a + o * 512, A + 320, n), imgs, n, nw)};
   DISN_TRY(dense_h2_launch(p3, 2, st));
   return 0;
 }
 
 // the point half of the global fold2/conv1: g512 . W4_point, no bias, no ReLU -> `pre` (+ its maximum)
 int mlp_g4_pre_h2(const disn_mlp_weights_t* w, int n, const MlpWs& s, int b, size_t o, int imgs, float* pre,
-                  hipStream_t st) {
+                  hipStream_t st, bool nw = false) {
   float* A = h2_slots(s, b);
-  const DenseH2Prob p = h2_batched(h2_prob(s.g512 + o * 512, 512, w->g_d4_point, s.zero512, 512, 0, A + 256, pre, A + 384, n), imgs, n);
+  const DenseH2Prob p = h2_batched(h2_prob(s.g512 + o * 512, 512, w->g_d4_point, s.zero512, 512, 0, A + 256, pre, A + 384, n), imgs, n, nw);
   DISN_TRY(dense_h2_launch(&p, 1, st));
   return 0;
 }
@@ -240,27 +241,27 @@ int mlp_g4_pre_h2(const disn_mlp_weights_t* w, int n, const MlpWs& s, int b, siz
 // forms give the same bits.  l_d4 is the [1984][512] matrix packed with 2048 rows (zero rows at the end).
 // feat_amax_done: the gather left its per-workgroup maxima of |feat| in the set's free tail (project_gather_taps_kernel)
 int mlp_phase1_h2(const disn_mlp_weights_t* w, int n, const float* feat, int feat_ld, const MlpWs& s, int b, size_t o,
-                  int imgs, hipStream_t st, bool feat_amax_done = false) {
+                  int imgs, hipStream_t st, bool feat_amax_done = false, bool nw = false) {
   float* A = h2_slots(s, b);
   if (!feat_amax_done) DISN_TRY(amax64_accumulate_launch(feat, (size_t)n * feat_ld, A + 448, st, imgs, 1024));
   DenseH2Prob p4 = h2_prob(s.h512a + o * 512, 512 + feat_ld, w->l_d4, w->l_b4, 512, 1, A + 320, s.h512b + o * 512,
                            A + 512, n);
   p4.lda = 512; p4.k1 = 512; p4.a2 = feat; p4.lda2 = feat_ld; p4.in_amax2 = A + 448; p4.Kimg = 2048;
   if (feat_amax_done) { p4.in_amax2 = A + kFeatMaxSlot; p4.in_amax2_n = project_gather_taps_amax_blocks(n, feat_ld); }
-  p4 = h2_batched(p4, imgs, n);
+  p4 = h2_batched(p4, imgs, n, nw);
   DISN_TRY(dense_h2_launch(&p4, 1, st));
-  const DenseH2Prob p5 = h2_batched(h2_prob(s.h512b + o * 512, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5 + o * 256, nullptr, n), imgs, n);
+  const DenseH2Prob p5 = h2_batched(h2_prob(s.h512b + o * 512, 512, w->l_d5, w->l_b5, 256, 1, A + 512, s.l5 + o * 256, nullptr, n), imgs, n, nw);
   DISN_TRY(dense_h2_launch(&p5, 1, st));
   return 0;
 }
 
 // global fold2/conv2 on relu(pre + the image's bias row): the deferred bias + ReLU
 int mlp_g5_h2(const disn_mlp_weights_t* w, int n, const float* pre, const float* gbias_b, const MlpWs& s, int b, size_t o,
-              int imgs, hipStream_t st) {
+              int imgs, hipStream_t st, bool nw = false) {
   DenseH2Prob p = h2_prob(pre, 512, w->g_d5, w->g_b5, 256, 1, h2_slots(s, b) + 384, s.g5 + o * 256, nullptr, n);
   p.in_bias = gbias_b;
   if (imgs > 1) p.in_bias_rows = n;
-  p = h2_batched(p, imgs, n);
+  p = h2_batched(p, imgs, n, nw);
   DISN_TRY(dense_h2_launch(&p, 1, st));
   return 0;
 }
@@ -661,7 +662,7 @@ int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* re
     } else if (h2) {
       DISN_TRY(conv_h2_launch(x, B, L.hw, L.hw, L.cin, w->conv_w_h2[i], w->conv_b[i], L.cout, 1,
                               s.amax + (size_t)B * 64 * i, out, kPoolAfter[i] ? s.bufP : nullptr,
-                              s.amax + (size_t)B * 64 * (i + 1), st, 0, 64));
+                              s.amax + (size_t)B * 64 * (i + 1), st, w->conv_form == 1 ? 11 : 0, 64));
       pooled = kPoolAfter[i];
     } else {
       rc = conv3x3_impl(x, B, L.hw, L.hw, L.cin, w->conv_w[i], w->conv_b[i], L.cout, 1, out, s.gemm_ws, gws_cap, st,
@@ -909,7 +910,11 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   // are a B = 1 call's; from 8192 points on it takes the fused kernels too: 2.13 -> 1.40 ms for one request of 65536 points
   // against the three-term GEMM chain this shape ran until round 4, tools/encode_query_forms_time.py)
   const int Np = pad128(N);
-  if (two && conv_h2_all && !featmap && (B >= tune::conv_wide_min || N >= 8192) && fused_small_ok(mw, B, Np)) {
+  // "strict" (disn_vgg_weights_t.conv_form = 1) in a call of >= 4 requests: the single-image forms of the convolutions
+  // (vgg_features) AND of the point-MLP layers (dense_h2.hip's four-k-wave tiles, per-image scales) -- the request's taps
+  // and, up to the fc head's form, its pred_sdf are those of the request alone
+  const bool strict = vw->conv_form == 1 && B >= tune::conv_wide_min && mlp_h2(mw, N);
+  if (!strict && two && conv_h2_all && !featmap && (B >= tune::conv_wide_min || N >= 8192) && fused_small_ok(mw, B, Np)) {
     float* sdf_out = sdf;
     if (Np != N) {   // pad the point sets (both streams run behind the fork / the convolutions anyway)
       DISN_TRY(restride_rows_launch(pts, B, N, e.pad_pts, Np, 3, st));
@@ -952,8 +957,8 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
                // per layer for the whole batch (hb = B images at once) or image by image (hb = 1)
       for (int b = 0; b < B; b += hb) {
         const size_t o = (size_t)b * N;
-        if ((rc = mlp_fold1_h2(mw, pts_rot + o * 3, N, e.q.mlp, b, o, hb, ctx->aux))) return rc;
-        if ((rc = mlp_g4_pre_h2(mw, N, e.q.mlp, b, o, hb, e.q.mlp.g4pre + o * 512, ctx->aux))) return rc;
+        if ((rc = mlp_fold1_h2(mw, pts_rot + o * 3, N, e.q.mlp, b, o, hb, ctx->aux, strict))) return rc;
+        if ((rc = mlp_g4_pre_h2(mw, N, e.q.mlp, b, o, hb, e.q.mlp.g4pre + o * 512, ctx->aux, strict))) return rc;
       }
     } else {
       DISN_TRY(pt_embed_launch(pts_rot, B * N, mw->g_w1, mw->g_b1, mw->l_w1, mw->l_b1, e.q.mlp.e1g, e.q.mlp.e1l, ctx->aux));
@@ -996,7 +1001,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   if (h2) {
     for (int b = 0; b < B; b += hb) {
       const size_t o = (size_t)b * N;
-      if ((rc = mlp_phase1_h2(mw, N, e.q.feat + o * feat_ld, feat_ld, e.q.mlp, b, o, hb, ms, gather_on_st))) return rc;
+      if ((rc = mlp_phase1_h2(mw, N, e.q.feat + o * feat_ld, feat_ld, e.q.mlp, b, o, hb, ms, gather_on_st, strict))) return rc;
     }
   } else if ((rc = mlp_phase1(mw, B * N, e.q.feat, e.q.mlp, ms))) return rc;
   if (two) {
@@ -1007,7 +1012,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   if (h2) {  // global fold2/conv2 on relu(pre + bias) per image, then -- behind ev[6] -- both fold2/conv5 and the sum
     for (int b = 0; b < B; b += hb) {
       const size_t o = (size_t)b * N;
-      if ((rc = mlp_g5_h2(mw, N, e.q.mlp.g4pre + o * 512, e.q.gbias + (size_t)b * 512, e.q.mlp, b, o, hb, st))) return rc;
+      if ((rc = mlp_g5_h2(mw, N, e.q.mlp.g4pre + o * 512, e.q.gbias + (size_t)b * 512, e.q.mlp, b, o, hb, st, strict))) return rc;
     }
     DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
     DISN_TRY(final_dot_launch(e.q.mlp.g5, e.q.mlp.l5, (int64_t)B * N, mw->g_w6, mw->g_b6, mw->l_w6, mw->l_b6, sdf, nullptr,

@@ -764,12 +764,16 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
   // fragment reads for conv5_x of 16 images: L2-bound, 32 % MFMA busy, 65 us), the whole image 21 (52 us).  Smaller
   // calls keep the two-row patches (measured equal to the eight-k-wave tiling at 4 / 8 / 12 images: r03ad).
   if (cfg == 10) return conv_h2_go<7, 1, 16, 14, 3, 4>(d, st);
-  if (cfg == 0 && tune::conv5_whole && W <= 14 && H <= 14 && B >= tune::conv_wide_min) {
+  // cfg 11 ("strict", disn_vgg_weights_t.conv_form = 1): the single-image tilings below by shape, whatever B -- the same
+  // k-waves and summation tree as a call of one image: the same bits
+  const bool strict = cfg == 11;
+  if (strict) cfg = 0;
+  if (!strict && cfg == 0 && tune::conv5_whole && W <= 14 && H <= 14 && B >= tune::conv_wide_min) {
     if ((long)B * (Cout / 32) >= 200) return conv_h2_go<7, 1, 16, 14, 3, 4>(d, st);
     return conv_h2_go<1, 1, 16, 14, 3, 4, 2>(d, st);
   }
   if (cfg >= 5) return conv_h2w_supported(H, W, Cin, Cout) ? conv_h2w_launch(d, st, cfg - 4) : hipErrorInvalidValue;
-  if (cfg == 0 && B >= tune::conv_wide_min && conv_h2w_supported(H, W, Cin, Cout)) return conv_h2w_launch(d, st, 0);
+  if (!strict && cfg == 0 && B >= tune::conv_wide_min && conv_h2w_supported(H, W, Cin, Cout)) return conv_h2w_launch(d, st, 0);
   if (cfg == 0) {
     // patch shape by image width; n-blocks per workgroup so that one image still gives >= ~200 workgroups
     if (W <= 14) cfg = 1;
@@ -838,7 +842,7 @@ int disn_conv3x3_h2(const float* in, int B, int H, int W, int Cin, const void* i
                     int relu, float* out, float* pool_out, float* out_amax, int tiling, void* ws, size_t ws_bytes,
                     void* stream) {
   if (!in || !image || !bias || !out || !ws || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
-  if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 10 || (pool_out && ((H | W) & 1)))
+  if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 11 || (pool_out && ((H | W) & 1)))
     return DISN_E_SHAPE;
   if (tiling >= 5 && tiling <= 9 && !disn::conv_h2w_supported(H, W, Cin, Cout)) return DISN_E_SHAPE;
   if ((tiling == 6 || tiling == 8) && Cout % 128) return DISN_E_SHAPE;   // variants 2, 4: four n-waves = 128 channels per workgroup

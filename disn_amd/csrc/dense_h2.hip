@@ -253,7 +253,7 @@ hipError_t dense_h2_launch(const DenseH2Prob* probs, int nprob, hipStream_t st) 
   // Rows of >= kConvWideMinImages images (a batched call): the batched form of dense_h2w.hip (another K summation
   // order: fp32 rounding apart from the tiles below, not bit for bit; the rule looks at the call's image count and
   // the rows per image only, so an image's bits never depend on its companions)
-  if (p.amax_rows > 0 && p.amax_rows % 128 == 0 && p.M / p.amax_rows >= tune::conv_wide_min) {
+  if (!p.no_wide && p.amax_rows > 0 && p.amax_rows % 128 == 0 && p.M / p.amax_rows >= tune::conv_wide_min) {
     bool ok = true;
     for (int i = 0; i < nprob; ++i) ok = ok && dense_h2w_supported(d.p[i]) && d.p[i].amax_rows == p.amax_rows;
     if (ok) return dense_h2w_go(d, st);

@@ -358,6 +358,7 @@ struct DenseH2Prob {     // out[M][N] = act(f(A) . W + bias), A = [a (k1 columns
   int k_begin;           // first row of the packed matrix this product uses (a multiple of 16): W[k_begin .. k_begin + K)
   const float* add_in;   // [M][ldc] addend (a partial product formed earlier) or nullptr: out = act(A . W + bias + add_in); may alias out
   int in_amax_n;         // > 0: in_amax has this many entries instead of 64
+  int no_wide;           // 1: the four-k-wave tiles of dense_h2.hip whatever the number of images ("strict": the bits of a call of one image)
 };
 struct DenseH2Dev {
   DenseH2Prob p[2];

@@ -162,7 +162,8 @@ class SdfEngine:
     layer-by-layer GEMM chain (three-term bf16 products); same math, fp32-rounding-level difference."""
 
     def __init__(self, store: Optional[WeightStore], device: Optional[torch.device] = None, fused: bool = True,
-                 conv_h2: bool = True, weights: Optional[DeviceWeights] = None, equalise: bool = True):
+                 conv_h2: bool = True, weights: Optional[DeviceWeights] = None, equalise: bool = True,
+                 strict: bool = False):
         """``weights``: share the device weights of another engine (``store`` is then ignored): several engine
         contexts -- each with its own workspaces and auxiliary stream -- over one copy of the ~0.85 GB of device weights
         (fc6..fc8 as [K][N] 495 MB, fc7 / fc8 transposed 84 MB, the convolutions in three packed forms 206 MB, the
@@ -173,10 +174,18 @@ class SdfEngine:
             raise RuntimeError("disn_amd needs a HIP device: the product path has no CPU fallback")
         self.device = torch.device(device)
         self.fused = bool(fused)
+        self.strict = bool(strict)
         with torch.cuda.device(self.device):
             self.weights = weights if weights is not None else DeviceWeights(store, self.device, conv_h2=conv_h2,
                                                                              equalise=equalise)
             self._ctx = ops.ctx_create()      # aux HIP stream + events for the overlapped encoder
+        # ``strict``: disn_vgg_weights_t.conv_form = 1 -- the single-image convolution kernels (k-wave tree, chains of 108
+        # MFMAs per accumulator) for calls of ANY size instead of the batched form (chains of up to 432) from four images
+        # on: a request's taps in a batched call are bit for bit those of the request alone and its pred_sdf keeps the
+        # single-request form's distance from the float64 oracle; about 30 % of a batched call's throughput
+        # (include/disn_amd.h).  The struct is this engine's own copy: the packed weights stay shared.
+        self._vgg = VggWeights.from_buffer_copy(self.weights.vgg)
+        self._vgg.conv_form = 1 if self.strict else 0
         self._ws: Dict[str, torch.Tensor] = {}
 
     def __del__(self):
@@ -232,7 +241,7 @@ class SdfEngine:
         with torch.cuda.device(self.device):
             from ._lib import lib
             ws = self._workspace("vgg", lib().disn_encode_workspace_bytes(imgs.shape[0]))
-            resized, taps, emb, featmap = ops.encode(self._ctx, self.weights.vgg, imgs, ws)
+            resized, taps, emb, featmap = ops.encode(self._ctx, self._vgg, imgs, ws)
         return Encoded(resized, taps, emb, featmap)
 
     # rows A..H in one call: what ONE sess.run([pred_sdf]) of the reference executes
@@ -275,7 +284,7 @@ class SdfEngine:
         with torch.cuda.device(self.device):
             from ._lib import lib
             ws = self._workspace("encq", lib().disn_encode_query_workspace_bytes(pts.shape[0], pts.shape[1]))
-            resized, taps, emb, featmap, sdf = ops.encode_query(self._ctx, self.weights.vgg, self.weights.mlp,
+            resized, taps, emb, featmap, sdf = ops.encode_query(self._ctx, self._vgg, self.weights.mlp,
                                                                 imgs, trans_mat, pts, pts_rot, ws, keep_featmap)
         return Encoded(resized, taps, emb, featmap), sdf
 
@@ -355,7 +364,7 @@ class StepPipeline:
     for bit (the kernels and their launch order within a step are the same)."""
 
     def __init__(self, store: WeightStore, device: Optional[torch.device] = None, in_flight: int = 3,
-                 batch: int = 1):
+                 batch: int = 1, strict: bool = False):
         """``batch``: consecutive jobs of equal shape are submitted ``batch`` at a time as ONE disn_encode_query call
         (images and point sets concatenated): the 495 MB of fc weights are read once per call instead of once per
         image, and every launch has ``batch`` times the work against the same fixed cost.  Every image keeps its own
@@ -384,7 +393,7 @@ class StepPipeline:
                 h = ops.stream_create()
                 self._handles.append(h)
                 self.streams.append(torch.cuda.ExternalStream(h, device=self.device))
-                eng = SdfEngine(store if weights is None else None, self.device, weights=weights)
+                eng = SdfEngine(store if weights is None else None, self.device, weights=weights, strict=strict)
                 weights = eng.weights
                 self.engines.append(eng)
         # one host thread per context, alive for the pipeline's life (a thread started per run() costs ~0.5 ms

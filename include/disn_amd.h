@@ -79,7 +79,8 @@ int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w
  * output element depends on the number of k-waves only: tilings with the same number give the same bits), 5..9 =
  * force variant 1..5 of the BATCHED form (conv_h2w.hip: waves own 32-channel n-blocks of 128..224-pixel patches and
  * walk K sequentially; variants 1..3 one k-wave, 4..5 two; H*W >= 784), 10 = the whole-image tiling of layers of at
- * most 14 x 14 pixels (one workgroup per image and 32-channel block, four k-waves).
+ * most 14 x 14 pixels (one workgroup per image and 32-channel block, four k-waves), 11 = by shape, single-image form
+ * whatever B (what disn_vgg_weights_t.conv_form = 1 runs).
  * SELECTION RULE of tiling 0 (also inside disn_vgg16_* / disn_encode*): calls of B >= 4 images take the batched form
  * for layers of 28 x 28 pixels and more (one k-wave where H*W*Cout >= 56*56*256 -- conv1_2 .. conv3_3 --, else two -- by layer shape only) and
  * four k-waves for the 14 x 14 layers (the whole-image tiling where B * Cout / 32 >= 200, two-row patches below:
@@ -135,6 +136,16 @@ typedef struct disn_vgg_weights {
   /* optional (NULL = not used): fc6, fc7, fc8 TRANSPOSED, [N][K] row-major (one contiguous K-long row per output).
    * With it a layer is one launch (a wave per output row pair, no split-K partials, no reduce pass). */
   const float* fc_w_t[3];
+  /* 0 (default): the kernel forms are chosen by the call size (B < 4: conv_h2.hip / dense_h2.hip, B >= 4: conv_h2w.hip /
+   * the fused small-set point MLP -- see disn_conv3x3_h2, disn_encode_query).  1 ("strict"): the single-image forms for
+   * EVERY call size -- conv_h2.hip's and dense_h2.hip's four / eight k-wave trees sum K in chains of ~108 MFMAs per
+   * accumulator where the batched forms have up to 432 -- so the taps of a request in a call of any size are BIT FOR BIT
+   * those of the request alone and its pred_sdf equals the request-alone result up to the fc head's form (which still
+   * goes by B: <= 5e-7 of the embedding either way), i.e. it keeps the single-request form's distance from the float64
+   * oracle (tests/test_gpu_sweep.py: EVERY request of the trained-like sweep <= 1e-5 -- worst 8.0e-6, median 2.2e-6 --
+   * where the default's batched forms leave 2.7 % of the requests at 1.0-1.46e-5).  Costs ~37 % of a batched call's
+   * throughput (bench.py --strict: 10.7 M against 17 M points/s).  N >= 8192 per request keeps the fused kernels (per-point scales) either way. */
+  int conv_form;
 } disn_vgg_weights_t;
 
 size_t disn_vgg16_workspace_bytes(int B);
