@@ -686,27 +686,30 @@ int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* re
 // row C: fc6 (7x7 VALID == dense over the NHWC-flattened pool5), fc7, fc8
 // (models/CNN/vgg.py:198-214; dropout inactive: is_training=False, model_normalization.py:76)
 int fc_layer(const float* x, int B, int K, const float* w_kn, const float* wt_nk, const float* bias, int N, int relu,
-             float* out, float* ws, hipStream_t st) {
+             float* out, float* ws, hipStream_t st, bool single_form = false) {
   // the one-launch row form re-reads x (B x K floats) once per wave: right for one to three rows (launch-latency bound
   // layers), 4x the weight bytes in L2 traffic at eight -- a batched call takes the split-K stream kernel for every layer
-  if (wt_nk && B < tune::conv_wide_min) DISN_TRY(gemv_rows_launch(x, B, K, wt_nk, bias, N, relu, out, st));   // (one threshold for every form switch: ADVICE r3)
-  else DISN_TRY(gemv_launch(x, B, K, w_kn, bias, N, relu, out, ws, st));
+  // single_form ("strict"): the forms of a call of one row for any B -- a row's sum is the same instruction sequence
+  if (wt_nk && (B < tune::conv_wide_min || single_form)) DISN_TRY(gemv_rows_launch(x, B, K, wt_nk, bias, N, relu, out, st));   // (one threshold for every form switch: ADVICE r3)
+  else DISN_TRY(gemv_launch(x, B, K, w_kn, bias, N, relu, out, ws, st, single_form));
   return 0;
 }
 
 int vgg_head(const disn_vgg_weights_t* w, const float* pool5, int B, float* embedding,
              const VggWs& s, hipStream_t st) {
   int rc;
+  const bool sf = w->conv_form == 1;   // "strict": every row as in a call of one image
   // fc6 (411 MB) stays on the split-K stream kernel: 6.2 TB/s there against 2.8 for the row form (r02i); the
   // 67 / 17 / 2 MB layers are launch-latency bound and take the one-launch row form
-  if ((rc = fc_layer(pool5, B, 25088, w->fc_w[0], nullptr, w->fc_b[0], 4096, 1, s.fc6, s.fc_ws, st))) return rc;
-  if ((rc = fc_layer(s.fc6, B, 4096, w->fc_w[1], w->fc_w_t[1], w->fc_b[1], 4096, 1, s.fc7, s.fc_ws, st))) return rc;
-  return fc_layer(s.fc7, B, 4096, w->fc_w[2], w->fc_w_t[2], w->fc_b[2], w->num_classes, 0, embedding, s.fc_ws, st);
+  if ((rc = fc_layer(pool5, B, 25088, w->fc_w[0], nullptr, w->fc_b[0], 4096, 1, s.fc6, s.fc_ws, st, sf))) return rc;
+  if ((rc = fc_layer(s.fc6, B, 4096, w->fc_w[1], w->fc_w_t[1], w->fc_b[1], 4096, 1, s.fc7, s.fc_ws, st, sf))) return rc;
+  return fc_layer(s.fc7, B, 4096, w->fc_w[2], w->fc_w_t[2], w->fc_b[2], w->num_classes, 0, embedding, s.fc_ws, st, sf);
 }
 
 // the per-image folded bias of the global fold2/conv1: gbias[b] = embedding[b] . W4_global + b4
-int gbias_layer(const disn_mlp_weights_t* w, const float* embedding, int B, float* gbias, float* ws, hipStream_t st) {
-  return fc_layer(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_w4_global_t, w->g_b4, 512, 0, gbias, ws, st);
+int gbias_layer(const disn_mlp_weights_t* w, const float* embedding, int B, float* gbias, float* ws, hipStream_t st,
+                bool single_form = false) {
+  return fc_layer(embedding, B, DISN_EMBED_DIM, w->g_w4_global, w->g_w4_global_t, w->g_b4, 512, 0, gbias, ws, st, single_form);
 }
 
 // Point sets of a fused-small call are padded to a multiple of 128 points per image INSIDE the library (round 5; pad
@@ -1008,7 +1011,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
-  { const int grc = gbias_layer(mw, embedding, B, e.q.gbias, e.q.gemv_ws, st); if (grc) return grc; }
+  { const int grc = gbias_layer(mw, embedding, B, e.q.gbias, e.q.gemv_ws, st, strict); if (grc) return grc; }
   if (h2) {  // global fold2/conv2 on relu(pre + bias) per image, then -- behind ev[6] -- both fold2/conv5 and the sum
     for (int b = 0; b < B; b += hb) {
       const size_t o = (size_t)b * N;

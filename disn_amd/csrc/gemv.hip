@@ -252,14 +252,17 @@ int gemv_splits(int K, int N, int B) {
 }
 
 size_t gemv_ws_bytes(int B, int K, int N) {
-  return (size_t)gemv_splits(K, N, B) * B * N * sizeof(float);
+  // (the single-row split count: what gemv_launch(single_form) uses for any B -- twice the batched form's)
+  return (size_t)gemv_splits(K, N, 1) * B * N * sizeof(float);
 }
 
+// single_form ("strict", disn_vgg_weights_t.conv_form = 1): the split count, the VALU kernels and the reduce lanes of a
+// call of ONE row for any B (eight rows per pass over the matrix) -- every row bit for bit what it gets alone
 hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const float* bias, int N,
-                       int relu, float* out, float* ws, hipStream_t st) {
-  const int S = gemv_splits(K, N, B);
+                       int relu, float* out, float* ws, hipStream_t st, bool single_form) {
+  const int S = gemv_splits(K, N, single_form ? 1 : B);
   dim3 grid(N / 256, S);
-  if (B >= tune::conv_wide_min && K % 4 == 0) {   // a batched call: sixteen rows per pass on the matrix pipe
+  if (!single_form && B >= tune::conv_wide_min && K % 4 == 0) {   // a batched call: sixteen rows per pass on the matrix pipe
     for (int b0 = 0; b0 < B; b0 += 16) {
       hipLaunchKernelGGL(gemv_mfma_kernel, grid, dim3(256), 0, st, x, K, w_kn, N, ws, B, b0);
       const hipError_t e = hipGetLastError();
@@ -284,7 +287,10 @@ hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const fl
     if (e != hipSuccess) return e;
     b0 += nb;
   }
-  return splitk_reduce_launch(ws, S, B, N, bias, 0, relu, out, N, st);
+  // (single_form: the lane count the reduce picks for ONE row, whatever B)
+  const size_t total1 = (size_t)(N / 4);
+  const int sl1 = (total1 >= 131072 || S < 4) ? 1 : ((total1 >= 16384 || S < 16) ? 4 : 16);
+  return splitk_reduce_launch(ws, S, B, N, bias, 0, relu, out, N, st, single_form ? sl1 : 0);
 }
 
 }  // namespace disn

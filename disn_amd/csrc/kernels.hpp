@@ -103,7 +103,7 @@ int gemv_splits(int K, int N, int B = 1);
 size_t gemv_ws_bytes(int B, int K, int N);
 // out[b][n] = act(sum_k x[b][k] W[k][n] + bias[n]); N % 256 == 0
 hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const float* bias, int N,
-                       int relu, float* out, float* ws, hipStream_t st);
+                       int relu, float* out, float* ws, hipStream_t st, bool single_form = false);
 // the same from the transposed matrix wt_nk [N][K]: one launch, no split-K partials (K % 4 == 0)
 hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, const float* bias, int N, int relu,
                             float* out, hipStream_t st);

@@ -548,11 +548,10 @@ def test_chained_batched_pipeline_on_separately_allocated_jobs():
 @pytest.mark.parametrize("B,N", [(5, 256), (4, 1000), (16, 2048)])
 def test_strict_mode_runs_the_single_image_forms(B, N):
     """disn_vgg_weights_t.conv_form = 1 (SdfEngine(strict=True), include/disn_amd.h): a call of >= 4 requests through the
-    single-image forms of the convolutions (conv_h2.hip) and of the point-MLP layers (dense_h2.hip's four-k-wave tiles).
-    (1) every request's taps are bit for bit those of the request alone; (2) its pred_sdf equals the request-alone result up to
-    the fc head's form (matrix pipe from four rows on: <= 5e-7 of the embedding); (3) the flag changes something: the
-    default engine's batched forms give other bits; (4) within 1e-5 of the float64 oracle.  N = 1000 is not a multiple of 64:
-    the layers then run image by image."""
+    single-image forms of the convolutions (conv_h2.hip), the fc head (one-row split count / row kernels) and the point-MLP
+    layers (dense_h2.hip's four-k-wave tiles).  (1) every request's taps, embedding AND pred_sdf are BIT FOR BIT those of the
+    request alone; (2) the flag changes something: the default engine's batched forms give other bits; (3) within 1e-5 of
+    the float64 oracle.  N = 1000 is not a multiple of 64: the layers then run image by image."""
     from disn_amd.engine import SdfEngine
     from disn_amd.weights import WeightStore
     store = WeightStore.random_init(6, mode="he")
@@ -569,10 +568,11 @@ def test_strict_mode_runs_the_single_image_forms(B, N):
         enc1, pred1 = fast.encode_query(*jobs[b])
         for k in range(5):
             assert torch.equal(enc_s.taps[k][b], enc1.taps[k][0]), "tap %d of request %d" % (k, b)
+        assert torch.equal(enc_s.embedding[b], enc1.embedding[0]), "embedding of request %d" % b
         worst = max(worst, float((pred_s[b] - pred1[0]).abs().max()))
     print("strict call of %d x %d: max |pred - request alone| %.3g; |strict - default| %.3g" % (
         B, N, worst, float((pred_s - pred_f).abs().max())))
-    assert worst <= 2.5e-6
+    assert worst == 0.0, "strict call: pred_sdf differs from the request alone by %g" % worst
     d = {"imgs": jobs[0][0].cpu().numpy(), "sample_pc": jobs[0][1].cpu().numpy(), "sample_pc_rot": jobs[0][1].cpu().numpy(),
          "trans_mat": jobs[0][2].cpu().numpy()}
     ref = O.get_model(d, store.arrays, dtype=np.float64)["pred_sdf"][0, :, 0]

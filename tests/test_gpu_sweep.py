@@ -81,15 +81,13 @@ def _forms(eng, s, dev, strict_eng=None):
         enc16, p16 = strict_eng.encode_query(dev(imgs16), dev(pts16), dev(tms16))
         p16 = p16.cpu().numpy()
         out["strict16"] = [(i % 8, i // 8, p16[i]) for i in range(16)]
-        # strict = the single-image convolution kernels for every call: image 4's taps in the 16-request call are bit for
-        # bit those of the request alone; its embedding differs by the fc head's form only (matrix-pipe split-K from four
-        # rows on, row kernels below: both <= 5e-7 of the embedding from the float64 head, tools/sweep_diag2.py)
+        # strict = the single-image forms of every kernel for every call size: image 4's taps, embedding and pred_sdf in the
+        # 16-request call are bit for bit those of the request alone
         one = eng.encode(dev(s["imgs"][4:5]))
         assert all(torch.equal(a[4], b[0]) for a, b in zip(enc16.taps, one.taps)), "strict call: taps differ from the request alone"
-        assert float((enc16.embedding[4] - one.embedding[0]).abs().max()) <= 2e-6 * float(one.embedding.abs().max())
-        # ... and its pred_sdf is the single-request one up to that (the point-MLP layers run their single-image form too)
+        assert torch.equal(enc16.embedding[4], one.embedding[0]), "strict call: embedding differs from the request alone"
         alone = [p for b, j, p in out["single"] if b == 4][0]
-        assert float(np.abs(p16[4] - alone).max()) <= 2.5e-6, float(np.abs(p16[4] - alone).max())   # (measured <= 1.2e-6)
+        assert np.array_equal(p16[4], alone), float(np.abs(p16[4] - alone).max())
     enc = eng.encode(dev(s["imgs"][:1]))
     grid = eng.query_grid(enc, 0, dev(s["trans_mat"][:1]), MS.GRID_PARAMS, MS.GRID_RES, sdf_weight=1.0).cpu().numpy()
     return out, grid

@@ -23,7 +23,7 @@ fi
 if has bench; then
   timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err; echo "bench (driver's command) exit $?"; tail -2 $OUT/bench_driver_cmd.err
   timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; tail -3 $OUT/bench.err
-  for v in "--batch 1 --in-flight 1" "--batch 1 --in-flight 3" "--batch 2 --in-flight 2" "--batch 4 --in-flight 1" "--batch 4 --in-flight 2" "--batch 8 --in-flight 1" "--batch 8 --in-flight 2" "--batch 16 --in-flight 1" "--steps 20 --warmup 5"; do
+  for v in "--batch 1 --in-flight 1" "--batch 1 --in-flight 3" "--batch 2 --in-flight 2" "--batch 4 --in-flight 1" "--batch 4 --in-flight 2" "--batch 8 --in-flight 1" "--batch 8 --in-flight 2" "--batch 16 --in-flight 1" "--steps 20 --warmup 5" "--strict" "--strict --steps 20 --warmup 5"; do
     echo "variant $v" | tee -a $OUT/bench_variants.txt
     timeout 120 python bench.py $(case "$v" in *--steps*) ;; *) echo --steps 240 --warmup 24;; esac) $v --no-extras 2>/dev/null | tail -1 | cut -c1-260 | tee -a $OUT/bench_variants.txt
   done
