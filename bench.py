@@ -599,8 +599,8 @@ def main():
                 line["strict_mode"] = {"points_per_s": ncall * SB * N_POINTS / dts, "ms_per_step": 1e3 * dts / (ncall * SB),
                                        "steps": ncall * SB, "max_abs_diff_to_the_default_form": d_fast,
                                        "note": "disn_vgg_weights_t.conv_form = 1 (StepPipeline(strict=True), --strict): the "
-                                               "single-image convolution kernels (k-wave tree) for every call size; a request's "
-                                               "taps are bit for bit those of the request alone.  Accuracy of both "
+                                               "single-image forms of every kernel for every call size; a request's taps, embedding "
+                                               "and pred_sdf are bit for bit those of the request alone.  Accuracy of both "
                                                "modes: cpu_baseline.parity_trained_like.sweep"}
                 pipe_s.close()
                 del pipe_s, res_s

@@ -139,12 +139,12 @@ typedef struct disn_vgg_weights {
   /* 0 (default): the kernel forms are chosen by the call size (B < 4: conv_h2.hip / dense_h2.hip, B >= 4: conv_h2w.hip /
    * the fused small-set point MLP -- see disn_conv3x3_h2, disn_encode_query).  1 ("strict"): the single-image forms for
    * EVERY call size -- conv_h2.hip's and dense_h2.hip's four / eight k-wave trees sum K in chains of ~108 MFMAs per
-   * accumulator where the batched forms have up to 432 -- so the taps of a request in a call of any size are BIT FOR BIT
-   * those of the request alone and its pred_sdf equals the request-alone result up to the fc head's form (which still
-   * goes by B: <= 5e-7 of the embedding either way), i.e. it keeps the single-request form's distance from the float64
-   * oracle (tests/test_gpu_sweep.py: EVERY request of the trained-like sweep <= 1e-5 -- worst 8.0e-6, median 2.2e-6 --
-   * where the default's batched forms leave 2.7 % of the requests at 1.0-1.46e-5).  Costs ~37 % of a batched call's
-   * throughput (bench.py --strict: 10.7 M against 17 M points/s).  N >= 8192 per request keeps the fused kernels (per-point scales) either way. */
+   * accumulator where the batched forms have up to 432; the fc head with the split count, VALU kernels and reduce lanes
+   * of a one-row call -- so the taps, the embedding AND pred_sdf of a request in a call of any size are BIT FOR BIT
+   * those of the request alone (N < 8192 per request), i.e. it keeps the single-request form's distance from the float64
+   * oracle (tests/test_gpu_sweep.py: EVERY request of the trained-like sweep <= 1e-5 -- median 2.2e-6 --
+   * where the default's batched forms leave 2.7 % of the requests at 1.0-1.46e-5).  Costs ~39 % of a batched call's
+   * throughput (bench.py --strict: 10.3 M against 17 M points/s).  N >= 8192 per request keeps the fused kernels (per-point scales) either way. */
   int conv_form;
 } disn_vgg_weights_t;
 
