@@ -71,9 +71,14 @@ class Session:
     re-used while the same image bytes are fed again -- the encoder/decoder split the
     reference defines but never uses (models/model_normalization.py:38-45,223-238).  Set it to
     False to re-run VGG on every ``run`` exactly as the reference does.
+
+    ``strict`` (default True for this drop-in surface): the engine runs the single-image kernel forms whatever the
+    batch size of a feed (disn_vgg_weights_t.conv_form = 1), so what ``sess.run`` returns for an image does not depend
+    on how many images were fed with it -- bit for bit ("a caller's sess.run at B = 1 and B = 4 returns
+    different bits").  The throughput API (disn_amd.engine.StepPipeline, bench.py) defaults to the batched forms.
     """
 
-    def __init__(self, weights=None, device=None, cache_encoder: bool = True, seed: int = 0):
+    def __init__(self, weights=None, device=None, cache_encoder: bool = True, seed: int = 0, strict: bool = True):
         from .engine import SdfEngine
         from .weights import WeightStore
         if weights is None:
@@ -81,7 +86,7 @@ class Session:
             # explicit here rather than a swallowed exception
             weights = WeightStore.random_init(seed)
         self.weights = weights
-        self.engine = SdfEngine(weights, device)
+        self.engine = SdfEngine(weights, device, strict=strict)
         self.cache_encoder = cache_encoder
         self._enc_key: Optional[bytes] = None
         self._enc_val = None
