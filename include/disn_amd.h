@@ -407,6 +407,9 @@ int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, 
  *               disn_sdf_mlp switch at the same N = 8192 per image.
  *   convolutions / fc head  B < 4: conv_h2.hip + one-launch fc rows; B >= 4: conv_h2w.hip + the split-K fc stream
  *               with up to sixteen batch rows per pass on the fp32 matrix pipe (gemv_mfma_kernel; disn_conv3x3_h2's rule).
+ *   strict mode  vw->conv_form == 1 (zero-initialise disn_vgg_weights_t: 0 is the default): the B < 4 forms of ALL of the
+ *               above for any B (N < 8192 per request) -- request b's taps, embedding and sdf are then bit for bit those
+ *               of a B = 1 call (tests/test_gpu_model.py::test_strict_mode_runs_the_single_image_forms); see the struct.
  * Every activation scale is per image (per point inside the fused kernels) on all of these paths, so request b's
  * outputs never depend on the other requests of its call, on its position, or on B beyond the thresholds above (B < 4:
  * bit for bit those of a B = 1 call; B >= 4: bit for bit those of any other call of >= 4 requests of the same N). */
