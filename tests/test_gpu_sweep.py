@@ -31,7 +31,7 @@ from oracle import disn_oracle as O
 
 pytestmark = pytest.mark.gpu
 BAR = 1e-5
-# What is asserted -- the measured distribution (profiles/r05e_sweep_full.json: 48 sets, 1104 requests):
+# What is asserted -- the measured distribution (profiles/r05k_sweep_full.json: 48 sets, 1104 default-mode + 960 strict-mode requests):
 #   * one request per call (conv_h2 / dense_h2) and the dense grid: EVERY case <= 1e-5 (measured <= 6.2e-6 / 8.4e-6);
 #   * the batched kernel forms (calls of 4 and of 16 requests): 90 % of the cases <= 1e-5 (measured p90 7.5e-6, median
 #     3.8e-6), at most 5 % above it (measured 26 of 960 = 2.7 %) and every case <= 1.5e-5 (measured 1.46e-5).  The cases
