@@ -1,9 +1,31 @@
-"""error of the encoder's stages by form on sweep set 4 (needs tools/_diag_set04.npz: float64 intermediates on the
-equalised variables, /tmp/gen_diag.py): taps (batched | single conv kernels) and the fc head (matrix-pipe | VALU split-K)"""
+"""error of the encoder's stages by form on sweep set 4: taps (batched | single conv kernels) and the fc head
+(matrix-pipe | VALU split-K) against float64 intermediates computed on the EQUALISED variables.
+
+    python tools/sweep_diag2.py make     CPU, ~1 minute: writes tools/_diag_set04.npz (21 MB, git-ignored; it travels to
+                                         the GPU box with the snapshot)
+    python tools/sweep_diag2.py          GPU: the comparison (profiles/r05d_sweep_diag2.txt)
+"""
 import os
 import sys
 
 import numpy as np
+
+ROOT0 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "make":
+    sys.path.insert(0, ROOT0)
+    sys.path.insert(0, os.path.join(ROOT0, "tests", "golden"))
+    import make_golden_sweep as MS0
+    from disn_amd.weights import WeightStore as WS0
+    from oracle import disn_oracle as O0
+    seed0, sigma0, outlier0 = MS0.SETS[4]
+    Weq = WS0(O0.trained_like_weights(seed0, sigma=sigma0, outlier_gain=outlier0)).equalised()[0].arrays
+    _, emb0, _, eps0 = O0.encode(MS0.sweep_inputs()["imgs"], Weq, np.float64)
+    taps0 = {nm: np.asarray(eps0["vgg_16/%s/%s" % (nm[:5], nm)], np.float64) for nm in O0.TAP_NAMES}
+    np.savez_compressed(os.path.join(ROOT0, "tools", "_diag_set04.npz"), emb64=np.asarray(emb0, np.float64),
+                        pool5_64=O0.max_pool_2x2(taps0["conv5_3"]), **{"tap64_" + k: v[:, ::3, ::3, :] for k, v in taps0.items()})
+    print("wrote tools/_diag_set04.npz")
+    sys.exit(0)
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
