@@ -365,7 +365,7 @@ def main():
     ap.add_argument("--dist-backend", choices=("auto", "nccl", "gloo"), default="auto",
                     help="auto: nccl (= RCCL); gloo when ranks must share a GPU (RCCL rejects duplicate devices)")
     ap.add_argument("--strict", action="store_true",
-                    help="--workload query: disn_vgg_weights_t.conv_form = 1 -- the single-image convolution kernels for calls "
+                    help="--workload query: disn_vgg_weights_t.strict_forms = 1 -- the single-image convolution kernels for calls "
                          "of any size (a request's taps are bit for bit those of the request alone; every request "
                          "of the trained-like sweep within 1e-5 of the float64 oracle) at about a third less throughput")
     ap.add_argument("--dry-run", action="store_true",
@@ -582,7 +582,7 @@ def main():
         except Exception as e:   # a failing extra must not cost the contract line
             line.setdefault("extras_failed", {})['one step at a time'] = repr(e)
             print("[bench] extra failed: %s: %r" % ('one step at a time', e), file=sys.stderr)
-        # ---- strict mode (conv_form = 1): the same submission through the single-image convolution kernels -------
+        # ---- strict mode (strict_forms = 1): the same submission through the single-image convolution kernels -------
         try:
             if not args.strict and SB >= 4:
                 pipe_s = StepPipeline(store, dev, in_flight=S, batch=SB, strict=True)
@@ -598,7 +598,7 @@ def main():
                 d_fast = float((res_s[0] - torch.cat(outs[:SB])).abs().max()) if len(outs) >= SB else None
                 line["strict_mode"] = {"points_per_s": ncall * SB * N_POINTS / dts, "ms_per_step": 1e3 * dts / (ncall * SB),
                                        "steps": ncall * SB, "max_abs_diff_to_the_default_form": d_fast,
-                                       "note": "disn_vgg_weights_t.conv_form = 1 (StepPipeline(strict=True), --strict): the "
+                                       "note": "disn_vgg_weights_t.strict_forms = 1 (StepPipeline(strict=True), --strict): the "
                                                "single-image forms of every kernel for every call size; a request's taps, embedding "
                                                "and pred_sdf are bit for bit those of the request alone.  Accuracy of both "
                                                "modes: cpu_baseline.parity_trained_like.sweep"}

@@ -37,7 +37,7 @@ class VggWeights(C.Structure):  # disn_vgg_weights_t
                 ("conv_w_x3", C.c_void_p * 13),   # optional three-term bf16 images (disn_pack_kn_x3)
                 ("conv_w_h2", C.c_void_p * 13),   # optional two-term f16 images (disn_pack_conv_h2)
                 ("fc_w_t", C.c_void_p * 3),       # optional transposed fc matrices [N][K]
-                ("conv_form", C.c_int)]           # 1: single-image convolution kernels for every call size ("strict")
+                ("strict_forms", C.c_int)]           # 1: single-image convolution kernels for every call size ("strict")
 
 
 MLP_FIELDS = ("g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3", "g_w4_point", "g_w4_global", "g_b4",

@@ -206,7 +206,7 @@ constexpr int kFeatMaxSlot = 576;  // floats 576 .. 1023 of a set: up to 448 per
 
 DenseH2Prob h2_batched(DenseH2Prob p, int imgs, int n, bool no_wide = false) {
   if (imgs > 1) { p.M = imgs * n; p.amax_rows = n; p.amax_stride = 1024; }
-  p.no_wide = no_wide ? 1 : 0;   // "strict" (disn_vgg_weights_t.conv_form = 1): never the batched form of dense_h2w.hip
+  p.no_wide = no_wide ? 1 : 0;   // "strict" (disn_vgg_weights_t.strict_forms = 1): never the batched form of dense_h2w.hip
   return p;
 }
 
@@ -662,7 +662,7 @@ int vgg_features(const disn_vgg_weights_t* w, const float* img, int B, float* re
     } else if (h2) {
       DISN_TRY(conv_h2_launch(x, B, L.hw, L.hw, L.cin, w->conv_w_h2[i], w->conv_b[i], L.cout, 1,
                               s.amax + (size_t)B * 64 * i, out, kPoolAfter[i] ? s.bufP : nullptr,
-                              s.amax + (size_t)B * 64 * (i + 1), st, w->conv_form == 1 ? 11 : 0, 64));
+                              s.amax + (size_t)B * 64 * (i + 1), st, w->strict_forms == 1 ? 11 : 0, 64));
       pooled = kPoolAfter[i];
     } else {
       rc = conv3x3_impl(x, B, L.hw, L.hw, L.cin, w->conv_w[i], w->conv_b[i], L.cout, 1, out, s.gemm_ws, gws_cap, st,
@@ -698,7 +698,7 @@ int fc_layer(const float* x, int B, int K, const float* w_kn, const float* wt_nk
 int vgg_head(const disn_vgg_weights_t* w, const float* pool5, int B, float* embedding,
              const VggWs& s, hipStream_t st) {
   int rc;
-  const bool sf = w->conv_form == 1;   // "strict": every row as in a call of one image
+  const bool sf = w->strict_forms == 1;   // "strict": every row as in a call of one image
   // fc6 (411 MB) stays on the split-K stream kernel: 6.2 TB/s there against 2.8 for the row form (r02i); the
   // 67 / 17 / 2 MB layers are launch-latency bound and take the one-launch row form
   if ((rc = fc_layer(pool5, B, 25088, w->fc_w[0], nullptr, w->fc_b[0], 4096, 1, s.fc6, s.fc_ws, st, sf))) return rc;
@@ -913,10 +913,10 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
   // are a B = 1 call's; from 8192 points on it takes the fused kernels too: 2.13 -> 1.40 ms for one request of 65536 points
   // against the three-term GEMM chain this shape ran until round 4, tools/encode_query_forms_time.py)
   const int Np = pad128(N);
-  // "strict" (disn_vgg_weights_t.conv_form = 1) in a call of >= 4 requests: the single-image forms of the convolutions
+  // "strict" (disn_vgg_weights_t.strict_forms = 1) in a call of >= 4 requests: the single-image forms of the convolutions
   // (vgg_features) AND of the point-MLP layers (dense_h2.hip's four-k-wave tiles, per-image scales) -- the request's taps
   // and, up to the fc head's form, its pred_sdf are those of the request alone
-  const bool strict = vw->conv_form == 1 && B >= tune::conv_wide_min && mlp_h2(mw, N);
+  const bool strict = vw->strict_forms == 1 && B >= tune::conv_wide_min && mlp_h2(mw, N);
   if (!strict && two && conv_h2_all && !featmap && (B >= tune::conv_wide_min || N >= 8192) && fused_small_ok(mw, B, Np)) {
     float* sdf_out = sdf;
     if (Np != N) {   // pad the point sets (both streams run behind the fork / the convolutions anyway)

@@ -764,7 +764,7 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
   // fragment reads for conv5_x of 16 images: L2-bound, 32 % MFMA busy, 65 us), the whole image 21 (52 us).  Smaller
   // calls keep the two-row patches (measured equal to the eight-k-wave tiling at 4 / 8 / 12 images: r03ad).
   if (cfg == 10) return conv_h2_go<7, 1, 16, 14, 3, 4>(d, st);
-  // cfg 11 ("strict", disn_vgg_weights_t.conv_form = 1): the single-image tilings below by shape, whatever B -- the same
+  // cfg 11 ("strict", disn_vgg_weights_t.strict_forms = 1): the single-image tilings below by shape, whatever B -- the same
   // k-waves and summation tree as a call of one image: the same bits
   const bool strict = cfg == 11;
   if (strict) cfg = 0;

@@ -256,7 +256,7 @@ size_t gemv_ws_bytes(int B, int K, int N) {
   return (size_t)gemv_splits(K, N, 1) * B * N * sizeof(float);
 }
 
-// single_form ("strict", disn_vgg_weights_t.conv_form = 1): the split count, the VALU kernels and the reduce lanes of a
+// single_form ("strict", disn_vgg_weights_t.strict_forms = 1): the split count, the VALU kernels and the reduce lanes of a
 // call of ONE row for any B (eight rows per pass over the matrix) -- every row bit for bit what it gets alone
 hipError_t gemv_launch(const float* x, int B, int K, const float* w_kn, const float* bias, int N,
                        int relu, float* out, float* ws, hipStream_t st, bool single_form) {

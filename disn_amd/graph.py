@@ -73,7 +73,7 @@ class Session:
     False to re-run VGG on every ``run`` exactly as the reference does.
 
     ``strict`` (default True for this drop-in surface): the engine runs the single-image kernel forms whatever the
-    batch size of a feed (disn_vgg_weights_t.conv_form = 1), so what ``sess.run`` returns for an image does not depend
+    batch size of a feed (disn_vgg_weights_t.strict_forms = 1), so what ``sess.run`` returns for an image does not depend
     on how many images were fed with it -- bit for bit ("a caller's sess.run at B = 1 and B = 4 returns
     different bits").  The throughput API (disn_amd.engine.StepPipeline, bench.py) defaults to the batched forms.
     """

@@ -80,7 +80,7 @@ int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w
  * force variant 1..5 of the BATCHED form (conv_h2w.hip: waves own 32-channel n-blocks of 128..224-pixel patches and
  * walk K sequentially; variants 1..3 one k-wave, 4..5 two; H*W >= 784), 10 = the whole-image tiling of layers of at
  * most 14 x 14 pixels (one workgroup per image and 32-channel block, four k-waves), 11 = by shape, single-image form
- * whatever B (what disn_vgg_weights_t.conv_form = 1 runs).
+ * whatever B (what disn_vgg_weights_t.strict_forms = 1 runs).
  * SELECTION RULE of tiling 0 (also inside disn_vgg16_* / disn_encode*): calls of B >= 4 images take the batched form
  * for layers of 28 x 28 pixels and more (one k-wave where H*W*Cout >= 56*56*256 -- conv1_2 .. conv3_3 --, else two -- by layer shape only) and
  * four k-waves for the 14 x 14 layers (the whole-image tiling where B * Cout / 32 >= 200, two-row patches below:
@@ -145,7 +145,7 @@ typedef struct disn_vgg_weights {
    * oracle (tests/test_gpu_sweep.py: EVERY request of the trained-like sweep <= 1e-5 -- median 2.2e-6 --
    * where the default's batched forms leave 2.7 % of the requests at 1.0-1.46e-5).  Costs ~39 % of a batched call's
    * throughput (bench.py --strict: 10.3 M against 17 M points/s).  N >= 8192 per request keeps the fused kernels (per-point scales) either way. */
-  int conv_form;
+  int strict_forms;
 } disn_vgg_weights_t;
 
 size_t disn_vgg16_workspace_bytes(int B);
@@ -407,7 +407,7 @@ int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, 
  *               disn_sdf_mlp switch at the same N = 8192 per image.
  *   convolutions / fc head  B < 4: conv_h2.hip + one-launch fc rows; B >= 4: conv_h2w.hip + the split-K fc stream
  *               with up to sixteen batch rows per pass on the fp32 matrix pipe (gemv_mfma_kernel; disn_conv3x3_h2's rule).
- *   strict mode  vw->conv_form == 1 (zero-initialise disn_vgg_weights_t: 0 is the default): the B < 4 forms of ALL of the
+ *   strict mode  vw->strict_forms == 1 (zero-initialise disn_vgg_weights_t: 0 is the default): the B < 4 forms of ALL of the
  *               above for any B (N < 8192 per request) -- request b's taps, embedding and sdf are then bit for bit those
  *               of a B = 1 call (tests/test_gpu_model.py::test_strict_mode_runs_the_single_image_forms); see the struct.
  * Every activation scale is per image (per point inside the fused kernels) on all of these paths, so request b's

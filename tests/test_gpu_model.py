@@ -547,7 +547,7 @@ def test_chained_batched_pipeline_on_separately_allocated_jobs():
 
 @pytest.mark.parametrize("B,N", [(5, 256), (4, 1000), (16, 2048)])
 def test_strict_mode_runs_the_single_image_forms(B, N):
-    """disn_vgg_weights_t.conv_form = 1 (SdfEngine(strict=True), include/disn_amd.h): a call of >= 4 requests through the
+    """disn_vgg_weights_t.strict_forms = 1 (SdfEngine(strict=True), include/disn_amd.h): a call of >= 4 requests through the
     single-image forms of the convolutions (conv_h2.hip), the fc head (one-row split count / row kernels) and the point-MLP
     layers (dense_h2.hip's four-k-wave tiles).  (1) every request's taps, embedding AND pred_sdf are BIT FOR BIT those of the
     request alone; (2) the flag changes something: the default engine's batched forms give other bits; (3) within 1e-5 of

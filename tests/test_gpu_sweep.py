@@ -10,7 +10,7 @@ to a common binade by an exact power of two; `test_sweep_without_equalisation_fa
 kernels on the raw variables miss the bar on the hardest set, i.e. the sweep does exercise what it claims to.
 
 Two modes are run on every weight set: the DEFAULT (kernel forms by call size: calls of >= 4 requests take the batched
-convolutions and the fused small-set MLP -- 17 M points/s) and STRICT (disn_vgg_weights_t.conv_form = 1, SdfEngine(strict=True):
+convolutions and the fused small-set MLP -- 17 M points/s) and STRICT (disn_vgg_weights_t.strict_forms = 1, SdfEngine(strict=True):
 the single-image forms for every call size -- 10.7 M points/s; a request's taps bit for bit, its pred_sdf up to the fc head's
 form, those of the request alone).  Strict: every request <= 1e-5.  Default: see the comment at BAR_BATCHED_WORST.
 
@@ -61,7 +61,7 @@ def _chosen():
 
 
 def _forms(eng, s, dev, strict_eng=None):
-    """-> {form: [(image, point set, pred numpy [256])]} + the grid.  strict_eng (same weights, conv_form = 1): the same
+    """-> {form: [(image, point set, pred numpy [256])]} + the grid.  strict_eng (same weights, strict_forms = 1): the same
     calls of 4 and 16 requests through the single-image convolution kernels -> 'strict4' / 'strict16'"""
     out = {"single": [], "batch4": [], "batch16": []}
     for b in (0, 4):
@@ -146,7 +146,7 @@ def test_sweep_within_the_bar_on_every_form():
     print("[parity sweep] distribution of max |gpu - f64| per (weight set, request): " + json.dumps(summary))
     bf = summary["by_form"]
     assert max(bf[f]["max"] for f in ("single", "grid")) <= BAR, json.dumps(bf)
-    # strict mode (disn_vgg_weights_t.conv_form = 1: single-image convolution kernels in calls of any size): EVERY request
+    # strict mode (disn_vgg_weights_t.strict_forms = 1: single-image convolution kernels in calls of any size): EVERY request
     strict_worst = max(bf["strict4"]["max"], bf["strict16"]["max"])
     summary["strict_worst"], summary["strict_headroom"] = strict_worst, 1.0 - strict_worst / BAR
     print("[parity sweep] strict mode: worst %.3g over %d requests (headroom %.0f %%)" % (
