@@ -940,7 +940,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
     if (ctx->pipe_record) DISN_TRY(hipEventRecord(ctx->pipe_record, st));
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
-    { const int grc = gbias_layer(mw, embedding, B, e.q.gbias, e.q.gemv_ws, st); if (grc) return grc; }
+    { const int grc = gbias_layer(mw, embedding, B, e.q.gbias, e.q.gemv_ws, st, vw->strict_forms == 1); if (grc) return grc; }
     DISN_TRY(hipStreamWaitEvent(st, ctx->ev[6], 0));
     if ((rc = fused_small_global(mw, e.q.gbias, pts_rot, B, N, e.q.mlp.l5, sdf, 1.0f, st))) return rc;
     if (sdf != sdf_out) DISN_TRY(restride_rows_launch(sdf, B, N, sdf_out, N0, 1, st));
@@ -1011,7 +1011,7 @@ int disn_encode_query(disn_ctx_t* ctx, const disn_vgg_weights_t* vw, const disn_
     DISN_TRY(hipEventRecord(ctx->ev[6], ctx->aux));
     if ((rc = vgg_head(vw, pool5, B, embedding, e.vgg, st))) return rc;
   }
-  { const int grc = gbias_layer(mw, embedding, B, e.q.gbias, e.q.gemv_ws, st, strict); if (grc) return grc; }
+  { const int grc = gbias_layer(mw, embedding, B, e.q.gbias, e.q.gemv_ws, st, vw->strict_forms == 1); if (grc) return grc; }
   if (h2) {  // global fold2/conv2 on relu(pre + bias) per image, then -- behind ev[6] -- both fold2/conv5 and the sum
     for (int b = 0; b < B; b += hb) {
       const size_t o = (size_t)b * N;

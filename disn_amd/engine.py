@@ -182,7 +182,7 @@ class SdfEngine:
         # ``strict``: disn_vgg_weights_t.strict_forms = 1 -- the single-image convolution kernels (k-wave tree, chains of 108
         # MFMAs per accumulator) for calls of ANY size instead of the batched form (chains of up to 432) from four images
         # on, the fc head and the point-MLP layers likewise: a request's taps, embedding and pred_sdf in a batched call are
-        # bit for bit those of the request alone (N < 8192 per request); about 40 % of a batched call's throughput
+        # bit for bit those of the request alone; about 40 % of a batched call's throughput
         # (include/disn_amd.h).  The struct is this engine's own copy: the packed weights stay shared.
         self._vgg = VggWeights.from_buffer_copy(self.weights.vgg)
         self._vgg.strict_forms = 1 if self.strict else 0

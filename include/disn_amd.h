@@ -141,10 +141,11 @@ typedef struct disn_vgg_weights {
    * EVERY call size -- conv_h2.hip's and dense_h2.hip's four / eight k-wave trees sum K in chains of ~108 MFMAs per
    * accumulator where the batched forms have up to 432; the fc head with the split count, VALU kernels and reduce lanes
    * of a one-row call -- so the taps, the embedding AND pred_sdf of a request in a call of any size are BIT FOR BIT
-   * those of the request alone (N < 8192 per request), i.e. it keeps the single-request form's distance from the float64
+   * those of the request alone (any N), i.e. it keeps the single-request form's distance from the float64
    * oracle (tests/test_gpu_sweep.py: EVERY request of the trained-like sweep <= 1e-5 -- median 2.2e-6 --
    * where the default's batched forms leave 2.7 % of the requests at 1.0-1.46e-5).  Costs ~39 % of a batched call's
-   * throughput (bench.py --strict: 10.3 M against 17 M points/s).  N >= 8192 per request keeps the fused kernels (per-point scales) either way. */
+   * throughput (bench.py --strict: 10.3 M against 17 M points/s).  N >= 8192 per request keeps the fused kernels (per-point scales) either
+   * way -- there, too, bit for bit the request alone. */
   int strict_forms;
 } disn_vgg_weights_t;
 
@@ -408,7 +409,7 @@ int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, 
  *   convolutions / fc head  B < 4: conv_h2.hip + one-launch fc rows; B >= 4: conv_h2w.hip + the split-K fc stream
  *               with up to sixteen batch rows per pass on the fp32 matrix pipe (gemv_mfma_kernel; disn_conv3x3_h2's rule).
  *   strict mode  vw->strict_forms == 1 (zero-initialise disn_vgg_weights_t: 0 is the default): the B < 4 forms of ALL of the
- *               above for any B (N < 8192 per request) -- request b's taps, embedding and sdf are then bit for bit those
+ *               above for any B -- request b's taps, embedding and sdf are then bit for bit those
  *               of a B = 1 call (tests/test_gpu_model.py::test_strict_mode_runs_the_single_image_forms); see the struct.
  * Every activation scale is per image (per point inside the fused kernels) on all of these paths, so request b's
  * outputs never depend on the other requests of its call, on its position, or on B beyond the thresholds above (B < 4:

@@ -545,13 +545,14 @@ def test_chained_batched_pipeline_on_separately_allocated_jobs():
     assert all(torch.equal(got[k], ref[k]) for k in range(len(jobs)))
 
 
-@pytest.mark.parametrize("B,N", [(5, 256), (4, 1000), (16, 2048)])
+@pytest.mark.parametrize("B,N", [(5, 256), (4, 1000), (16, 2048), (4, 8192)])
 def test_strict_mode_runs_the_single_image_forms(B, N):
     """disn_vgg_weights_t.strict_forms = 1 (SdfEngine(strict=True), include/disn_amd.h): a call of >= 4 requests through the
     single-image forms of the convolutions (conv_h2.hip), the fc head (one-row split count / row kernels) and the point-MLP
     layers (dense_h2.hip's four-k-wave tiles).  (1) every request's taps, embedding AND pred_sdf are BIT FOR BIT those of the
     request alone; (2) the flag changes something: the default engine's batched forms give other bits; (3) within 1e-5 of
-    the float64 oracle.  N = 1000 is not a multiple of 64: the layers then run image by image."""
+    the float64 oracle.  N = 1000 is not a multiple of 64: the layers then run image by image; N = 8192 per request takes the
+    fused kernels in either mode (per-point scales): still bit for bit the request alone."""
     from disn_amd.engine import SdfEngine
     from disn_amd.weights import WeightStore
     store = WeightStore.random_init(6, mode="he")
