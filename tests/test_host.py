@@ -291,3 +291,51 @@ def h_status(store):
     assert _lib.lib().disn_scale_channels(None, 1, 64, None, 0, None, None) == -1
     assert _lib.lib().disn_scale_channels(1, 1, 6, 1, 0, 1, None) == -2
     return 0
+
+
+def test_header_is_c99_and_struct_layouts_match_the_ctypes_binding(tmp_path):
+    """include/disn_amd.h is the boundary a C caller compiles against: it must be valid C99 (gcc -std=c99 -pedantic), a C
+    program must link against the library and reach its host-only entry points, and the struct layouts the C compiler
+    sees must be the ones disn_amd/_lib.py declares to ctypes (a field added on one side only would shift every later
+    member: disn_vgg_weights_t.strict_forms, disn_eq_weights_t were added in ABI 9)"""
+    import ctypes as C
+    from disn_amd import _lib
+    lib_path = _build()
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include <string.h>
+#include "disn_amd.h"
+int main(void) {
+  disn_vgg_weights_t v; disn_mlp_weights_t m; disn_eq_weights_t e; disn_param_layout_t p; disn_cam_weights_t c;
+  memset(&v, 0, sizeof v); memset(&m, 0, sizeof m); memset(&e, 0, sizeof e); (void)p; (void)c;
+  printf("abi %d %d\n", DISN_ABI_VERSION, disn_abi_version());
+  printf("vgg %zu %zu %zu %zu\n", sizeof v, offsetof(disn_vgg_weights_t, num_classes), offsetof(disn_vgg_weights_t, fc_w_t),
+         offsetof(disn_vgg_weights_t, strict_forms));
+  printf("mlp %zu %zu\n", sizeof m, offsetof(disn_mlp_weights_t, l_feat));
+  printf("eq %zu %zu %zu\n", sizeof e, offsetof(disn_eq_weights_t, mlp_w), offsetof(disn_eq_weights_t, num_classes));
+  printf("layout %zu cam %zu\n", sizeof p, sizeof c);
+  printf("crc %u\n", disn_crc32c("123456789", 9, 0));
+  printf("args %d %d %zu\n", disn_equalise_weights(&e, NULL, NULL), disn_scale_channels(NULL, 1, 64, NULL, 0, NULL, NULL),
+         disn_encode_query_workspace_bytes(1, 2048) > 0 ? (size_t)1 : (size_t)0);
+  return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    inc = os.path.join(ROOT, "include")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, str(src), "-o", str(exe),
+                        lib_path, "-Wl,-rpath," + os.path.dirname(lib_path), "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.stdout, out.stderr[-2000:])
+    f = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l.strip()}
+    assert f["abi"] == [str(_lib.ABI_VERSION)] * 2
+    V, M, E = _lib.VggWeights, _lib.MlpWeights, _lib.EqWeights
+    assert [int(x) for x in f["vgg"]] == [C.sizeof(V), V.num_classes.offset, V.fc_w_t.offset, V.strict_forms.offset]
+    assert [int(x) for x in f["mlp"]] == [C.sizeof(M), M.l_feat.offset]
+    assert [int(x) for x in f["eq"]] == [C.sizeof(E), E.mlp_w.offset, E.num_classes.offset]
+    assert [int(f["layout"][0]), int(f["layout"][2])] == [C.sizeof(_lib.ParamLayout), C.sizeof(_lib.CamWeights)]
+    assert int(f["crc"][0]) == 0xE3069283                 # CRC-32C check value of "123456789"
+    assert f["args"] == ["-1", "-1", "1"]
