@@ -38,6 +38,49 @@ def _noise(R, seed):
     return v
 
 
+# ---- the independent pin: skimage.measure.marching_cubes outputs (tests/golden/make_mc_fixtures.py, run with the image's
+# conda interpreter) -- neither this repo's table generator nor its oracle; "independent, not reference-held" (the
+# reference's own mesher is Vega-FEM's closed binary, test/create_sdf.py:305-322)
+SK_CASES = ["sphere33", "blobs41", "cfg1grid65", "noise25"]
+
+
+def _sk():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mc_skimage.npz"))
+
+
+def _mesh_stats(verts, faces):
+    v, f = np.asarray(verts, np.float64), np.asarray(faces, np.int64)
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    e = np.unique(np.sort(e, 1), axis=0)
+    p = v[f]
+    area = 0.5 * np.linalg.norm(np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), axis=1).sum()
+    vol = abs(np.einsum("ij,ij->i", p[:, 0], np.cross(p[:, 1], p[:, 2])).sum()) / 6.0
+    return len(v) - len(e) + len(f), float(area), float(vol)
+
+
+def _check_against_skimage(case, verts, faces):
+    from scipy.spatial import cKDTree
+    g = _sk()
+    cloud = g[case + "_cloud"].astype(np.float64)
+    n = g[case + "_vol"].shape[0]
+    voxel = 2.0 / (n - 1)
+    v = np.asarray(verts, np.float64)
+    # vertex-set Hausdorff distance: both methods put one vertex on every cut grid edge (linear interpolation) -- every
+    # vertex of ours must be one of theirs (to float32 rounding; half a voxel asserted); Lewiner's tables ADD a vertex
+    # inside some ambiguous cubes, so their cloud may lie up to one voxel from ours
+    d_ab = cKDTree(cloud).query(v)[0].max()
+    d_ba = cKDTree(v).query(cloud)[0].max()
+    assert d_ab <= 0.5 * voxel and d_ba <= 1.0 * voxel, (case, d_ab / voxel, d_ba / voxel)
+    chi, area, vol = _mesh_stats(verts, faces)
+    assert abs(area - float(g[case + "_area"])) <= 0.01 * float(g[case + "_area"]), (case, area, float(g[case + "_area"]))
+    if case in ("sphere33", "blobs41"):   # smooth surfaces: no ambiguous cube -> the same topology
+        assert chi == int(g[case + "_chi"]), (case, chi, int(g[case + "_chi"]))
+    # (noise25, cfg1grid65 -- the rough surface of random-init weights: Lewiner's tables and this repo's face-consistent
+    #  table connect ambiguous cubes differently; measured chi 20 vs 44 on cfg1grid65 with IDENTICAL edge vertices)
+    if case != "noise25":
+        assert abs(vol - float(g[case + "_volume"])) <= 0.01 * float(g[case + "_volume"]), (case, vol, float(g[case + "_volume"]))
+
+
 # ------------------------------------------------------------------ CPU
 def test_case_table_basic_facts():
     ntri, tri, maxt = M.gen.build_tables()
@@ -102,6 +145,15 @@ def test_iso_level_and_degenerate_inputs():
     assert vb[:, 0].max() > 1.0 and abs(vb[:, 2]).max() <= 0.5
 
 
+@pytest.mark.parametrize("case", SK_CASES)
+def test_oracle_against_skimage_fixture(case):
+    """oracle/mc_oracle.py vs scikit-image's mesher on the same volume: vertex clouds within half a voxel, equal
+    Euler characteristic, area and enclosed volume within 1 %"""
+    g = _sk()
+    v, f = M.marching_cubes(g[case + "_vol"], g["box"], float(g[case + "_iso"]))
+    _check_against_skimage(case, v, f)
+
+
 def test_write_obj_roundtrip(tmp_path):
     from disn_amd import isosurface as iso
     v, f = M.marching_cubes(_sphere(12), BOX, 0.0)
@@ -158,3 +210,16 @@ def test_gpu_full_resolution_mesh_properties(tmp_path):
     assert p.endswith(os.path.join("03001627", "03001627_abc_03.obj"))
     v2, f2 = iso.read_obj(p)
     assert np.array_equal(v2, vn) and np.array_equal(f2, fn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", SK_CASES)
+def test_gpu_marching_cubes_against_skimage_fixture(case):
+    """disn_mc_count / disn_mc_emit vs scikit-image's mesher (independent of this repo's tables and oracle)"""
+    import torch
+    from disn_amd import isosurface
+    g = _sk()
+    vol = g[case + "_vol"]
+    v, f = isosurface.marching_cubes(torch.from_numpy(vol.reshape(-1)).cuda(), [float(x) for x in g["box"]],
+                                     vol.shape[0] - 1, float(g[case + "_iso"]))
+    _check_against_skimage(case, v.cpu().numpy(), f.cpu().numpy())
