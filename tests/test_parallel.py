@@ -99,6 +99,43 @@ def test_sharded_grid_all_to_all_gloo_world2(total, n_images):
     assert sorted(seen) == list(range(n_images))
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("exchange", ["all_gather", "all_to_all"])
+def test_sharded_grid_gloo_world8_config4_shape(exchange):
+    """BASELINE config 4's launch shape on CPU: 8 ranks, 8 images, a grid whose point count leaves the same remainder
+    mod 8 as 257^3 (65^3 = 274 625 = 8 * 34 328 + 1: one rank's slice is a point longer) -- both exchanges"""
+    world, n_images, total = 8, 8, 65 ** 3
+    assert total % world == (257 ** 3) % world == 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 777 + (11 if exchange == "all_to_all" else 0)) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, n_images, q, exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    k = np.arange(total, dtype=np.float64)
+    expect = np.stack([(np.sin(k * 0.37 + b) * 3.0).astype(np.float32) for b in range(n_images)])
+    sizes = par.shard_sizes(total, world)
+    assert sum(sizes) == total and sorted(set(sizes)) == [34328, 34329]
+    seen = []
+    for res in results:
+        rank, out, calls = res[0], res[1], res[2]
+        k0, k1 = par.shard_range(total, world, rank)
+        assert calls == [(b, k0, k1) for b in range(n_images)]
+        if exchange == "all_to_all":
+            own = res[3]
+            assert own == par.owned_images(n_images, world, rank) == [rank]   # one image per GPU: the rank that meshes it
+            assert np.array_equal(out, expect[own])
+            seen += own
+        else:
+            assert np.array_equal(out, expect), "rank %d" % rank
+    if exchange == "all_to_all":
+        assert sorted(seen) == list(range(n_images))
+
+
 def test_single_process_equals_unsharded():
     total = 343
 
