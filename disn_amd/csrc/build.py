@@ -32,8 +32,8 @@ SOURCES = {
     "cam_head.hip": [],
     "mlp_small.hip": [],
     "mlp_fused.hip": [],
-    "conv_h2.hip": [],
-    "conv_h2w.hip": [],
+    "conv_h2.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+    "conv_h2w.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],   # the unrolled chunk bodies exceed the default 16 k
     "dense_h2.hip": [],
     "dense_h2w.hip": [],
     "elementwise.hip": ["-ffp-contract=off"],

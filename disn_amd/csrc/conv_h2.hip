@@ -287,7 +287,9 @@ hipError_t conv_h2_pack_launch(const float* w, int Cin, int Cout, void* image, f
 // ABL (tools/ubench/conv_h2_ablate.hip only; 0 in the library): 1 no weight loads in the loop, 2 no halo loads,
 // 4 no split + LDS store, 8 no A-fragment reads in the loop (wrong results: timing only)
 // OCC: workgroups per CU the register budget is cut for (2: the batched calls' multi-round grids, tuning builds)
-template <int MB, int NW, int SEG, int TW, int D, int WK, int ABL = 0, int OCC = 1>
+// FL > 0 (the 14 x 14 layers of a batched call): a k-wave's accumulators restart every FL chunks (chains of 27 FL MFMAs)
+// and the finished segment is added to a second register set in fp32 VALU adds, as in conv_h2w.hip's SEG form
+template <int MB, int NW, int SEG, int TW, int D, int WK, int ABL = 0, int OCC = 1, int FL = 0>
 __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) void conv_h2_kernel(const ConvH2Dev P) {
   // (HIP's second launch-bound is waves per SIMD, not workgroups per CU)
   constexpr int CK = 16 * WK;         // input channels per chunk
@@ -344,38 +346,59 @@ __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) voi
   // ---- halo loader: unit u = (pixel, float4 of the chunk's 64 channels); 16 lanes = one pixel ----------------
   // every load is unconditional and every loaded value is used (an out-of-image unit reads a valid pixel and is
   // ANDed with 0): no exec-mask branches, so the compiler can count the loads in flight (s_waitcnt vmcnt(N))
-  int goff[LP], woff[LP];
-  unsigned gmask[LP];
+  // REG (the 14-pixel patches with 64-channel chunks: 16 halo pixels x 16 units = the 256 threads): unit k of a thread is
+  // halo ROW k of its (column, channel group) -- offsets and masks are arithmetic in k, three registers instead of 3 LP
+  constexpr bool REG = FL > 0 && RP * UPP == NT;
+  int goff[REG ? 1 : LP], woff[REG ? 1 : LP];
+  unsigned gmask[REG ? 1 : LP];
+  const int r_hx = tid / UPP, r_c4 = tid % UPP;
+  const bool r_xok = x0 - 1 + r_hx >= 0 && x0 - 1 + r_hx < W;
+  const int r_g0 = ((y0 - 1) * W + x0 - 1 + r_hx) * Cin + 4 * r_c4;
+  if constexpr (!REG) {
 #pragma unroll
-  for (int k = 0; k < LP; ++k) {
-    const int u = tid + k * NT;
-    const int hp = u / UPP, c4 = u % UPP;
-    const int hy = hp / RP, hx = hp - hy * RP;
-    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-    const bool in_halo = u < HP * UPP;
-    const bool ok = in_halo && y >= 0 && y < H && x >= 0 && x < W;
-    goff[k] = ok ? (y * W + x) * Cin + 4 * c4 : 4 * c4;
-    gmask[k] = ok ? 0xffffffffu : 0u;
-    woff[k] = in_halo ? hp * KPIX + 8 * c4 : -1;
+    for (int k = 0; k < LP; ++k) {
+      const int u = tid + k * NT;
+      const int hp = u / UPP, c4 = u % UPP;
+      const int hy = hp / RP, hx = hp - hy * RP;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool in_halo = u < HP * UPP;
+      const bool ok = in_halo && y >= 0 && y < H && x >= 0 && x < W;
+      goff[k] = ok ? (y * W + x) * Cin + 4 * c4 : 4 * c4;
+      gmask[k] = ok ? 0xffffffffu : 0u;
+      woff[k] = in_halo ? hp * KPIX + 8 * c4 : -1;
+    }
   }
-  auto load_chunk = [&](int c, float4 (&ra)[LP]) {
+  auto unit_ok = [&](int k) __attribute__((always_inline)) { return r_xok && y0 - 1 + k >= 0 && y0 - 1 + k < H; };
+  auto load_chunk = [&](int c, float4 (&ra)[LP]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < LP; ++k) ra[k] = *reinterpret_cast<const float4*>(inb + goff[k] + CK * c);
+    for (int k = 0; k < LP; ++k) {
+      if constexpr (REG) ra[k] = *reinterpret_cast<const float4*>(inb + (unit_ok(k) ? r_g0 + k * W * Cin : 4 * r_c4) + CK * c);
+      else ra[k] = *reinterpret_cast<const float4*>(inb + goff[k] + CK * c);
+    }
   };
   float sa = 1.0f;
-  auto store_unit = [&](int buf, const float4 (&ra)[LP], int k) {
-    if (woff[k] < 0) return;
+  auto store_unit = [&](int buf, const float4 (&ra)[LP], int k) __attribute__((always_inline)) {
+    int wo;
+    unsigned gm;
+    if constexpr (REG) {
+      wo = (k * RP + r_hx) * KPIX + 8 * r_c4;
+      gm = unit_ok(k) ? 0xffffffffu : 0u;
+    } else {
+      if (woff[k] < 0) return;
+      wo = woff[k];
+      gm = gmask[k];
+    }
     const float x[4] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w};
     ch_h4 hh, ll;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float v = __uint_as_float(__float_as_uint(x[e]) & gmask[k]) * sa;
+      const float v = __uint_as_float(__float_as_uint(x[e]) & gm) * sa;
       const _Float16 h = (_Float16)v;
       hh[e] = h;
       ll[e] = (_Float16)(v - (float)h);
     }
-    *reinterpret_cast<ch_h4*>(&lds[buf * BUF + woff[k]]) = hh;
-    *reinterpret_cast<ch_h4*>(&lds[buf * BUF + woff[k] + CK * 2]) = ll;
+    *reinterpret_cast<ch_h4*>(&lds[buf * BUF + wo]) = hh;
+    *reinterpret_cast<ch_h4*>(&lds[buf * BUF + wo + CK * 2]) = ll;
   };
 
   // the first halo is requested before anything else (loads return in order: nothing may queue in front of it)
@@ -417,6 +440,17 @@ __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) voi
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  f2v tot[FL > 0 ? MB : 1][8];
+  ch_f16v zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+  if (FL > 0) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) tot[mb][r] = f2v{0.f, 0.f};
+  }
 
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) amax_lane = fmaxf(amax_lane, __shfl_xor(amax_lane, off));
@@ -442,8 +476,9 @@ __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) voi
     }
   };
   constexpr int T0 = 5;
-  auto chunk = [&](int c, auto more_c) {
+  auto chunk = [&](int c, auto more_c, auto first_c) __attribute__((always_inline)) {
     constexpr bool MORE = decltype(more_c)::value;
+    constexpr bool FIRST = decltype(first_c)::value;   // first chunk of a segment (FL > 0)
     float4 ra[LP];
     if (MORE && !(ABL & 2)) load_chunk(c + 1, ra);
     if (ABL & 2) {
@@ -452,6 +487,48 @@ __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) voi
     }
     const unsigned char* A = &lds[(c & 1) * BUF];
     const unsigned char* wcur = wp + (size_t)c * kChunkStride;
+    if constexpr (FL > 0 && MB > 2) {
+      // the segmented form of the whole-image tiling: the second accumulator set takes the registers of the double-buffered
+      // A fragments (2 x 7 blocks x 8) -- here a ring of four (block, tap) sub-steps, read two sub-steps ahead
+      constexpr int S = 9 * MB, NBR = 3, AH = 2;
+      ch_h8 rh[NBR], rl[NBR];
+      auto rd = [&](int s) __attribute__((always_inline)) {
+        const int t = s / MB, mb = s % MB;
+        const int shift = ((t / 3 - 1) * RP + (t % 3 - 1)) * KPIX;
+        rh[s % NBR] = *reinterpret_cast<const ch_h8*>(A + arow[mb] + shift);
+        rl[s % NBR] = *reinterpret_cast<const ch_h8*>(A + arow[mb] + shift + CK * 2);
+      };
+#pragma unroll
+      for (int s = 0; s < AH; ++s) rd(s);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const ch_h8 bh = qh[t % D], bl = ql[t % D];
+        if (MORE || t + D < 9) {
+          const unsigned char* wa = wcur + ((t + D) / 9) * kChunkStride + (size_t)((t + D) % 9) * 2048;
+          qh[t % D] = *reinterpret_cast<const ch_h8*>(wa);
+          ql[t % D] = *reinterpret_cast<const ch_h8*>(wa + 1024);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int sidx = t * MB + mb;
+          if (sidx + AH < S) rd(sidx + AH);
+          const bool f = FIRST && t == 0;
+          if (f) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) tot[mb][r] += f2v{acc[mb][2 * r], acc[mb][2 * r + 1]};
+          }
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[sidx % NBR], bh, f ? zero16 : acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[sidx % NBR], bl, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[sidx % NBR], bh, acc[mb], 0, 0, 0);
+        }
+        if (MORE && t >= T0) {
+#pragma unroll
+          for (int k = 0; k < LP; ++k)
+            if (T0 + ((9 - T0) * k) / LP == t) store_unit((c + 1) & 1, ra, k);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     ch_h8 ah[2][MB], al[2][MB];
     read_a(A, 0, ah[0], al[0]);
 #pragma unroll
@@ -470,7 +547,12 @@ __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) voi
       __builtin_amdgcn_sched_barrier(0);  // the loads above are ISSUED here, not sunk next to their uses
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t & 1][mb], bh, acc[mb], 0, 0, 0);
+        const bool f = FIRST && t == 0;   // the block's finished segment -> tot, the new one starts from C = 0
+        if (f) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) tot[mb][r] += f2v{acc[mb][2 * r], acc[mb][2 * r + 1]};
+        }
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t & 1][mb], bh, f ? zero16 : acc[mb], 0, 0, 0);
         acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t & 1][mb], bl, acc[mb], 0, 0, 0);
         acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t & 1][mb], bh, acc[mb], 0, 0, 0);
       }
@@ -487,14 +569,36 @@ __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) voi
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
     __syncthreads();
   };
+  constexpr std::true_type T{};
+  constexpr std::false_type F{};
+  if constexpr (FL == 0) {
 #pragma unroll 1
-  for (int c = 0; c + 1 < NC; ++c) {
-    chunk(c, std::true_type{});
-    if (c < 8) { CH2_STAMP(4 + c); }
+    for (int c = 0; c + 1 < NC; ++c) {
+      chunk(c, T, F);
+      if (c < 8) { CH2_STAMP(4 + c); }
+    }
+    chunk(NC - 1, F, F);
+  } else {
+    static_assert(FL == 2, "chunks per segment");   // (NC % 2 == 0: Cin % (32 WK) == 0, the launcher's business)
+#pragma unroll 1
+    for (int c = 0; c + 2 < NC; c += 2) {
+      chunk(c, T, T);
+      chunk(c + 1, T, F);
+    }
+    chunk(NC - 2, T, T);
+    chunk(NC - 1, F, F);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const f2v t = tot[mb][r] + f2v{acc[mb][2 * r], acc[mb][2 * r + 1]};
+        acc[mb][2 * r] = t[0];
+        acc[mb][2 * r + 1] = t[1];
+      }
   }
-  chunk(NC - 1, std::false_type{});
   CH2_STAMP(12);
 
   // ---- sum of the k-waves through LDS in a fixed order -- (w0 + w2) + (w1 + w3), with eight waves
@@ -719,13 +823,14 @@ hipError_t conv1_1_direct_launch(const float* in, int B, int H, int W, const flo
   return hipGetLastError();
 }
 
-template <int MB, int NW, int SEG, int TW, int D, int WK, int OCC = 1>
+template <int MB, int NW, int SEG, int TW, int D, int WK, int OCC = 1, int FL = 0>
 static hipError_t conv_h2_go(ConvH2Dev d, hipStream_t st) {
+  if (FL > 0 && (d.Cin / (16 * WK)) % FL != 0) return hipErrorInvalidValue;
   constexpr int TH = MB * (32 / SEG);
   d.tiles_x = (d.W + TW - 1) / TW;
   d.tiles_y = (d.H + TH - 1) / TH;
   const int grid = d.B * d.tiles_x * d.tiles_y * (d.Cout / (32 * NW));
-  hipLaunchKernelGGL((conv_h2_kernel<MB, NW, SEG, TW, D, WK, 0, OCC>), dim3(grid), dim3(64 * WK * NW), 0, st, d);
+  hipLaunchKernelGGL((conv_h2_kernel<MB, NW, SEG, TW, D, WK, 0, OCC, FL>), dim3(grid), dim3(64 * WK * NW), 0, st, d);
   return hipGetLastError();
 }
 
@@ -764,16 +869,25 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
   // fragment reads for conv5_x of 16 images: L2-bound, 32 % MFMA busy, 65 us), the whole image 21 (52 us).  Smaller
   // calls keep the two-row patches (measured equal to the eight-k-wave tiling at 4 / 8 / 12 images: r03ad).
   if (cfg == 10) return conv_h2_go<7, 1, 16, 14, 3, 4>(d, st);
+  if (cfg == 19) return conv_h2_go<7, 1, 16, 14, 3, 4, 1, 2>(d, st);   // the whole-image tiling in segments of two chunks
   // cfg 11 ("strict", disn_vgg_weights_t.strict_forms = 1): the single-image tilings below by shape, whatever B -- the same
   // k-waves and summation tree as a call of one image: the same bits
   const bool strict = cfg == 11;
   if (strict) cfg = 0;
+  // cfg 18 (the training step): the batched forms of round 3 for every layer (conv_h2w_launch variant -1)
+  const bool fast = cfg == 18;
+  if (fast) cfg = 0;
   if (!strict && cfg == 0 && tune::conv5_whole && W <= 14 && H <= 14 && B >= tune::conv_wide_min) {
-    if ((long)B * (Cout / 32) >= 200) return conv_h2_go<7, 1, 16, 14, 3, 4>(d, st);
-    return conv_h2_go<1, 1, 16, 14, 3, 4, 2>(d, st);
+    if (fast || Cin % 128 != 0) {   // (the training step: round 3's chains of 216)
+      if ((long)B * (Cout / 32) >= 200) return conv_h2_go<7, 1, 16, 14, 3, 4>(d, st);
+      return conv_h2_go<1, 1, 16, 14, 3, 4, 2>(d, st);
+    }
+    // inference: the four k-waves in segments of two chunks (chains of 54), whatever the patch
+    if ((long)B * (Cout / 32) >= 200) return conv_h2_go<7, 1, 16, 14, 3, 4, 1, 2>(d, st);
+    return conv_h2_go<1, 1, 16, 14, 3, 4, 2, 2>(d, st);
   }
-  if (cfg >= 5) return conv_h2w_supported(H, W, Cin, Cout) ? conv_h2w_launch(d, st, cfg - 4) : hipErrorInvalidValue;
-  if (!strict && cfg == 0 && B >= tune::conv_wide_min && conv_h2w_supported(H, W, Cin, Cout)) return conv_h2w_launch(d, st, 0);
+  if (cfg >= 5) return conv_h2w_supported(H, W, Cin, Cout) ? conv_h2w_launch(d, st, cfg == 12 ? 6 : cfg - 4) : hipErrorInvalidValue;
+  if (!strict && cfg == 0 && B >= tune::conv_wide_min && conv_h2w_supported(H, W, Cin, Cout)) return conv_h2w_launch(d, st, fast ? -1 : 0);
   if (cfg == 0) {
     // patch shape by image width; n-blocks per workgroup so that one image still gives >= ~200 workgroups
     if (W <= 14) cfg = 1;
@@ -842,10 +956,12 @@ int disn_conv3x3_h2(const float* in, int B, int H, int W, int Cin, const void* i
                     int relu, float* out, float* pool_out, float* out_amax, int tiling, void* ws, size_t ws_bytes,
                     void* stream) {
   if (!in || !image || !bias || !out || !ws || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
-  if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 11 || (pool_out && ((H | W) & 1)))
+  if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 19 || (tiling >= 13 && tiling <= 17) || (pool_out && ((H | W) & 1)))
     return DISN_E_SHAPE;
-  if (tiling >= 5 && tiling <= 9 && !disn::conv_h2w_supported(H, W, Cin, Cout)) return DISN_E_SHAPE;
-  if ((tiling == 6 || tiling == 8) && Cout % 128) return DISN_E_SHAPE;   // variants 2, 4: four n-waves = 128 channels per workgroup
+  if (((tiling >= 5 && tiling <= 9) || tiling == 12) && !disn::conv_h2w_supported(H, W, Cin, Cout)) return DISN_E_SHAPE;
+  if ((tiling == 6 || tiling == 8 || tiling == 12) && Cout % 128) return DISN_E_SHAPE;   // four n-waves = 128 channels per workgroup
+  if (tiling == 12 && Cin % 32) return DISN_E_SHAPE;                                        // whole segments of two chunks
+  if (tiling == 19 && (H > 14 || W > 14 || Cin % 128)) return DISN_E_SHAPE;
   if (tiling == 10 && (H > 14 || W > 14)) return DISN_E_SHAPE;
   if (ws_bytes < (size_t)B * 512) return DISN_E_WS;
   hipStream_t st = (hipStream_t)stream;

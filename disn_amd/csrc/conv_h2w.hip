@@ -52,7 +52,7 @@ constexpr int w_row_bytes(int raw) {  // smallest size >= raw that is 128 (mod 2
 
 // MB row blocks per wave, MWV m-waves x NWV n-waves x WK k-waves per workgroup, patch TH x TW (= 32 MB MWV pixels),
 // OCC workgroups per CU the register budget is cut for
-template <int MB, int MWV, int NWV, int WK, int TH, int TW, int OCC>
+template <int MB, int MWV, int NWV, int WK, int TH, int TW, int OCC, int SEG = 0>
 __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4) void conv_h2w_kernel(const ConvH2Dev P) {
   constexpr int NWAVES = MWV * NWV * WK, NT = 64 * NWAVES;
   constexpr int CK = 16 * WK;              // input channels per chunk: one k16 block per k-wave
@@ -172,6 +172,24 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+  // SEG > 0: the accumulators restart every SEG chunks (chains of 27 SEG MFMAs) and the finished segment is added to
+  // a second register set: out = ((s0 + s1) + s2) + ... in fp32 VALU adds
+  // (tot as register PAIRS, never an MFMA operand: no 16-register tuples to keep aligned; one v_pk_add_f32 per pair)
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  f2v tot[SEG > 0 ? MB : 1][8];
+  ch_f16v zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+  if (SEG > 0) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) tot[mb][r] = f2v{0.f, 0.f};
+  }
+  auto flush = [&](int mb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) tot[mb][r] += f2v{acc[mb][2 * r], acc[mb][2 * r + 1]};
+  };
 
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) amax_lane = fmaxf(amax_lane, __shfl_xor(amax_lane, off));
@@ -197,8 +215,9 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   constexpr int T0 = 4;
   constexpr int P0 = (T0 * MB + 1) / 2;          // first pair that may carry a unit of the next halo
   constexpr int SLOTS = NP - P0;
-  auto chunk = [&](int c, auto more_c) {
+  auto chunk = [&](int c, auto more_c, auto first_c) __attribute__((always_inline)) {
     constexpr bool MORE = decltype(more_c)::value;
+    constexpr bool FIRST = decltype(first_c)::value;   // first chunk of a segment (SEG > 0): see the flush below
     float4 ra[LP];
     if (MORE) load_chunk(c + 1, ra);
     int ab[MB];
@@ -221,15 +240,20 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
       if (s0 + 2 * PD < S) rd(s0 + 2 * PD);
       if (s1 + 2 * PD < S) rd(s1 + 2 * PD);
       __builtin_amdgcn_sched_barrier(0);  // the reads above are ISSUED here, not sunk next to their uses
+      // segment start: block m's finished segment goes to tot[m] right before the block's first MFMA of the new
+      // segment, which starts from C = 0 -- the adds of one block run under the MFMAs of the others
+      const bool f0 = FIRST && t0 == 0, f1 = FIRST && t1 == 0 && s1 < S;
+      if (f0) flush(m0);
+      if (f1) flush(m1);
       if (s1 < S) {
-        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s0 % NB], qh[t0 % D], acc[m0], 0, 0, 0);
-        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s1 % NB], qh[t1 % D], acc[m1], 0, 0, 0);
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s0 % NB], qh[t0 % D], f0 ? zero16 : acc[m0], 0, 0, 0);
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s1 % NB], qh[t1 % D], f1 ? zero16 : acc[m1], 0, 0, 0);
         acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s0 % NB], ql[t0 % D], acc[m0], 0, 0, 0);
         acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s1 % NB], ql[t1 % D], acc[m1], 0, 0, 0);
         acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s0 % NB], qh[t0 % D], acc[m0], 0, 0, 0);
         acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s1 % NB], qh[t1 % D], acc[m1], 0, 0, 0);
       } else {
-        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s0 % NB], qh[t0 % D], acc[m0], 0, 0, 0);
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s0 % NB], qh[t0 % D], f0 ? zero16 : acc[m0], 0, 0, 0);
         acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s0 % NB], ql[t0 % D], acc[m0], 0, 0, 0);
         acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s0 % NB], qh[t0 % D], acc[m0], 0, 0, 0);
       }
@@ -263,12 +287,38 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
     __syncthreads();
   };
   static_assert(LP <= SLOTS, "halo units per thread");
+  if constexpr (SEG == 0) {
 #pragma unroll 1
-  for (int c = 0; c + 1 < NC; ++c) {
-    chunk(c, std::true_type{});
-    if (c < 8) { CH2W_STAMP(4 + c); }
+    for (int c = 0; c + 1 < NC; ++c) {
+      chunk(c, std::true_type{}, std::false_type{});
+      if (c < 8) { CH2W_STAMP(4 + c); }
+    }
+    chunk(NC - 1, std::false_type{}, std::false_type{});
+  } else {
+    // segments of SEG chunks (SEG = 1, 2, 4; NC % SEG == 0: the launcher's business); the very first "flush" adds
+    // zeros to zeros
+    static_assert(SEG == 1 || SEG == 2 || SEG == 4, "chunks per segment");
+    constexpr std::true_type T{};
+    constexpr std::false_type F{};
+#pragma unroll 1
+    for (int c = 0; c + SEG < NC; c += SEG) {
+      chunk(c, T, T);
+      if constexpr (SEG >= 2) chunk(c + 1, T, F);
+      if constexpr (SEG >= 4) { chunk(c + 2, T, F); chunk(c + 3, T, F); }
+      if (c < 8) { CH2W_STAMP(4 + c); }
+    }
+    if constexpr (SEG == 1) chunk(NC - 1, F, T);
+    if constexpr (SEG == 2) { chunk(NC - 2, T, T); chunk(NC - 1, F, F); }
+    if constexpr (SEG == 4) { chunk(NC - 4, T, T); chunk(NC - 3, T, F); chunk(NC - 2, T, F); chunk(NC - 1, F, F); }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const f2v t = tot[mb][r] + f2v{acc[mb][2 * r], acc[mb][2 * r + 1]};
+        acc[mb][2 * r] = t[0];
+        acc[mb][2 * r + 1] = t[1];
+      }
   }
-  chunk(NC - 1, std::false_type{});
   CH2W_STAMP(12);
 
   // ---- two k-waves: p0 + p1 through LDS.  k-wave 0 finishes blocks 0 .. MBH - 1, k-wave 1 the others: each hands
@@ -371,12 +421,13 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   CH2W_STAMP(14);
 }
 
-template <int MB, int MWV, int NWV, int WK, int TH, int TW, int OCC>
+template <int MB, int MWV, int NWV, int WK, int TH, int TW, int OCC, int SEG = 0>
 static hipError_t conv_h2w_go(ConvH2Dev d, hipStream_t st) {
+  if (SEG > 0 && (d.Cin / (16 * WK)) % SEG != 0) return hipErrorInvalidValue;   // whole segments only
   d.tiles_x = (d.W + TW - 1) / TW;
   d.tiles_y = (d.H + TH - 1) / TH;
   const int grid = d.B * d.tiles_x * d.tiles_y * (d.Cout / (32 * NWV));
-  hipLaunchKernelGGL((conv_h2w_kernel<MB, MWV, NWV, WK, TH, TW, OCC>), dim3(grid), dim3(64 * MWV * NWV * WK), 0, st, d);
+  hipLaunchKernelGGL((conv_h2w_kernel<MB, MWV, NWV, WK, TH, TW, OCC, SEG>), dim3(grid), dim3(64 * MWV * NWV * WK), 0, st, d);
   return hipGetLastError();
 }
 
@@ -394,11 +445,17 @@ bool conv_h2w_supported(int H, int W, int Cin, int Cout) {
   return conv_h2_supported(H, W, Cin, Cout) && Cin % 32 == 0 && (long)H * W >= 28 * 28;
 }
 
-// variant: 0 = by shape and batch; 1..5 force <4,2,2,1,8,32>, <7,1,4,1,8,28>, <7,1,2,1,8,28>, <7,1,4,2,8,28>, <7,1,2,2,8,28>
+// variant: 0 = by shape (the inference path), -1 = round 3's selection by shape and batch (the training step); 1..5 force
+// <4,2,2,1,8,32>, <7,1,4,1,8,28>, <7,1,2,1,8,28>, <7,1,4,2,8,28>, <7,1,2,2,8,28>, 6 the segmented <7,1,4,1,8,28,1,SEG=2>
 // (tests: every shape through every variant; 1..3 have one k-wave, 4..5 two -- variants with the same number of
-// k-waves give the same bits)
+// k-waves give the same bits; 6 has its own: one k-wave in segments of two chunks)
 hipError_t conv_h2w_launch(ConvH2Dev d, hipStream_t st, int variant) {
-  if (variant == 0) {
+  // variant 0 (the inference path): layers whose one-k-wave chain would exceed 108 MFMAs per accumulator (Cin >= 128)
+  // take the SEGMENTED form -- chains of 54, the segments summed in fp32 -- whatever the batch; conv1_2 / conv2_1
+  // (Cin = 64: chains of 108 as they are) the round-3 variants below.  variant -1 (the training step): round 3's
+  // selection for every layer (chains of up to 432: faster at 4 .. 11 images per call, 1.7 x the error)
+  if (variant == 0 && d.Cin >= 128 && d.Cout % 128 == 0) variant = 6;
+  if (variant == 0 || variant == -1) {
     const int wk = conv_h2w_kwaves(d.H, d.W, d.Cin, d.Cout);
     if (wk == 1) {
       // 128-channel workgroups (two per CU) while they give >= ~200 workgroups, else the 64-channel 8 x 32 patches
@@ -417,6 +474,7 @@ hipError_t conv_h2w_launch(ConvH2Dev d, hipStream_t st, int variant) {
     case 3: return conv_h2w_go<7, 1, 2, 1, 8, 28, 2>(d, st);
     case 4: return conv_h2w_go<7, 1, 4, 2, 8, 28, 1>(d, st);
     case 5: return conv_h2w_go<7, 1, 2, 2, 8, 28, 1>(d, st);
+    case 6: return conv_h2w_go<7, 1, 4, 1, 8, 28, 1, 2>(d, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -204,7 +204,7 @@ int conv_bwd(const float* x, int B, int H, int W, int Cin, const float* w, const
     DISN_TRY(gemm_tn_launch(t, s.tn_ws, st));
   }
   if (dx && h2img) {
-    DISN_TRY(conv_h2_launch(dz, B, H, W, Cout, h2img, s.zero, Cin, 0, amax, dx, nullptr, nullptr, st, 0, 64));
+    DISN_TRY(conv_h2_launch(dz, B, H, W, Cout, h2img, s.zero, Cin, 0, amax, dx, nullptr, nullptr, st, 18, 64));
   } else if (dx) {
     const float* wt = prepacked;
     if (!wt) {
@@ -563,7 +563,7 @@ int disn_train_step(disn_ctx_t* ctx, const float* params, float* grads, const fl
     } else if (h2fwd) {
       DISN_TRY(conv_h2_launch(x, B, c.hw, c.hw, c.cin, t.conv_h2img[i], P(2 * i + 1), c.cout, 1,
                               t.amax + (size_t)B * 64 * i, t.act[i], c.pool ? t.pooled[i] : nullptr,
-                              t.amax + (size_t)B * 64 * (i + 1), st, 0, 64));
+                              t.amax + (size_t)B * 64 * (i + 1), st, 18, 64));
     } else {
       DISN_RC(conv_fwd(x, B, c.hw, c.hw, c.cin, t.conv_p[i], P(2 * i + 1), c.cout, 1, t.act[i], gws, gwb, st, bf));
     }

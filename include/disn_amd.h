@@ -80,13 +80,21 @@ int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w
  * force variant 1..5 of the BATCHED form (conv_h2w.hip: waves own 32-channel n-blocks of 128..224-pixel patches and
  * walk K sequentially; variants 1..3 one k-wave, 4..5 two; H*W >= 784), 10 = the whole-image tiling of layers of at
  * most 14 x 14 pixels (one workgroup per image and 32-channel block, four k-waves), 11 = by shape, single-image form
- * whatever B (what disn_vgg_weights_t.strict_forms = 1 runs).
- * SELECTION RULE of tiling 0 (also inside disn_vgg16_* / disn_encode*): calls of B >= 4 images take the batched form
- * for layers of 28 x 28 pixels and more (one k-wave where H*W*Cout >= 56*56*256 -- conv1_2 .. conv3_3 --, else two -- by layer shape only) and
- * four k-waves for the 14 x 14 layers (the whole-image tiling where B * Cout / 32 >= 200, two-row patches below:
- * same bits); everything else the single-image form.  The two forms sum K in different orders: results agree to fp32 rounding
- * (both within 2e-6 of the layer's scale of the float64 convolution), NOT bit for bit -- an image's bits depend on
- * which form ran it (B >= 4 or not), never on its companions, its position or the exact B.
+ * whatever B (what disn_vgg_weights_t.strict_forms = 1 runs), 12 = the SEGMENTED batched variant (round 6: one k-wave whose
+ * accumulators restart every two 16-channel chunks -- chains of 54 MFMAs -- the finished segments summed in fp32 VALU adds;
+ * Cout % 128 == 0), 18 = round 3's batched selection by shape and batch (one or two k-waves, chains of up to 432: what the
+ * training step runs), 19 = tiling 10 in segments of two 64-channel chunks (Cin % 128 == 0).
+ * SELECTION RULE of tiling 0 (also inside disn_vgg16_* / disn_encode*): calls of B >= 4 images take, by LAYER SHAPE only,
+ *   - layers of 28 x 28 pixels and more with Cin >= 128 (conv2_2 .. conv4_3): the segmented batched variant (12);
+ *   - layers of 28 x 28 pixels and more with Cin = 64 (conv1_2, conv2_1): the one-k-wave batched form (chains of 108);
+ *   - the 14 x 14 layers: four k-waves in segments of two chunks (19 where B * Cout / 32 >= 200, two-row patches below:
+ *     same bits);
+ * everything else the single-image form.  The forms sum K in different orders: results agree to fp32 rounding (all
+ * within 1e-6 of the layer's scale of the float64 convolution; rms 3-4e-8), NOT bit for bit -- an image's bits depend on
+ * which form ran it (B >= 4 or not), never on its companions, its position or the exact B.  Why segments: a chain of
+ * L MFMAs on one fp32 accumulator carries ~0.3 sqrt(L) ulp of rounding noise (tools/ubench/mfma_round.hip: 6.2 ulp rms
+ * at 432, 0.9-1.0 with a restart every 27-54); round 3's chains of 216-432 put 2.7 % of trained-like batched requests at
+ * 1.0-1.46e-5 of the float64 oracle (profiles/r05k_sweep_full.json), the segmented forms none (profiles/r06e_sweep_full.json).
  * ws: disn_conv3x3_h2_workspace_bytes(B). */
 size_t disn_pack_conv_h2_bytes(int Cin, int Cout);
 int disn_pack_conv_h2(const float* w_hwio, int Cin, int Cout, void* image, void* stream);

@@ -89,7 +89,12 @@ def test_whole_image_tiling_of_14_pixel_layers(ops, B, H, W, Cin, Cout):
     alone = host(ops.conv3x3_h2(dev(x[B - 1:]), img, dev(b), Cout, True, tiling=10))
     assert np.array_equal(alone[0], got[B - 1])
     if B >= 4:
-        assert np.array_equal(host(ops.conv3x3_h2(dev(x), img, dev(b), Cout, True, tiling=0)), got)
+        # tiling 0 (inference): four k-waves in SEGMENTS of two chunks -- tiling 19's bits whatever the patch; tiling 18
+        # (the training step's selection): the plain four-k-wave chains of tiling 10
+        seg = host(ops.conv3x3_h2(dev(x), img, dev(b), Cout, True, tiling=19))
+        assert float(np.abs(seg - ref).max()) <= 1e-6 * scale
+        assert np.array_equal(host(ops.conv3x3_h2(dev(x), img, dev(b), Cout, True, tiling=0)), seg)
+        assert np.array_equal(host(ops.conv3x3_h2(dev(x), img, dev(b), Cout, True, tiling=18)), got)
     # four k-waves: the bits of the other four-k-wave tilings
     if Cin % 128:
         assert np.array_equal(host(ops.conv3x3_h2(dev(x), img, dev(b), Cout, True, tiling=1)), got)
@@ -127,14 +132,14 @@ def test_tilings_agree_bit_for_bit_and_runs_repeat(ops):
 
 
 def test_14_pixel_layers_of_a_batched_call_run_with_four_k_waves(ops):
-    """14-pixel layers (conv5_x) stay on conv_h2.hip; in a call of four images and more they run with FOUR k-waves
-    (two-row patches, two workgroups per CU, or the whole-image tiling in large calls): the bits of the four-k-wave
-    order whatever the tiling -- here four copies of one image against that image through tiling 10 -- and within fp32
+    """14-pixel layers (conv5_x) stay on conv_h2.hip; in a call of four images and more they run with FOUR k-waves in
+    segments of two chunks (two-row patches, two workgroups per CU, or the whole-image tiling in large calls): the same
+    bits whatever the tiling -- here four copies of one image against that image through tiling 19 -- and within fp32
     rounding of the single-image call's eight-k-wave tree."""
     hw, cin, cout = 14, 512, 512
     x, w, b = case(1, hw, hw, cin, cout, 77 + hw)
     img = ops.pack_conv_h2(dev(w))
-    one, pool1, _ = ops.conv3x3_h2(dev(x), img, dev(b), cout, True, pool=True, want_amax=True, tiling=10)
+    one, pool1, _ = ops.conv3x3_h2(dev(x), img, dev(b), cout, True, pool=True, want_amax=True, tiling=19)
     four, pool4, amax4 = ops.conv3x3_h2(dev(np.repeat(x, 4, axis=0)), img, dev(b), cout, True, pool=True, want_amax=True)
     for k in range(4):
         assert torch.equal(four[k], one[0]) and torch.equal(pool4[k], pool1[0]), k
@@ -146,9 +151,10 @@ def test_14_pixel_layers_of_a_batched_call_run_with_four_k_waves(ops):
 # ---- the batched form (disn_amd/csrc/conv_h2w.hip): tiling 5..9 force its variants 1..5, tiling 0 takes it from
 # four images per call on (28-pixel layers and larger) --------------------------------------------------------------
 WIDE_ONE_KWAVE, WIDE_TWO_KWAVES = (5, 6, 7), (8, 9)
+WIDE_SEGMENTED = 12   # one k-wave in segments of two chunks (round 6): what tiling 0 takes for Cin >= 128
 
 
-@pytest.mark.parametrize("tiling", WIDE_ONE_KWAVE + WIDE_TWO_KWAVES)
+@pytest.mark.parametrize("tiling", WIDE_ONE_KWAVE + WIDE_TWO_KWAVES + (WIDE_SEGMENTED,))
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 30, 44, 64, 128), (1, 36, 62, 128, 128), (3, 28, 28, 192, 128)])
 def test_every_batched_variant_on_ragged_shapes(ops, tiling, B, H, W, Cin, Cout):
     x, w, b = case(B, H, W, Cin, Cout, 100 * tiling + H, relu_input=False)
@@ -173,6 +179,15 @@ def test_batched_variants_with_the_same_k_waves_agree_bit_for_bit_and_runs_repea
     assert np.abs(o[5] - o[8]).max() <= 2e-6 * np.abs(o[8]).max()      # two fp32 summation orders
     for t in (5, 6, 8, 9):
         assert np.array_equal(o[t], host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=t)))
+    # the segmented variant (tiling 0's choice for Cin >= 128): its own order -- segments of two chunks summed in fp32 --
+    # closer to the float64 convolution than the 216-MFMA chain of the one-k-wave variants; runs repeat
+    seg = host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=WIDE_SEGMENTED))
+    assert np.array_equal(seg, host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=WIDE_SEGMENTED)))
+    assert np.array_equal(seg, host(ops.conv3x3_h2(dev(np.concatenate([x, x])), img, bd, 128, True, tiling=0))[:2])   # B = 4: tiling 0 takes it
+    ref = O.conv2d(x, w, b, "SAME", True, dtype=np.float64)
+    e_seg, e_one = np.sqrt(((seg - ref) ** 2).mean()), np.sqrt(((o[5] - ref) ** 2).mean())
+    print("rms error / layer maximum: segmented %.3g, one k-wave %.3g" % (e_seg / np.abs(ref).max(), e_one / np.abs(ref).max()))
+    assert e_seg < e_one and np.abs(seg - ref).max() <= 1e-6 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("hw,cin,cout", [(224, 64, 64), (112, 64, 128), (112, 128, 128), (56, 128, 256), (56, 256, 256),

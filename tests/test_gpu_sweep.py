@@ -10,9 +10,10 @@ to a common binade by an exact power of two; `test_sweep_without_equalisation_fa
 kernels on the raw variables miss the bar on the hardest set, i.e. the sweep does exercise what it claims to.
 
 Two modes are run on every weight set: the DEFAULT (kernel forms by call size: calls of >= 4 requests take the batched
-convolutions and the fused small-set MLP -- 17 M points/s) and STRICT (disn_vgg_weights_t.strict_forms = 1, SdfEngine(strict=True):
-the single-image forms for every call size -- 10.7 M points/s; a request's taps bit for bit, its pred_sdf up to the fc head's
-form, those of the request alone).  Strict: every request <= 1e-5.  Default: see the comment at BAR_BATCHED_WORST.
+convolutions -- from round 6 in SEGMENTED accumulation, conv_h2w.hip's SEG form: chains of 54 MFMAs per accumulator, the
+segments summed in fp32 VALU adds -- and the fused small-set MLP) and STRICT (disn_vgg_weights_t.strict_forms = 1,
+SdfEngine(strict=True): the single-image forms for every call size; a request's taps, embedding and pred_sdf bit for bit
+those of the request alone).  EVERY request of EVERY form in EITHER mode: <= 1e-5.
 
 Default: 12 of the 48 weight sets (all of sigma = 2 for four seeds + one of every other (sigma, outlier) pair);
 DISN_SWEEP=full runs all 48 (profiles/r05*_sweep_full.json is that run).  The distribution is printed and, when
@@ -31,21 +32,12 @@ from oracle import disn_oracle as O
 
 pytestmark = pytest.mark.gpu
 BAR = 1e-5
-# What is asserted -- the measured distribution (profiles/r05k_sweep_full.json: 48 sets, 1104 default-mode + 960 strict-mode requests):
-#   * one request per call (conv_h2 / dense_h2) and the dense grid: EVERY case <= 1e-5 (measured <= 6.2e-6 / 8.4e-6);
-#   * the batched kernel forms (calls of 4 and of 16 requests): 90 % of the cases <= 1e-5 (measured p90 7.5e-6, median
-#     3.8e-6), at most 5 % above it (measured 26 of 960 = 2.7 %) and every case <= 1.5e-5 (measured 1.46e-5).  The cases
-#     above 1e-5 sit on four of the eight weight seeds, at every sigma -- the seeds on which the float32 CPU oracle is itself
-#     1.1-1.9e-5 from the float64 truth.  It is fp32 ACCUMULATION noise, not the operand split the equalisation repairs
-#     (the hardest set through the raw upload: 1.8e-3): conv_h2w sums K in chains of up to 432 MFMAs per accumulator where
-#     the single-image kernels' k-wave tree has 108 (tools/sweep_diag2.py: tap error 1.8-2x the single form's at every
-#     depth; tools/sweep_diag.py: the embedding computed from those taps carries two thirds of the difference), and shorter
-#     chains cost the batched form its speed (one or two k-waves per n-block is what made it fast) or a second
-#     accumulator set the 256-register two-workgroup variants do not have.
-#   north_star's bar reads "SDF values within 1e-5": the SDF value is pred_sdf / 10 (test/create_sdf.py:285), on which
-#   every case of every form is <= 1.5e-6; the tests hold the un-divided network output to it, ten times stricter.
-BAR_BATCHED_WORST = 1.5e-5
-BATCHED_FRACTION_ABOVE_BAR = 0.05
+# What is asserted: every case of every form <= BAR (1e-5 on the UN-divided network output; the SDF value is pred_sdf / 10,
+# test/create_sdf.py:285).  Measured over all 48 sets (profiles/r06e_sweep_full.json: 1104 default-mode + 960 strict-mode
+# requests): single <= 6.2e-6, grid <= 8.4e-6, calls of 4 / 16 requests <= 7.6e-6 / 9.8e-6 (median 2.7e-6, p90 5.1e-6),
+# strict <= 8.8e-6.  Until round 5 the batched convolutions summed K in chains of up to 432 MFMAs per accumulator and 2.7 %
+# of the batched requests sat at 1.0-1.46e-5 (profiles/r05k_sweep_full.json); tools/ubench/mfma_round.hip measures what a
+# chain costs (rms 6.2 ulp at 432 MFMAs, 0.9-1.0 ulp with a restart every 27-54) and conv_h2w.hip's SEG form is that restart.
 
 sys.path.insert(0, GOLDEN)
 import make_golden_sweep as MS   # noqa: E402
@@ -161,8 +153,7 @@ def test_sweep_within_the_bar_on_every_form():
         with open(os.path.join(od, "sweep_%s.json" % ("full" if len(rows) == len(MS.SETS) else "default")), "w") as f:
             json.dump({"summary": summary, "rows": rows}, f, indent=1)
     for f in ("batch4", "batch16"):
-        assert bf[f]["p90"] <= BAR and bf[f]["max"] <= BAR_BATCHED_WORST, json.dumps(bf[f])
-    assert (batched > BAR).mean() <= BATCHED_FRACTION_ABOVE_BAR
+        assert bf[f]["max"] <= BAR, json.dumps(bf[f])
     assert worst / 10.0 <= 2e-6          # the SDF values themselves (test/create_sdf.py:285 divides by SDF_WEIGHT = 10)
     # the GPU path is closer to the float64 truth than the reference's own fp32 arithmetic (the CPU oracle in float32)
     assert np.median([r["batch16"] for r in rows]) <= np.median([r["oracle32_minus_f64"] for r in rows])
@@ -189,5 +180,5 @@ def test_sweep_without_equalisation_fails_where_the_model_says():
         print("[parity sweep] set %d %s: worst max |gpu - f64| %.3g" % (i, "equalised" if eq else "raw variables", res[eq]))
         del eng
         torch.cuda.empty_cache()
-    assert res[True] <= BAR_BATCHED_WORST
+    assert res[True] <= BAR
     assert res[False] > 10.0 * res[True], "the raw upload was expected to lose precision on this set (measured: 1.8e-3)"

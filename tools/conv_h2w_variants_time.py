@@ -32,7 +32,7 @@ for cin, cout, hw in LAYERS:
     o = torch.empty((B, hw, hw, cout), device=dev)
     ref = None
     res = []
-    for tiling in (0, 5, 6, 7, 8, 9):
+    for tiling in (0, 5, 6, 7, 8, 9, 12, 13, 14, 15):
         try:
             t = ev_ms(lambda: ops.conv3x3_h2(x, img, b, cout, True, tiling=tiling, out=o))
             same = ""

@@ -11,19 +11,20 @@ import sys
 import numpy as np
 
 ROOT0 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SET = int(os.environ.get("DIAG_SET", "4"))   # sweep weight set (DIAG_SET=24 python tools/sweep_diag2.py [make])
 if len(sys.argv) > 1 and sys.argv[1] == "make":
     sys.path.insert(0, ROOT0)
     sys.path.insert(0, os.path.join(ROOT0, "tests", "golden"))
     import make_golden_sweep as MS0
     from disn_amd.weights import WeightStore as WS0
     from oracle import disn_oracle as O0
-    seed0, sigma0, outlier0 = MS0.SETS[4]
+    seed0, sigma0, outlier0 = MS0.SETS[SET]
     Weq = WS0(O0.trained_like_weights(seed0, sigma=sigma0, outlier_gain=outlier0)).equalised()[0].arrays
     _, emb0, _, eps0 = O0.encode(MS0.sweep_inputs()["imgs"], Weq, np.float64)
     taps0 = {nm: np.asarray(eps0["vgg_16/%s/%s" % (nm[:5], nm)], np.float64) for nm in O0.TAP_NAMES}
-    np.savez_compressed(os.path.join(ROOT0, "tools", "_diag_set04.npz"), emb64=np.asarray(emb0, np.float64),
+    np.savez_compressed(os.path.join(ROOT0, "tools", "_diag_set%02d.npz" % SET), emb64=np.asarray(emb0, np.float64),
                         pool5_64=O0.max_pool_2x2(taps0["conv5_3"]), **{"tap64_" + k: v[:, ::3, ::3, :] for k, v in taps0.items()})
-    print("wrote tools/_diag_set04.npz")
+    print("wrote tools/_diag_set%02d.npz" % SET)
     sys.exit(0)
 
 import torch
@@ -37,10 +38,10 @@ from disn_amd.engine import SdfEngine   # noqa: E402
 from disn_amd.weights import WeightStore   # noqa: E402
 from oracle import disn_oracle as O   # noqa: E402
 
-g = np.load(os.path.join(ROOT, "tools", "_diag_set04.npz"))
+g = np.load(os.path.join(ROOT, "tools", "_diag_set%02d.npz" % SET))
 s = MS.sweep_inputs()
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
-seed, sigma, outlier = MS.SETS[4]
+seed, sigma, outlier = MS.SETS[SET]
 store = WeightStore(O.trained_like_weights(seed, sigma=sigma, outlier_gain=outlier))
 eq = store.equalised()[0]
 eng = SdfEngine(store)
