@@ -705,7 +705,7 @@ def main():
             ms = ev_time_ms(lambda: ops.gather_taps(enc.taps, tm, p2k, feat2k), 20, torch)
             g["step_project_gather_taps_n2048"] = gline(
                 ms, N_POINTS * GATHER_BYTES_PER_PT,
-                "the gather of the timed step (hidden under fc6 on the auxiliary stream); 29 440 B/point convention; "
+                "the gather of ONE request (thread-per-float4 kernel: below 10 240 points per launch; hidden under fc6 on the auxiliary stream); 29 440 B/point convention; "
                 "it reads %d B/point of L2/MALL-resident tap pixels" % (94208 + 5888), "gather_taps_n2048")
             # (2) the dense grid's gather in the layer-by-layer path: gather_fold_kernel, 65 536 points of one
             #     chunk: 4 x 2 KB pmap rows + 2 KB pre-activation read + 2 KB written per point = 12 288 B/point
@@ -790,8 +790,17 @@ def main():
             ms_gather = ev_time_ms(lambda: ops.gather_taps_split(enc_nb.taps, tms_nb, pts_nb, amax_nb), 20, torch)
             ms_all = ev_time_ms(lambda: ops.query_taps_fused(eng.weights.mlp, enc_nb.taps, enc_nb.embedding, tms_nb, pts_nb), 20, torch)
             flop = nb * N_POINTS * MLP_FLOP_PER_PT
+            # the gather of a batched call (round 6: one wave per point, project_gather_taps_wave_kernel<split>), alone on the GPU
+            if isinstance(line.get("roofline_gather"), dict):
+                gb = nb * N_POINTS * GATHER_BYTES_PER_PT
+                line["roofline_gather"]["call_project_gather_taps_wave_%dx%d" % (nb, N_POINTS)] = {
+                    "ms": ms_gather, "algorithmic_bytes": gb, "achieved": gb / ms_gather / 1e6, "frac": gb / ms_gather / 1e6 / PEAK_HBM_GBS,
+                    "traffic": None,
+                    "note": "the gather of the timed call in split form [h8 | l8] (project_gather_taps_wave_kernel: one wave per point, "
+                            "duplicate tap rows / columns skipped by scalar branches; ~36 KB/point requested through L1 against the "
+                            "thread-per-float4 kernel's 100 KB; the same bits); 29 440 B/point convention; A/B: profiles/r06j_gather_ab.txt"}
             line["roofline_mlp_small"] = {
-                "kernel": "disn_query_taps_fused on the %d x %d points of one call: 5 x amax64 + tap_amax + project_gather_taps_kernel "
+                "kernel": "disn_query_taps_fused on the %d x %d points of one call: 5 x amax64 + tap_amax + project_gather_taps_wave_kernel "
                           "(split form) + mlp_fused_kernel<local, FEAT> + the global bias fold (split-K GEMV) + mlp_fused_kernel<global>" % (nb, N_POINTS),
                 "bound": "mfma", "ms": ms_all, "ms_gather_alone": ms_gather, "ms_mlp_without_gather": ms_all - ms_gather,
                 "achieved": 3.0 * flop / ms_all / 1e9, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
       chunk(c, T, T);
       if constexpr (SEG >= 2) chunk(c + 1, T, F);
       if constexpr (SEG >= 4) { chunk(c + 2, T, F); chunk(c + 3, T, F); }
-      if (c < 8) { CH2W_STAMP(4 + c); }
+      if (c / SEG < 8) { CH2W_STAMP(4 + c / SEG); }
     }
     if constexpr (SEG == 1) chunk(NC - 1, F, T);
     if constexpr (SEG == 2) { chunk(NC - 2, T, T); chunk(NC - 1, F, F); }

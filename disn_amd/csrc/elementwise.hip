@@ -503,6 +503,254 @@ __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Round 6: the same rows, ONE WAVE PER POINT (all five taps, models/model_normalization.py:171-190).  The kernel above
+// gives every (point, 4 channels) its own thread: 368 threads re-derive the point's projection, resampler weights and
+// tap coordinates, and each issues 16 tap loads -- 100 KB per point requested through L1 for 31 KB of distinct bytes
+// (r05i PMC), load-issue bound at 0.45-0.55 of the HBM roofline.  Here the projection and the five taps' geometry are
+// wave-uniform (computed once per point, the row / column offsets passed through readfirstlane so that the branches
+// below are scalar), a lane owns 4 channels, and a point is six passes of the wave:
+//     tap 4 channels 0..255 | 256..511, tap 3 the same, tap 2, then [tap 1 (lanes 0..31) | tap 0 (32..47) | the
+//     zero padding columns 1472 .. feat_ld - 1 (48..63)].
+// The resampler's four map pixels {ify, icy} x {ifx, icx} are up-sampled from the tap rows {ylo, yhi}(ify), {ylo,
+// yhi}(icy) and the same four columns; for the up-sampled taps (scale < 1: taps 1..4) the rows of icy are those of ify
+// (case a: 1 - s of the points), or start at ify's second row (case b) -- wave-uniform facts: duplicate rows and
+// columns are neither loaded nor interpolated twice.  4.4-5.8 loads per pass instead of 16 for taps 2..4 (expected,
+// s = 0.41 / 0.20 / 0.10), ~40 wave loads and 36 KB requested per point instead of 92 and 94 KB.  The arithmetic is the
+// kernel above's expression by expression (horizontal lerp of a row pair, vertical lerp, the resampler's weighted sum in
+// its order; this file is compiled with -ffp-contract=off): the SAME BITS (tests: both against the oracle bit for bit).
+// ---------------------------------------------------------------------------
+typedef float gf2 __attribute__((ext_vector_type(2)));
+struct GF4 { gf2 lo, hi; };   // a float4 as two packed pairs: v_pk_add_f32 / v_pk_mul_f32 (never fused: -ffp-contract=off)
+__device__ __forceinline__ GF4 gf4_load(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return GF4{gf2{v.x, v.y}, gf2{v.z, v.w}};
+}
+// a + (b - a) * t
+__device__ __forceinline__ GF4 gf4_lerp(const GF4& a, const GF4& b, float t) {
+  const gf2 tt{t, t};
+  return GF4{a.lo + (b.lo - a.lo) * tt, a.hi + (b.hi - a.hi) * tt};
+}
+__device__ __forceinline__ GF4 gf4_sel(bool c, const GF4& a, const GF4& b) { return c ? a : b; }
+
+struct TapGeom {
+  int roff[4], coff[4];   // floats: rows {ylo, yhi}(ify), {ylo, yhi}(icy); columns the same for ifx, icx
+  float xl[2], yl[2];
+};
+__device__ __forceinline__ TapGeom tap_geom(int hw, int ch, float s, int ify, int icy, int ifx, int icx) {
+  TapGeom g;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {   // (project_gather_taps_kernel<true>'s lines: clamped map pixel -> tap_pixel's coordinates)
+    const int oy = min(max(h ? icy : ify, 0), DISN_IMG - 1), ox = min(max(h ? icx : ifx, 0), DISN_IMG - 1);
+    const float ty = (float)oy * s, tx = (float)ox * s;
+    const int ylo = (int)floorf(ty), xlo = (int)floorf(tx);
+    const int yhi = min(ylo + 1, hw - 1), xhi = min(xlo + 1, hw - 1);
+    g.yl[h] = ty - (float)ylo;
+    g.xl[h] = tx - (float)xlo;
+    g.roff[2 * h] = ylo * hw * ch;
+    g.roff[2 * h + 1] = yhi * hw * ch;
+    g.coff[2 * h] = xlo * ch;
+    g.coff[2 * h + 1] = xhi * ch;
+  }
+  return g;
+}
+
+struct PointGeom {
+  float w_ff, w_cc, w_fc, w_cf;
+  bool ok, ff, cc, fc, cf;
+  int ify, icy, ifx, icx;
+};
+
+// the four up-sampled map pixels of this lane's 4 channels, then the resampler's sum.  RC / CC: how the tap rows (columns)
+// of the map's second row icy (column icx) relate to those of the first -- 0: the same two (case a), 1: they start at the
+// first pair's second row (case b: one new row), 2: two new rows (always right: duplicates are then loaded twice).
+template <int RC, int CC>
+__device__ __forceinline__ float4 tap_resample(const float* __restrict__ base, const TapGeom& g, const PointGeom& pg) {
+  constexpr bool rneed[4] = {true, true, RC == 2, RC != 0};
+  constexpr bool cneed[4] = {true, true, CC == 2, CC != 0};
+  GF4 T[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (rneed[r] && cneed[q]) T[r][q] = gf4_load(base + g.roff[r] + g.coff[q]);   // (every load before any use)
+  GF4 H[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (rneed[r]) {
+      H[r][0] = gf4_lerp(T[r][0], T[r][1], g.xl[0]);
+      H[r][1] = gf4_lerp(CC == 0 ? T[r][0] : (CC == 1 ? T[r][1] : T[r][2]), CC == 0 ? T[r][1] : T[r][3], g.xl[1]);
+    }
+  GF4 P[2][2];
+#pragma unroll
+  for (int hx = 0; hx < 2; ++hx) {
+    P[0][hx] = gf4_lerp(H[0][hx], H[1][hx], g.yl[0]);
+    P[1][hx] = gf4_lerp(RC == 0 ? H[0][hx] : (RC == 1 ? H[1][hx] : H[2][hx]), RC == 0 ? H[1][hx] : H[3][hx], g.yl[1]);
+  }
+  const gf2 z{0.f, 0.f};
+  // v = w_ff p_ff; v = v + w_cc p_cc; v = v + w_fc p_fc; v = v + w_cf p_cf   (sample4's order)
+  const gf2 wff{pg.w_ff, pg.w_ff}, wcc{pg.w_cc, pg.w_cc}, wfc{pg.w_fc, pg.w_fc}, wcf{pg.w_cf, pg.w_cf};
+  gf2 lo = wff * (pg.ff ? P[0][0].lo : z), hi = wff * (pg.ff ? P[0][0].hi : z);
+  lo = lo + wcc * (pg.cc ? P[1][1].lo : z);
+  hi = hi + wcc * (pg.cc ? P[1][1].hi : z);
+  lo = lo + wfc * (pg.fc ? P[1][0].lo : z);
+  hi = hi + wfc * (pg.fc ? P[1][0].hi : z);
+  lo = lo + wcf * (pg.cf ? P[0][1].lo : z);
+  hi = hi + wcf * (pg.cf ? P[0][1].hi : z);
+  return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+// wave-uniform offsets (scalar registers): the case by comparison, a scalar branch to one of nine straight-line bodies
+__device__ __forceinline__ float4 tap_resample_uniform(const float* __restrict__ base, const TapGeom& g, const PointGeom& pg) {
+  const int rc = g.roff[2] == g.roff[0] ? 0 : (g.roff[2] == g.roff[1] ? 1 : 2);
+  const int cc = g.coff[2] == g.coff[0] ? 0 : (g.coff[2] == g.coff[1] ? 1 : 2);
+  switch (rc * 3 + cc) {
+    case 0: return tap_resample<0, 0>(base, g, pg);
+    case 1: return tap_resample<0, 1>(base, g, pg);
+    case 2: return tap_resample<0, 2>(base, g, pg);
+    case 3: return tap_resample<1, 0>(base, g, pg);
+    case 4: return tap_resample<1, 1>(base, g, pg);
+    case 5: return tap_resample<1, 2>(base, g, pg);
+    case 6: return tap_resample<2, 0>(base, g, pg);
+    case 7: return tap_resample<2, 1>(base, g, pg);
+    default: return tap_resample<2, 2>(base, g, pg);
+  }
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void project_gather_taps_wave_kernel(TapSet t, const float* __restrict__ trans_mat,
+                                                                       const float* __restrict__ pts, int B, int n,
+                                                                       float* __restrict__ feat, int feat_ld,
+                                                                       float* __restrict__ amax, size_t amax_stride,
+                                                                       const float* __restrict__ split_amax) {
+  // amax != nullptr: gridDim.x = B * G, workgroup (b, iw) walks image b and stores the maximum |feat| it wrote at
+  // amax[b * amax_stride + iw] (every (b, iw) writes), as the kernel above
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  size_t pt, end, step;
+  int iw = 0, bimg = 0;
+  if (amax) {
+    const int G = gridDim.x / B;
+    bimg = blockIdx.x / G;
+    iw = blockIdx.x - bimg * G;
+    pt = (size_t)bimg * n + (size_t)iw * nw + wave;
+    end = (size_t)(bimg + 1) * n;
+    step = (size_t)G * nw;
+  } else {
+    pt = (size_t)blockIdx.x * nw + wave;
+    end = (size_t)B * n;
+    step = (size_t)gridDim.x * nw;
+  }
+  float vmax = 0.f;
+  auto emit = [&](size_t p, int b, int c, const float4& o) __attribute__((always_inline)) {
+    if (SPLIT) {   // (the kernel above's split store: lanes 2i, 2i + 1 are the halves of one 8-channel group)
+      const float sc = split_pow2_scale(feat_split_amax(split_amax[b]));
+      const float xs[4] = {o.x * sc, o.y * sc, o.z * sc, o.w * sc};
+      _Float16 hh[4], ll[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hh[e] = (_Float16)xs[e];
+        ll[e] = (_Float16)(xs[e] - (float)hh[e]);
+      }
+      const uint2 hv = *reinterpret_cast<const uint2*>(hh), lv = *reinterpret_cast<const uint2*>(ll);
+      const bool odd = (c & 4) != 0;
+      const uint2 send = odd ? hv : lv;
+      uint2 recv;
+      recv.x = (unsigned)__shfl_xor((int)send.x, 1);
+      recv.y = (unsigned)__shfl_xor((int)send.y, 1);
+      const uint4 out = odd ? make_uint4(recv.x, recv.y, lv.x, lv.y) : make_uint4(hv.x, hv.y, recv.x, recv.y);
+      unsigned char* row = reinterpret_cast<unsigned char*>(feat) + (p * (size_t)feat_ld + (size_t)(c & ~7)) * 4 + (odd ? 16 : 0);
+      *reinterpret_cast<uint4*>(row) = out;
+    } else {
+      *reinterpret_cast<float4*>(feat + p * feat_ld + c) = o;
+    }
+    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+  };
+  for (; pt < end; pt += step) {
+    const int b = (int)(pt / n);
+    float x, y;
+    project_point(trans_mat + (size_t)b * 12, pts[pt * 3], pts[pt * 3 + 1], pts[pt * 3 + 2], x, y);
+    PointGeom pg;
+    pg.ok = x > -1.0f && y > -1.0f && x < (float)DISN_IMG && y < (float)DISN_IMG;
+    {
+      const float fx = floorf(x), fy = floorf(y);
+      const float cx = fx + 1.0f, cy = fy + 1.0f;
+      const float dx = cx - x, dy = cy - y;
+      pg.ifx = (int)fx; pg.ify = (int)fy; pg.icx = (int)cx; pg.icy = (int)cy;
+      pg.w_ff = dx * dy;
+      pg.w_cc = (1.0f - dx) * (1.0f - dy);
+      pg.w_fc = dx * (1.0f - dy);
+      pg.w_cf = (1.0f - dx) * dy;
+      const bool xf = pg.ifx >= 0 && pg.ifx < DISN_IMG, xc = pg.icx >= 0 && pg.icx < DISN_IMG;
+      const bool yf = pg.ify >= 0 && pg.ify < DISN_IMG, yc = pg.icy >= 0 && pg.icy < DISN_IMG;
+      pg.ff = xf && yf; pg.cc = xc && yc; pg.fc = xf && yc; pg.cf = xc && yf;
+    }
+    // a NaN projection (degenerate camera) fails `ok`: zeros, as sample4.  The int conversions above are then unused.
+    const bool okw = __builtin_amdgcn_readfirstlane((int)pg.ok) != 0;
+    // ---- taps 4, 3 (two passes each), tap 2: wave-uniform geometry
+#pragma unroll 1
+    for (int k = 4; k >= 2; --k) {
+      const int hw = 224 >> k, ch = k == 2 ? 256 : 512, coff0 = k == 2 ? 192 : (k == 3 ? 448 : 960);
+      const float* tap = t.p[k] + (size_t)b * t.stride[k];
+      TapGeom g;
+      if (okw) {
+        g = tap_geom(hw, ch, t.s[k], pg.ify, pg.icy, pg.ifx, pg.icx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          g.roff[i] = __builtin_amdgcn_readfirstlane(g.roff[i]);
+          g.coff[i] = __builtin_amdgcn_readfirstlane(g.coff[i]);
+        }
+      }
+#pragma unroll 1
+      for (int half = 0; half < (k == 2 ? 1 : 2); ++half) {
+        const int cl = 4 * lane + 256 * half;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (okw) o = tap_resample_uniform(tap + cl, g, pg);
+        emit(pt, b, coff0 + cl, o);
+      }
+    }
+    // ---- tap 1 (lanes 0..31), tap 0 (32..47), padding columns (48..63): per-lane geometry, no skipping
+    {
+      const bool is1 = lane < 32, is0 = lane >= 32 && lane < 48;
+      const int cl = is1 ? 4 * lane : 4 * (lane - 32);
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (okw && (is1 || is0)) {
+        const TapGeom g1 = tap_geom(112, 128, t.s[1], pg.ify, pg.icy, pg.ifx, pg.icx);
+        const TapGeom g0 = tap_geom(224, 64, t.s[0], pg.ify, pg.icy, pg.ifx, pg.icx);
+        TapGeom g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          g.roff[i] = is1 ? g1.roff[i] : g0.roff[i];
+          g.coff[i] = is1 ? g1.coff[i] : g0.coff[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          g.xl[i] = is1 ? g1.xl[i] : g0.xl[i];
+          g.yl[i] = is1 ? g1.yl[i] : g0.yl[i];
+        }
+        const float* tap = (is1 ? t.p[1] + (size_t)b * t.stride[1] : t.p[0] + (size_t)b * t.stride[0]) + cl;
+        o = tap_resample<2, 2>(tap, g, pg);
+      }
+      const int c = is1 ? 64 + cl : (is0 ? cl : DISN_FEAT + 4 * (lane - 48));
+      if (is1 || is0) emit(pt, b, c, o);
+      else if (c < feat_ld) {
+        *reinterpret_cast<float4*>(feat + pt * feat_ld + c) = make_float4(0.f, 0.f, 0.f, 0.f);   // (zeros in either form)
+      }
+    }
+  }
+  if (amax) {
+    __shared__ float red[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    if (lane == 0) red[wave] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = 0.f;
+      for (int w = 0; w < nw; ++w) m = fmaxf(m, red[w]);
+      amax[(size_t)bimg * amax_stride + iw] = m;
+    }
+  }
+}
+
 // workgroups per image of the launch with maxima (1024 threads each) -- the count of entries the consumer reads.
 // All five taps: up to 448 entries (the free tail of an image's slot set, api.hip); a tap RANGE (the two gathers of a
 // batched call: taps 0..3 behind conv4_3, tap 4 behind conv5_3): up to 224, the two launches' entries side by side.
@@ -530,19 +778,39 @@ hipError_t project_gather_taps_launch(const float* const taps[5], const float* t
     t.stride[k] = (size_t)(224 >> k) * (224 >> k) * ch[k];
   }
   if (feat_ld <= 0) feat_ld = DISN_FEAT;
+  // all five taps into rows of 1472 .. 1536 floats, from 10 240 points on: one wave per point (round 6; the SAME BITS, so
+  // the choice is free).  Its six passes per point are six dependent memory round trips: below ~5 x 2048 points, where
+  // the chip is not filled with waves anyway, the thread-per-float4 kernel's 368 independent threads per point win
+  // (profiles/r06j_gather_ab.txt: 1 x 2048 points 14 against 35 us, 4 x 2048 44 / 49, 8 x 2048 85 / 70, 16 x 2048 174 / 123).
+  // tune::gather_l16 != 0 (tuning builds) forces the thread-per-float4 kernel: 1 its all-loads-first schedule, 2 the default one
+  if (tap_begin == 0 && tap_end == 5 && feat_ld >= DISN_FEAT && feat_ld <= DISN_FEAT + 64 && feat_ld % 4 == 0 && tune::gather_l16 == 0 &&
+      (size_t)B * n >= 10240) {
+    if (amax) {
+      int G = project_gather_taps_amax_blocks(n, feat_ld, tap_begin, tap_end);
+      if (amax_cap > 0 && G > amax_cap) G = amax_cap;
+      if (split_amax) hipLaunchKernelGGL(project_gather_taps_wave_kernel<true>, dim3((unsigned)(B * G)), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax);
+      else hipLaunchKernelGGL(project_gather_taps_wave_kernel<false>, dim3((unsigned)(B * G)), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax);
+    } else {
+      const size_t npt = (size_t)B * n;
+      const unsigned grid = (unsigned)((npt + 3) / 4 < 32768 ? (npt + 3) / 4 : 32768);
+      if (split_amax) hipLaunchKernelGGL(project_gather_taps_wave_kernel<true>, dim3(grid), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax);
+      else hipLaunchKernelGGL(project_gather_taps_wave_kernel<false>, dim3(grid), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax);
+    }
+    return hipGetLastError();
+  }
   const int c4_begin = c4_off[tap_begin];
   const int c4_count = (tap_end == 5 && feat_ld > DISN_FEAT ? feat_ld / 4 : c4_off[tap_end]) - c4_begin;
   const size_t total = (size_t)B * n * c4_count;
   if (amax) {
     int G = project_gather_taps_amax_blocks(n, feat_ld, tap_begin, tap_end);
     if (amax_cap > 0 && G > amax_cap) G = amax_cap;   // entries the caller has room for
-    if (tune::gather_l16) hipLaunchKernelGGL(project_gather_taps_kernel<true>, dim3((unsigned)(B * G)), dim3(1024), 0, st, t, trans_mat, pts, B, n,
+    if (tune::gather_l16 == 1) hipLaunchKernelGGL(project_gather_taps_kernel<true>, dim3((unsigned)(B * G)), dim3(1024), 0, st, t, trans_mat, pts, B, n,
                        c4_begin, c4_count, feat, feat_ld, amax, amax_stride, split_amax);
     else hipLaunchKernelGGL(project_gather_taps_kernel<false>, dim3((unsigned)(B * G)), dim3(1024), 0, st, t, trans_mat, pts, B, n,
                        c4_begin, c4_count, feat, feat_ld, amax, amax_stride, split_amax);
     return hipGetLastError();
   }
-  if (tune::gather_l16) hipLaunchKernelGGL(project_gather_taps_kernel<true>, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
+  if (tune::gather_l16 == 1) hipLaunchKernelGGL(project_gather_taps_kernel<true>, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
                      trans_mat, pts, B, n, c4_begin, c4_count, feat, feat_ld, amax, amax_stride, split_amax);
   else hipLaunchKernelGGL(project_gather_taps_kernel<false>, dim3(grid_for(total, 16384)), dim3(256), 0, st, t,
                      trans_mat, pts, B, n, c4_begin, c4_count, feat, feat_ld, amax, amax_stride, split_amax);

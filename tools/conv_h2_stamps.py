@@ -19,6 +19,9 @@ if os.environ.get("KNOB"):
         k, v = kv.split("=")
         _tuning.set_knob(k, int(v))
 LAYERS = [(64, 64, 224), (128, 128, 112), (256, 256, 56), (512, 512, 28), (512, 512, 14)]
+if os.environ.get("LAYERS"):   # LAYERS=256x256x56,512x512x28 (cin x cout x hw)
+    LAYERS = [tuple(int(v) for v in l.split("x")) for l in os.environ["LAYERS"].split(",")]
+TILING = int(os.environ.get("TILING", "0"))   # disn_conv3x3_h2 tiling (12: the segmented batched variant -- STAMP_CK=32: a stamp per segment)
 NAMES = ["setup", "prologue(load+split+barrier)"] + ["chunk%d" % i for i in range(8)] + ["last chunk", "k-reduce", "epilogue"]
 for cin, cout, hw in LAYERS:
     x = torch.rand((1, hw, hw, cin), device=dev).repeat(B, 1, 1, 1)
@@ -28,10 +31,10 @@ for cin, cout, hw in LAYERS:
     o = torch.empty((B, hw, hw, cout), device=dev)
     stamps = torch.zeros((65536, 16), dtype=torch.int64, device=dev)   # one row per workgroup
     for _ in range(3):
-        ops.conv3x3_h2(x, img, b, cout, True, out=o)
+        ops.conv3x3_h2(x, img, b, cout, True, out=o, tiling=TILING)
     torch.cuda.synchronize()
     h.disn_tuning_set_ptr(0, stamps.data_ptr())
-    ops.conv3x3_h2(x, img, b, cout, True, out=o)
+    ops.conv3x3_h2(x, img, b, cout, True, out=o, tiling=TILING)
     torch.cuda.synchronize()
     h.disn_tuning_set_ptr(0, None)
     s = stamps.cpu().numpy()
