@@ -110,7 +110,7 @@ inline int exp_of(float v) {  // floor(log2(v)) of a positive normal float
 }
 
 // column factors of W [rows][cols] (already row-scaled): c[f] as above; returns log2 of the largest factor
-float eq_factors(const float* w, long rows, int cols, std::vector<float>& c) {
+float eq_factors(const float* w, const float* bias, long rows, int cols, std::vector<float>& c) {
   std::vector<float> m(cols, 0.f);
   for (long r = 0; r < rows; ++r) {
     const float* p = w + r * cols;
@@ -132,12 +132,19 @@ float eq_factors(const float* w, long rows, int cols, std::vector<float>& c) {
   const float med = nz[nz.size() / 2];
   if (med < 1e-30f) return 0.f;
   const int eM = exp_of(med);
+  // an UP-scaled column takes its bias along: b c must stay within the layer's largest bias (a nearly dead
+  // column with an ordinary bias, scaled up by 2^16, would set the image's activation scale -- the other channels of
+  // the two-term f16 kernels would lose ~13 bits to it)
+  float bmax = 0.f;
+  for (int f = 0; f < cols; ++f)
+    if (std::isfinite(bias[f])) bmax = std::fmax(bmax, std::fabs(bias[f]));
   int dmin = 0, dmax = 0;
   for (int f = 0; f < cols; ++f) {
     if (!std::isfinite(m[f])) continue;
     const float mf = std::fmax(m[f], std::ldexp(med, -16));
     int d = eM - exp_of(mf);  // <= 16; negative for columns above the median
     if (d < -100) d = -100;
+    while (d > 0 && std::fabs(bias[f]) * std::ldexp(1.0f, d) > bmax) --d;
     c[f] = std::ldexp(1.0f, d);
     dmin = d < dmin ? d : dmin;
     dmax = d > dmax ? d : dmax;
@@ -174,7 +181,7 @@ extern "C" int disn_equalise_weights(const disn_eq_weights_t* w, float* tap_scal
   std::vector<float> c;
   for (int i = 0; i < 13; ++i) {
     const int ci = kEqConvCin[i], co = kEqConvCout[i];
-    const float span = eq_factors(w->conv_w[i], 9L * ci, co, c);
+    const float span = eq_factors(w->conv_w[i], w->conv_b[i], 9L * ci, co, c);
     if (span_log2) span_log2[i] = span;
     scale_cols(w->conv_w[i], 9L * ci, co, c);
     for (int f = 0; f < co; ++f) w->conv_b[i][f] *= c[f];
@@ -190,7 +197,7 @@ extern "C" int disn_equalise_weights(const disn_eq_weights_t* w, float* tap_scal
     const int k4 = s == 0 ? 512 + w->num_classes : 1984;
     for (int l = 0; l < 5; ++l) {   // fold1/conv1 .. fold2/conv2 produce hidden channels; fold2/conv5 is the output
       const int ci = l == 3 ? k4 : kEqMlpCin[l], co = kEqMlpCout[l];
-      const float span = eq_factors(w->mlp_w[s][l], ci, co, c);
+      const float span = eq_factors(w->mlp_w[s][l], w->mlp_b[s][l], ci, co, c);
       if (span_log2) span_log2[13 + 5 * s + l] = span;
       scale_cols(w->mlp_w[s][l], ci, co, c);
       for (int f = 0; f < co; ++f) w->mlp_b[s][l][f] *= c[f];

@@ -154,6 +154,9 @@ class Encoded:
     pred: Optional[torch.Tensor] = None   # pred_sdf of the run that produced this state (encode_query)
     pmap: Optional[dict] = None           # image index -> [137*137,512] folded feature map (SdfEngine.pmap_of)
     pmap_amax: Optional[dict] = None      # image index -> max |pmap| (1-element tensor; the fused kernels' bound)
+    units: str = "true"                   # "equalised": taps / featmap carry the engine's power-of-two channel factors
+                                          # (DeviceWeights.tap_scale; SdfEngine.true_taps / true_features convert);
+                                          # "true": the reference's end_points magnitudes
 
 
 class SdfEngine:
@@ -215,6 +218,9 @@ class SdfEngine:
 
     # equalised <-> true units (DeviceWeights(equalise=True): Encoded.taps / .featmap and everything gathered from them
     # carry the power-of-two channel factors weights.tap_scale; identity copies for an engine built with equalise=False)
+    def _units(self) -> str:
+        return "equalised" if self.weights.status.get("equalised") else "true"
+
     def true_taps(self, enc: "Encoded") -> List[torch.Tensor]:
         """the five taps in the reference's units (end_points of slim vgg_16: models/model_normalization.py:76-78)"""
         with torch.cuda.device(self.device):
@@ -242,7 +248,7 @@ class SdfEngine:
             from ._lib import lib
             ws = self._workspace("vgg", lib().disn_encode_workspace_bytes(imgs.shape[0]))
             resized, taps, emb, featmap = ops.encode(self._ctx, self._vgg, imgs, ws)
-        return Encoded(resized, taps, emb, featmap)
+        return Encoded(resized, taps, emb, featmap, units=self._units())
 
     # rows A..H in one call: what ONE sess.run([pred_sdf]) of the reference executes
     def featmap_of(self, enc: Encoded) -> torch.Tensor:
@@ -286,7 +292,7 @@ class SdfEngine:
             ws = self._workspace("encq", lib().disn_encode_query_workspace_bytes(pts.shape[0], pts.shape[1]))
             resized, taps, emb, featmap, sdf = ops.encode_query(self._ctx, self._vgg, self.weights.mlp,
                                                                 imgs, trans_mat, pts, pts_rot, ws, keep_featmap)
-        return Encoded(resized, taps, emb, featmap), sdf
+        return Encoded(resized, taps, emb, featmap, units=self._units()), sdf
 
     # rows D, F, G, H
     def query(self, enc: Encoded, pts, trans_mat, pts_rot=None, fold: Optional[bool] = None,
@@ -606,7 +612,7 @@ class StepPipeline:
                 for k in idx:
                     b = jobs[k][0].shape[0]
                     if keep_encoded:
-                        e = Encoded(enc.resized[o:o + b], [t[o:o + b] for t in enc.taps], enc.embedding[o:o + b], None)
+                        e = Encoded(enc.resized[o:o + b], [t[o:o + b] for t in enc.taps], enc.embedding[o:o + b], None, units=enc.units)
                         out[k] = (e, sdf[o:o + b])
                     else:
                         out[k] = sdf[o:o + b]
@@ -636,7 +642,7 @@ class StepPipeline:
                         o = 0
                         for k in idx:
                             b = jobs[k][0].shape[0]
-                            out[k] = (Encoded(enc.resized[o:o + b], [t[o:o + b] for t in enc.taps], enc.embedding[o:o + b], None),
+                            out[k] = (Encoded(enc.resized[o:o + b], [t[o:o + b] for t in enc.taps], enc.embedding[o:o + b], None, units=enc.units),
                                       sdf[o:o + b]) if keep_encoded else sdf[o:o + b]
                             o += b
                         prev = rec

@@ -414,11 +414,20 @@ int disn_encode(disn_ctx_t* ctx, const disn_vgg_weights_t* w, const float* img, 
  *               (B >= 4, N % 128 == 0; disn_dense_h2's rule); otherwise (a feature map asked for at N >= 8192; more than
  *               512 requests of a few points each) the three-term bf16 / f32-input GEMM chain of disn_dense.  disn_query /
  *               disn_sdf_mlp switch at the same N = 8192 per image.
- *   convolutions / fc head  B < 4: conv_h2.hip + one-launch fc rows; B >= 4: conv_h2w.hip + the split-K fc stream
- *               with up to sixteen batch rows per pass on the fp32 matrix pipe (gemv_mfma_kernel; disn_conv3x3_h2's rule).
+ *   convolutions / fc head  B < 4: conv_h2.hip + one-launch fc rows; B >= 4: conv_h2w.hip (conv2_2 .. conv4_3 and the
+ *               14 x 14 layers in SEGMENTED accumulation, round 6: disn_conv3x3_h2's rule) + the split-K fc stream with up
+ *               to sixteen batch rows per pass on the fp32 matrix pipe (gemv_mfma_kernel).
+ *   gather      from 10 240 points per call on: one wave per point (project_gather_taps_wave_kernel); below: one thread per
+ *               (point, four channels).  The SAME bits (the arithmetic is one expression tree; elementwise.hip).
  *   strict mode  vw->strict_forms == 1 (zero-initialise disn_vgg_weights_t: 0 is the default): the B < 4 forms of ALL of the
  *               above for any B -- request b's taps, embedding and sdf are then bit for bit those
  *               of a B = 1 call (tests/test_gpu_model.py::test_strict_mode_runs_the_single_image_forms); see the struct.
+ *               Not needed for the 1e-5 bar since round 6 (every form holds it on the 48-set sweep); it buys reproducible
+ *               bits across call sizes at ~65 % of the throughput.  Where it does NOT reach: (1) the point MLP
+ *               of a call in single-stream mode (ctx == NULL) or with B > 512 falls to the three-term GEMM chain over B * N
+ *               rows, whose split-K plan depends on B * N; (2) disn_query / disn_query_folded / disn_query_fused take no
+ *               vgg struct: their per-image global-bias fold runs the batched fc form from B >= 4 on -- the same encoder
+ *               state queried at B = 1 and at B = 4 gives pred_sdf equal to fp32 rounding (<= 1.2e-6), not bit for bit.
  * Every activation scale is per image (per point inside the fused kernels) on all of these paths, so request b's
  * outputs never depend on the other requests of its call, on its position, or on B beyond the thresholds above (B < 4:
  * bit for bit those of a B = 1 call; B >= 4: bit for bit those of any other call of >= 4 requests of the same N). */

@@ -265,14 +265,26 @@ def test_equalised_weights_are_the_same_network():
 
 def test_equalisation_does_not_blow_up_a_dead_column():
     """a hidden channel whose weight column is 2^-40 of its neighbours' (a dead feature with an ordinary bias) is scaled
-    up by at most 2^16: its bias must not become the tensor's maximum (ADVICE r4 on the fused images, same rule here)"""
+    up only as far as its bias allows: b c stays within the layer's largest bias (ADVICE r5 -- scaled by the full 2^16
+    it would set the image's activation scale and cost every other channel of the two-term kernels ~13 bits); with a
+    zero bias the cap is 2^16"""
     from disn_amd.weights import WeightStore
     st = WeightStore.random_init(1, mode="he")
     w = st.arrays["vgg_16/conv3/conv3_2/weights"]
     w[:, :, :, 7] *= np.float32(2.0 ** -40)
     eq, ts, span = st.equalised()
-    c7 = eq.arrays["vgg_16/conv3/conv3_2/biases"][7] / st.arrays["vgg_16/conv3/conv3_2/biases"][7]
-    assert c7 == 2.0 ** 16
+    b = st.arrays["vgg_16/conv3/conv3_2/biases"]
+    c7 = eq.arrays["vgg_16/conv3/conv3_2/biases"][7] / b[7]
+    assert 1.0 <= c7 <= 2.0 ** 16 and np.frexp(c7)[0] == 0.5
+    assert abs(b[7]) * c7 <= np.abs(b).max() and (c7 == 2.0 ** 16 or abs(b[7]) * 2 * c7 > np.abs(b).max())
+    st = WeightStore.random_init(1, mode="he")
+    st.arrays["vgg_16/conv3/conv3_2/weights"][:, :, :, 7] *= np.float32(2.0 ** -40)
+    st.arrays["vgg_16/conv3/conv3_2/biases"][7] = 0.0
+    eq, ts, span = st.equalised()
+    w0, w1 = st.arrays["vgg_16/conv3/conv3_2/weights"][..., 7], eq.arrays["vgg_16/conv3/conv3_2/weights"][..., 7]
+    # (the column also carries the inverse factors of conv3_1's channels on its rows: compare one row's ratio with a neighbour column's)
+    r7 = (w1 / w0)[0, 0, :] / (eq.arrays["vgg_16/conv3/conv3_2/weights"][..., 8] / st.arrays["vgg_16/conv3/conv3_2/weights"][..., 8])[0, 0, :]
+    assert np.all(np.isfinite(r7)) and np.log2(r7.max()) >= 10
     nxt = eq.arrays["vgg_16/conv3/conv3_3/weights"][:, :, 7, :] * np.float32(2.0 ** 16)
     ref = st.arrays["vgg_16/conv3/conv3_3/weights"][:, :, 7, :]
     c_out = eq.arrays["vgg_16/conv3/conv3_3/biases"] / st.arrays["vgg_16/conv3/conv3_3/biases"]
