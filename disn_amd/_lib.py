@@ -14,7 +14,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # DISN_AMD_LIB: tools/ only -- points the binding at a tuning build (csrc/build.py --tuning), never set by the product
 LIB_PATH = os.environ.get("DISN_AMD_LIB") or os.path.join(HERE, "csrc", "libdisn_amd.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -87,6 +87,7 @@ SIGNATURES = {
     "disn_conv3x3_x3": (I, [P, I, I, I, I, P, P, I, I, P, P, Z, P]),
     "disn_pack_conv_h2_bytes": (Z, [I, I]),
     "disn_pack_conv_h2": (I, [P, I, I, P, P]),
+    "disn_conv_h2_gain_span": (I, [P, I, I, P, P]),
     "disn_conv1_1_workspace_bytes": (Z, []),
     "disn_conv1_1": (I, [P, I, I, I, P, P, I, P, P, P, Z, P]),
     "disn_conv3x3_h2_workspace_bytes": (Z, [I]),

@@ -950,6 +950,26 @@ int disn_pack_conv_h2(const float* w_hwio, int Cin, int Cout, void* image, void*
   return e == hipSuccess ? 0 : (int)e;
 }
 
+int disn_conv_h2_gain_span(const void* image, int Cin, int Cout, float* span_log2, void* stream) {
+  if (!image || !span_log2 || Cin <= 0 || Cout <= 0 || Cout > 4096) return DISN_E_ARG;
+  if (Cin % 64 || Cout % 64) return DISN_E_SHAPE;
+  // the image's tail: inv_sw[Cout], then the column maxima cmax[Cout] the pack measured (what the scales came from)
+  float inv[4096];
+  hipError_t e = hipMemcpyAsync(inv, static_cast<const unsigned char*>(image) + (size_t)Cin * 9 * Cout * 4 + (size_t)Cout * 4,
+                                (size_t)Cout * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  float lo = 0.f, hi = 0.f;
+  for (int f = 0; f < Cout; ++f) {
+    const float v = inv[f];
+    if (!(v > 0.f) || !(v < 3.0e38f)) continue;   // an all-zero column has no gain
+    if (lo == 0.f || v < lo) lo = v;
+    if (v > hi) hi = v;
+  }
+  *span_log2 = lo > 0.f ? log2f(hi / lo) : 0.f;
+  return *span_log2 > 12.0f ? DISN_W_GAIN_SPAN : 0;
+}
+
 size_t disn_conv3x3_h2_workspace_bytes(int B) { return B > 0 ? (size_t)B * 512 : 0; }
 
 int disn_conv3x3_h2(const float* in, int B, int H, int W, int Cin, const void* image, const float* bias, int Cout,

@@ -31,7 +31,9 @@ class DeviceWeights:
         two-term f16 kernels needs on trained weights: DESIGN 4k).  Taps, the feature map and gathered features of an
         engine built this way are in equalised units; ``tap_scale`` [1472] converts (SdfEngine.true_taps /
         true_features / internal_features; the model_normalization surface does it for its end_points).
-        ``status``: what was done -- {'equalised', 'channel_gain_span_log2' (per layer), 'max_span_log2'}."""
+        ``status``: what was done -- {'equalised', 'channel_gain_span_log2' (per layer, BEFORE equalisation),
+        'max_span_log2', 'packed_gain_span_log2' (per two-term conv image, of what was packed), 'gain_span_warnings'
+        (layers whose packed span exceeds 12 binades: only with equalise=False on a checkpoint that needed it)}."""
         if not store.complete():
             raise ValueError("WeightStore is incomplete")
         self.device = device
@@ -59,7 +61,13 @@ class DeviceWeights:
             if ci != 3:   # three-term bf16 image: same fp32 accuracy on the 16x faster bf16 MFMA pipes
                 v.conv_w_x3[i] = self._hold(ops.pack_kn_x3(wd)).data_ptr()
             if conv_h2:   # single-image kernels (conv_h2.hip): two-term f16 image; conv1_1: the TF tensor as is
-                v.conv_w_h2[i] = (wd if ci == 3 else self._hold(ops.pack_conv_h2(wd))).data_ptr()
+                img_h2 = wd if ci == 3 else self._hold(ops.pack_conv_h2(wd))
+                v.conv_w_h2[i] = img_h2.data_ptr()
+                if ci != 3:   # the accuracy contract's guard (disn_conv_h2_gain_span): the span of what was ACTUALLY packed
+                    sp, warned = ops.conv_h2_gain_span(img_h2, ci, co)
+                    self.status.setdefault("packed_gain_span_log2", []).append(sp)
+                    if warned:
+                        self.status.setdefault("gain_span_warnings", []).append(nm)
             v.conv_b[i] = dev(store[nm + "/biases"]).data_ptr()
         for i, nm in enumerate(("fc6", "fc7", "fc8")):
             w = store["vgg_16/%s/weights" % nm]

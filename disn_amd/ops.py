@@ -130,6 +130,15 @@ def pack_conv_h2(w_hwio: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def conv_h2_gain_span(image: torch.Tensor, cin: int, cout: int):
+    """disn_conv_h2_gain_span -> (span_log2, warned): the channel-gain span of the variable a conv_h2 image was packed from"""
+    span = C.c_float(0.0)
+    rc = lib().disn_conv_h2_gain_span(image.data_ptr(), int(cin), int(cout), C.byref(span), _stream())
+    if rc not in (0, 1):
+        check("disn_conv_h2_gain_span", rc)
+    return float(span.value), rc == 1
+
+
 def conv3x3_h2(x: torch.Tensor, image: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool = True,
                pool: bool = False, want_amax: bool = False, tiling: int = 0,
                out: Optional[torch.Tensor] = None):

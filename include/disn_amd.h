@@ -38,7 +38,7 @@ extern "C" {
 #define DISN_E_WS (-3)    /* workspace too small */
 
 /* ABI version of this header; disn_abi_version() returns the library's. */
-#define DISN_ABI_VERSION 9
+#define DISN_ABI_VERSION 10
 int disn_abi_version(void);
 
 /* ---------------------------------------------------------------------- *
@@ -98,6 +98,14 @@ int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w
  * ws: disn_conv3x3_h2_workspace_bytes(B). */
 size_t disn_pack_conv_h2_bytes(int Cin, int Cout);
 int disn_pack_conv_h2(const float* w_hwio, int Cin, int Cout, void* image, void* stream);
+/* Round 6 (ABI 10) -- the accuracy contract's guard: log2 of (largest / smallest non-zero) per-output-channel weight
+ * scale of a packed image, i.e. the channel-gain span of the variable it was packed from, into *span_log2 (HOST float;
+ * the call synchronises `stream`).  Returns 0, or DISN_W_GAIN_SPAN (= 1, a WARNING: the image is usable) when the span
+ * exceeds 12 binades -- the activations the layer produces then span as much, and the NEXT layer's two-term split (one
+ * power-of-two scale per image, ~22 bits) starves its small channels: pack the variables through
+ * disn_equalise_weights first (an equalised checkpoint reports <= 2). */
+#define DISN_W_GAIN_SPAN 1
+int disn_conv_h2_gain_span(const void* image, int Cin, int Cout, float* span_log2, void* stream);
 /* conv1_1 (3 -> 64 channels; models/CNN/vgg.py:187) as a direct fp32 FMA convolution: w_hwio is the TF tensor
  * [3][3][3][64] as is; optional out_amax = max |out|.  ws: disn_conv1_1_workspace_bytes(). */
 size_t disn_conv1_1_workspace_bytes(void);

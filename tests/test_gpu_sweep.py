@@ -174,6 +174,9 @@ def test_sweep_without_equalisation_fails_where_the_model_says():
     for eq in (False, True):
         eng = SdfEngine(store, equalise=eq)
         assert eng.weights.status["equalised"] is eq
+        # the C ABI's guard (disn_conv_h2_gain_span): the raw upload is flagged, the equalised one is clean
+        assert bool(eng.weights.status.get("gain_span_warnings")) is (not eq), eng.weights.status.get("packed_gain_span_log2")
+        assert max(eng.weights.status["packed_gain_span_log2"]) <= (3.0 if eq else 64.0)
         forms, grid = _forms(eng, s, dev)
         e = _errors(forms, grid, gold, i)
         res[eq] = max(max(v) for v in e.values())

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, name), "library does not export %s" % name
     from disn_amd import _lib
     assert set(_lib.SIGNATURES) == declared, (set(_lib.SIGNATURES) ^ declared)
-    assert _lib.lib().disn_abi_version() == _lib.ABI_VERSION == 9
+    assert _lib.lib().disn_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_code_object_targets_gfx950():
