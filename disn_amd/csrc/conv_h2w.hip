@@ -186,9 +186,17 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
 #pragma unroll
       for (int r = 0; r < 8; ++r) tot[mb][r] = f2v{0.f, 0.f};
   }
+  // (the finished segment sits in accumulation registers -- the 256 arch VGPRs are taken by tot, the A ring and the loader --
+  // and VALU cannot read those: two v_accvgpr_read + one v_pk_add_f32 per register pair, written out so that the compiler
+  // keeps tot in arch VGPRs instead of shuttling it through the accumulation file around every add)
   auto flush = [&](int mb) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) tot[mb][r] += f2v{acc[mb][2 * r], acc[mb][2 * r + 1]};
+    for (int r = 0; r < 8; ++r) {
+      f2v t;
+      asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t[0]) : "a"(acc[mb][2 * r]));
+      asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t[1]) : "a"(acc[mb][2 * r + 1]));
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(tot[mb][r]) : "v"(t));
+    }
   };
 
 #pragma unroll
