@@ -326,6 +326,28 @@ def dry_run(args, torch, dist, world, rank, launched):
         dist.destroy_process_group()
 
 
+
+def _accuracy_of_the_timed_mode(strict: bool, sb: int):
+    """north_star's tolerance for the kernel FORMS the main line times, from the committed full sweep of this round
+    (tests/test_gpu_sweep.py with DISN_SWEEP=full on a GPU box -> profiles/r06n_sweep_full.json: 48 trained-like weight
+    sets x 8 images, max |pred_sdf - float64 oracle| per request); the line's own three-set spot check of the same
+    forms on this box is cpu_baseline.parity_trained_like.sweep"""
+    out = {"bar": 1e-5, "on": "pred_sdf (the un-divided network output; the SDF value is pred_sdf / 10)",
+           "timed_forms": ("strict: the single-image forms for every call size" if strict else
+                           ("batched forms (calls of >= 4 requests): segmented convolutions, matrix-pipe fc head, fused small-set MLP"
+                            if sb >= 4 else "single-image forms (calls of < 4 requests)"))}
+    try:
+        sw = json.load(open(os.path.join(ROOT, "profiles", "r06n_sweep_full.json")))["summary"]
+        bf = sw["by_form"]
+        forms = ("strict4", "strict16") if strict else (("batch4", "batch16") if sb >= 4 else ("single",))
+        out.update({"sweep_worst_of_the_timed_forms": max(bf[f]["max"] for f in forms),
+                    "sweep_requests": sum(bf[f]["n"] for f in forms), "sweep_sets": sw["sets"],
+                    "sweep_worst_of_every_form": sw["worst"], "within_bar": max(bf[f]["max"] for f in forms) <= 1e-5,
+                    "source": "profiles/r06n_sweep_full.json (tests/test_gpu_sweep.py, DISN_SWEEP=full; asserts <= bar for every form)"})
+    except Exception as e:   # the committed file is the evidence; its absence must not cost the line
+        out["sweep"] = "profiles/r06n_sweep_full.json not readable: %r" % (e,)
+    return out
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -543,6 +565,7 @@ def main():
         "dtype": "f32 results (products: two-term f16 split on v_mfma_f32_32x32x16_f16, ~22-bit operands, fp32 accumulate; "
                  "gather / projection / resize / fc: fp32 FMA)",
         "data": "synthetic", "steps_per_call": SB, "calls_in_flight": S,
+        "accuracy": _accuracy_of_the_timed_mode(args.strict, SB),
         "config": {"workload": "BASELINE config 2: VGG-16 encode + 2048 random query points, img_feat_twostream, "
                                "fp32, random-init (xavier) weights, nothing cached between steps" + (
                                    " [--strict: single-image convolution kernels for every call size]" if args.strict else ""),
@@ -663,6 +686,15 @@ def main():
                                                  "against the dense f16 MFMA peak (MI355X_MICROARCH.md: 2.5 PFLOP/s)",
                                 "algorithmic_tflops": alg_tflops,
                                 "frac_of_f32_mfma_peak": alg_tflops / PEAK_FP32_MFMA_TFLOPS,
+                                "sustained_mfma_ceiling": {
+                                    "pure_mfma_tflops": 1690.0, "with_operand_reads_tflops": 1500.0,
+                                    "frac_of_sustained": exec_tflops / 1500.0,
+                                    "note": "measured on this part (tools/ubench/mfma_f16_rate.hip, profiles/r06i_mfma_f16_rate.txt): a kernel that "
+                                            "issues NOTHING but back-to-back v_mfma_f32_32x32x16_f16 on random operands, every CU, 1 or 2 waves "
+                                            "per SIMD, sustains 1.69 PFLOP/s = 0.68 of the 2.5 PFLOP/s data-sheet peak (DVFS: the clock drops "
+                                            "under matrix load), and 1.50 PFLOP/s = 0.60 with the convolutions' operand traffic beside it (two "
+                                            "ds_read_b128 per MFMA triple).  `frac` above stays priced against the data-sheet peak; "
+                                            "frac_of_sustained is the same executed rate against what the silicon delivers to a pure MFMA+LDS stream"},
                                 "traffic": traffic,
                                 "traffic_measured_on": pmc.get("build"),
                                 "traffic_note": "memory-side bytes per call of the 13 conv launches (FETCH_SIZE x2 + calibrated "
@@ -1044,7 +1076,7 @@ def main():
                                       "worst": max(errs["single"] + errs["batch16"]), "bar": 1e-5,
                                       "equalised_weights": True,
                                       "reference": "tests/golden/stress_sweep.npz (float64 oracle); the full sweep: "
-                                                   "tests/test_gpu_sweep.py, profiles/r05*_sweep_*.json"}
+                                                   "tests/test_gpu_sweep.py, profiles/r06n_sweep_full.json"}
                 parity_tl["worst"] = max(parity_tl["worst"], parity_tl["sweep"]["worst"])
             except Exception as e:
                 parity_tl = {"error": repr(e)} if parity_tl is None else dict(parity_tl, sweep_error=repr(e))

@@ -513,9 +513,14 @@ __global__ __launch_bounds__(64 * WK * NW, OCC == 1 ? 1 : OCC * WK * NW / 4) voi
           const int sidx = t * MB + mb;
           if (sidx + AH < S) rd(sidx + AH);
           const bool f = FIRST && t == 0;
-          if (f) {
+          if (f) {   // (accumulation registers -> arch VGPR pair -> v_pk_add_f32, as conv_h2w.hip's flush)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) tot[mb][r] += f2v{acc[mb][2 * r], acc[mb][2 * r + 1]};
+            for (int r = 0; r < 8; ++r) {
+              f2v tt;
+              asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(tt[0]) : "a"(acc[mb][2 * r]));
+              asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(tt[1]) : "a"(acc[mb][2 * r + 1]));
+              asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(tot[mb][r]) : "v"(tt));
+            }
           }
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[sidx % NBR], bh, f ? zero16 : acc[mb], 0, 0, 0);
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[sidx % NBR], bl, acc[mb], 0, 0, 0);

@@ -30,6 +30,8 @@ def test_default_line_contract():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["unit"] == "points/s" and d["value"] > 1e5
     assert "workload" in d["config"]
+    # the timed forms' accuracy rides on the line: the committed 48-set sweep's worst for the forms that ran
+    assert d["accuracy"]["within_bar"] is True and d["accuracy"]["sweep_worst_of_the_timed_forms"] <= d["accuracy"]["bar"] == 1e-5
 
 
 @pytest.mark.parametrize("exchange", ["all_to_all", "all_gather"])
