@@ -414,8 +414,11 @@ bool fused_small_ok(const disn_mlp_weights_t* w, int B, int N) {
 int fused_small_local(const disn_mlp_weights_t* w, float* const taps[5], const float* const tap_slots[5],
                       size_t slot_stride, const float* trans_mat, const float* pts, const float* pts_rot, int B, int N,
                       float* feat_split, float* featmax, float* lsum, hipStream_t st) {
-  DISN_TRY(tap_amax_launch(tap_slots, slot_stride, B, featmax, st));
-  DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, feat_split, st, kFeatPad, nullptr, 0, 0, featmax));
+  // (the one-wave-per-point gather takes the images' tap maxima from the slots itself and leaves them in featmax)
+  const bool slots_in_gather = project_gather_taps_takes_slots(B, N, kFeatPad);
+  if (!slots_in_gather) DISN_TRY(tap_amax_launch(tap_slots, slot_stride, B, featmax, st));
+  DISN_TRY(project_gather_taps_launch(taps, trans_mat, pts, B, N, 0, 5, feat_split, st, kFeatPad, nullptr, 0, 0, featmax,
+                                      slots_in_gather ? tap_slots : nullptr, slot_stride));
   DISN_TRY(mlp_fused_small_launch(true, w->l_feat, w->l_w1, w->l_b1, w->l_b2, w->l_b3, w->l_b4, w->l_b5, w->l_w6, w->l_b6,
                                   pts_rot, N, B, feat_split, kFeatPad, featmax, nullptr, lsum, 1.0f, st));
   return 0;

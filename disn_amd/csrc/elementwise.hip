@@ -520,6 +520,7 @@ __global__ __launch_bounds__(1024) void project_gather_taps_kernel(TapSet t,
 // kernel above's expression by expression (horizontal lerp of a row pair, vertical lerp, the resampler's weighted sum in
 // its order; this file is compiled with -ffp-contract=off): the SAME BITS (tests: both against the oracle bit for bit).
 // ---------------------------------------------------------------------------
+struct GatherSlots { const float* p[5]; size_t stride; float* out; };   // see project_gather_taps_wave_kernel
 typedef float gf2 __attribute__((ext_vector_type(2)));
 struct GF4 { gf2 lo, hi; };   // a float4 as two packed pairs: v_pk_add_f32 / v_pk_mul_f32 (never fused: -ffp-contract=off)
 __device__ __forceinline__ GF4 gf4_load(const float* p) {
@@ -621,9 +622,12 @@ __global__ __launch_bounds__(256) void project_gather_taps_wave_kernel(TapSet t,
                                                                        const float* __restrict__ pts, int B, int n,
                                                                        float* __restrict__ feat, int feat_ld,
                                                                        float* __restrict__ amax, size_t amax_stride,
-                                                                       const float* __restrict__ split_amax) {
+                                                                       const float* __restrict__ split_amax, GatherSlots slots) {
   // amax != nullptr: gridDim.x = B * G, workgroup (b, iw) walks image b and stores the maximum |feat| it wrote at
-  // amax[b * amax_stride + iw] (every (b, iw) writes), as the kernel above
+  // amax[b * amax_stride + iw] (every (b, iw) writes), as the kernel above.
+  // slots.p[0] != nullptr (SPLIT): the image's tap maximum is taken HERE from its 5 x 64 activation-maximum slots (five
+  // loads and a wave maximum per point: what tap_amax_kernel did in a launch of its own on the call's critical path) and
+  // published by the image's first point in slots.out[b] for the fused kernel behind
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   size_t pt, end, step;
@@ -641,9 +645,10 @@ __global__ __launch_bounds__(256) void project_gather_taps_wave_kernel(TapSet t,
     step = (size_t)gridDim.x * nw;
   }
   float vmax = 0.f;
+  float img_amax = 0.f;
   auto emit = [&](size_t p, int b, int c, const float4& o) __attribute__((always_inline)) {
     if (SPLIT) {   // (the kernel above's split store: lanes 2i, 2i + 1 are the halves of one 8-channel group)
-      const float sc = split_pow2_scale(feat_split_amax(split_amax[b]));
+      const float sc = split_pow2_scale(feat_split_amax(img_amax));
       const float xs[4] = {o.x * sc, o.y * sc, o.z * sc, o.w * sc};
       _Float16 hh[4], ll[4];
 #pragma unroll
@@ -667,6 +672,19 @@ __global__ __launch_bounds__(256) void project_gather_taps_wave_kernel(TapSet t,
   };
   for (; pt < end; pt += step) {
     const int b = (int)(pt / n);
+    if (SPLIT) {
+      if (slots.p[0]) {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) m = fmaxf(m, slots.p[k][(size_t)b * slots.stride + lane]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        img_amax = m;
+        if (lane == 0 && pt == (size_t)b * n) slots.out[b] = m;
+      } else {
+        img_amax = split_amax[b];
+      }
+    }
     float x, y;
     project_point(trans_mat + (size_t)b * 12, pts[pt * 3], pts[pt * 3 + 1], pts[pt * 3 + 2], x, y);
     PointGeom pg;
@@ -751,6 +769,11 @@ __global__ __launch_bounds__(256) void project_gather_taps_wave_kernel(TapSet t,
   }
 }
 
+bool project_gather_taps_takes_slots(int B, int n, int feat_ld) {
+  if (feat_ld <= 0) feat_ld = DISN_FEAT;
+  return feat_ld >= DISN_FEAT && feat_ld <= DISN_FEAT + 64 && feat_ld % 4 == 0 && tune::gather_l16 == 0 && (size_t)B * n >= 10240;
+}
+
 // workgroups per image of the launch with maxima (1024 threads each) -- the count of entries the consumer reads.
 // All five taps: up to 448 entries (the free tail of an image's slot set, api.hip); a tap RANGE (the two gathers of a
 // batched call: taps 0..3 behind conv4_3, tap 4 behind conv5_3): up to 224, the two launches' entries side by side.
@@ -768,7 +791,8 @@ int project_gather_taps_amax_blocks(int n, int feat_ld, int tap_begin, int tap_e
 hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
                                       const float* pts, int B, int n, int tap_begin, int tap_end,
                                       float* feat, hipStream_t st, int feat_ld, float* amax,
-                                      size_t amax_stride, int amax_cap, const float* split_amax) {
+                                      size_t amax_stride, int amax_cap, const float* split_amax,
+                                      const float* const* tap_slots, size_t slot_stride) {
   static const int c4_off[6] = {0, 16, 48, 112, 240, DISN_FEAT4};
   static const int ch[5] = {64, 128, 256, 512, 512};
   TapSet t;
@@ -783,18 +807,23 @@ hipError_t project_gather_taps_launch(const float* const taps[5], const float* t
   // the chip is not filled with waves anyway, the thread-per-float4 kernel's 368 independent threads per point win
   // (profiles/r06j_gather_ab.txt: 1 x 2048 points 14 against 35 us, 4 x 2048 44 / 49, 8 x 2048 85 / 70, 16 x 2048 174 / 123).
   // tune::gather_l16 != 0 (tuning builds) forces the thread-per-float4 kernel: 1 its all-loads-first schedule, 2 the default one
-  if (tap_begin == 0 && tap_end == 5 && feat_ld >= DISN_FEAT && feat_ld <= DISN_FEAT + 64 && feat_ld % 4 == 0 && tune::gather_l16 == 0 &&
-      (size_t)B * n >= 10240) {
+  if (tap_begin == 0 && tap_end == 5 && project_gather_taps_takes_slots(B, n, feat_ld)) {
+    GatherSlots gs{};
+    if (tap_slots && split_amax) {
+      for (int k = 0; k < 5; ++k) gs.p[k] = tap_slots[k];
+      gs.stride = slot_stride;
+      gs.out = const_cast<float*>(split_amax);
+    }
     if (amax) {
       int G = project_gather_taps_amax_blocks(n, feat_ld, tap_begin, tap_end);
       if (amax_cap > 0 && G > amax_cap) G = amax_cap;
-      if (split_amax) hipLaunchKernelGGL(project_gather_taps_wave_kernel<true>, dim3((unsigned)(B * G)), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax);
-      else hipLaunchKernelGGL(project_gather_taps_wave_kernel<false>, dim3((unsigned)(B * G)), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax);
+      if (split_amax) hipLaunchKernelGGL(project_gather_taps_wave_kernel<true>, dim3((unsigned)(B * G)), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax, gs);
+      else hipLaunchKernelGGL(project_gather_taps_wave_kernel<false>, dim3((unsigned)(B * G)), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax, gs);
     } else {
       const size_t npt = (size_t)B * n;
       const unsigned grid = (unsigned)((npt + 3) / 4 < 32768 ? (npt + 3) / 4 : 32768);
-      if (split_amax) hipLaunchKernelGGL(project_gather_taps_wave_kernel<true>, dim3(grid), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax);
-      else hipLaunchKernelGGL(project_gather_taps_wave_kernel<false>, dim3(grid), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax);
+      if (split_amax) hipLaunchKernelGGL(project_gather_taps_wave_kernel<true>, dim3(grid), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax, gs);
+      else hipLaunchKernelGGL(project_gather_taps_wave_kernel<false>, dim3(grid), dim3(256), 0, st, t, trans_mat, pts, B, n, feat, feat_ld, amax, amax_stride, split_amax, gs);
     }
     return hipGetLastError();
   }

@@ -132,7 +132,13 @@ hipError_t project_gather_launch(const float* featmap_b, const float* trans_mat_
 hipError_t project_gather_taps_launch(const float* const taps[5], const float* trans_mat,
                                       const float* pts, int B, int n, int tap_begin, int tap_end,
                                       float* feat, hipStream_t st, int feat_ld = 0, float* amax = nullptr,
-                                      size_t amax_stride = 0, int amax_cap = 0, const float* split_amax = nullptr);
+                                      size_t amax_stride = 0, int amax_cap = 0, const float* split_amax = nullptr,
+                                      const float* const* tap_slots = nullptr, size_t slot_stride = 0);
+// tap_slots != nullptr (with split_amax, from 10 240 points on -- the one-wave-per-point kernel): image b's 64 activation-
+// maximum slots of tap k at tap_slots[k] + b * slot_stride.  The kernel then takes the image's maximum over the 5 x 64
+// slots ITSELF and writes it to split_amax[b] (an OUTPUT then: what tap_amax_launch would have produced, for the fused
+// kernel behind) -- no tap_amax launch in front of the gather.
+bool project_gather_taps_takes_slots(int B, int n, int feat_ld);   // whether that form runs for this shape (else: tap_amax_launch first)
 // split_amax != nullptr ([B] floats, >= max |tap| of each image): rows in SPLIT form (two f16 planes of feature * the
 // image's power-of-two scale, [h8 | l8] per 8 channels) -- the operand of mlp_fused_small_launch(local)
 // amax != nullptr (all five taps): max |feat| per workgroup at amax[b * amax_stride + (0 .. blocks - 1)]
