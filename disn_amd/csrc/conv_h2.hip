@@ -891,7 +891,7 @@ hipError_t conv_h2_launch(const float* in, int B, int H, int W, int Cin, const v
     if ((long)B * (Cout / 32) >= 200) return conv_h2_go<7, 1, 16, 14, 3, 4, 1, 2>(d, st);
     return conv_h2_go<1, 1, 16, 14, 3, 4, 2, 2>(d, st);
   }
-  if (cfg >= 5) return conv_h2w_supported(H, W, Cin, Cout) ? conv_h2w_launch(d, st, cfg == 12 ? 6 : cfg - 4) : hipErrorInvalidValue;
+  if (cfg >= 5) return conv_h2w_supported(H, W, Cin, Cout) ? conv_h2w_launch(d, st, cfg >= 12 ? cfg - 6 : cfg - 4) : hipErrorInvalidValue;
   if (!strict && cfg == 0 && B >= tune::conv_wide_min && conv_h2w_supported(H, W, Cin, Cout)) return conv_h2w_launch(d, st, fast ? -1 : 0);
   if (cfg == 0) {
     // patch shape by image width; n-blocks per workgroup so that one image still gives >= ~200 workgroups
@@ -981,11 +981,11 @@ int disn_conv3x3_h2(const float* in, int B, int H, int W, int Cin, const void* i
                     int relu, float* out, float* pool_out, float* out_amax, int tiling, void* ws, size_t ws_bytes,
                     void* stream) {
   if (!in || !image || !bias || !out || !ws || B <= 0 || H <= 0 || W <= 0) return DISN_E_ARG;
-  if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 19 || (tiling >= 13 && tiling <= 17) || (pool_out && ((H | W) & 1)))
+  if (!disn::conv_h2_supported(H, W, Cin, Cout) || tiling < 0 || tiling > 19 || (tiling >= 14 && tiling <= 17) || (pool_out && ((H | W) & 1)))
     return DISN_E_SHAPE;
-  if (((tiling >= 5 && tiling <= 9) || tiling == 12) && !disn::conv_h2w_supported(H, W, Cin, Cout)) return DISN_E_SHAPE;
+  if (((tiling >= 5 && tiling <= 9) || tiling == 12 || tiling == 13) && !disn::conv_h2w_supported(H, W, Cin, Cout)) return DISN_E_SHAPE;
   if ((tiling == 6 || tiling == 8 || tiling == 12) && Cout % 128) return DISN_E_SHAPE;   // four n-waves = 128 channels per workgroup
-  if (tiling == 12 && Cin % 32) return DISN_E_SHAPE;                                        // whole segments of two chunks
+  if ((tiling == 12 || tiling == 13) && (Cin % 64 || Cin < 128)) return DISN_E_SHAPE;       // two K halves of whole segments
   if (tiling == 19 && (H > 14 || W > 14 || Cin % 128)) return DISN_E_SHAPE;
   if (tiling == 10 && (H > 14 || W > 14)) return DISN_E_SHAPE;
   if (ws_bytes < (size_t)B * 512) return DISN_E_WS;

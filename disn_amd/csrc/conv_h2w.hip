@@ -52,7 +52,10 @@ constexpr int w_row_bytes(int raw) {  // smallest size >= raw that is 128 (mod 2
 
 // MB row blocks per wave, MWV m-waves x NWV n-waves x WK k-waves per workgroup, patch TH x TW (= 32 MB MWV pixels),
 // OCC workgroups per CU the register budget is cut for
-template <int MB, int MWV, int NWV, int WK, int TH, int TW, int OCC, int SEG = 0>
+// PARK (WK == 1, SEG == 2): the TWO-K-HALVES order of the two-k-wave segmented variant in ONE k-wave -- the even k16 blocks
+// first (p0: what k-wave 0 of <.., WK = 2, .., SEG = 2> sums), that total parked in LDS, then the odd blocks (p1), p0 + p1:
+// bit for bit the two-k-wave variant's result with four n-waves per halo instead of two (large calls), see conv_h2w_launch
+template <int MB, int MWV, int NWV, int WK, int TH, int TW, int OCC, int SEG = 0, bool PARK = false>
 __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4) void conv_h2w_kernel(const ConvH2Dev P) {
   constexpr int NWAVES = MWV * NWV * WK, NT = 64 * NWAVES;
   constexpr int CK = 16 * WK;              // input channels per chunk: one k16 block per k-wave
@@ -66,7 +69,9 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   constexpr int WPR = TW / 2;              // windows per patch row pair
   constexpr int D = 3;                     // weight pairs in flight per wave (taps ahead)
   constexpr int XCH = WK == 2 ? MWV * NWV * MB * 4096 : 0;
-  constexpr int LDS_BYTES = 2 * BUF > XCH ? 2 * BUF : XCH;
+  constexpr int PARKB = PARK ? NWAVES * MB * 4096 : 0;   // the parked p0 of every wave, behind the halo buffers
+  static_assert(!PARK || (WK == 1 && SEG == 2), "PARK: one k-wave in segments of two chunks");
+  constexpr int LDS_BYTES = PARK ? 2 * BUF + PARKB : (2 * BUF > XCH ? 2 * BUF : XCH);
   static_assert(TH * TW == 32 * MB * MWV && TH % 2 == 0 && TW % 2 == 0, "patch = whole row blocks of 2x2 windows");
   static_assert(WK == 1 || WK == 2, "k-waves");
   static_assert(LDS_BYTES * OCC <= 160 * 1024, "LDS");
@@ -97,6 +102,8 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   const int H = P.H, W = P.W, Cin = P.Cin, Cout = P.Cout;
   const int NC = Cin / CK;
   const float* inb = P.in + (size_t)b * H * W * Cin;
+  // chunk i of the walk -> k16 block: i itself, or (PARK) the even blocks, then the odd ones
+  auto blk = [&](int i) __attribute__((always_inline)) { return PARK ? (i < (NC >> 1) ? 2 * i : 2 * (i - (NC >> 1)) + 1) : i; };
 
   // ---- halo loader: unit u = (halo pixel, float4 of the chunk's CK channels).  Every load is unconditional and
   // every loaded value is used (an out-of-image unit reads a valid address and is ANDed with 0): no exec-mask
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   }
   auto load_chunk = [&](int c, float4 (&ra)[LP]) {
 #pragma unroll
-    for (int k = 0; k < LP; ++k) ra[k] = *reinterpret_cast<const float4*>(inb + goff[k] + CK * c);
+    for (int k = 0; k < LP; ++k) ra[k] = *reinterpret_cast<const float4*>(inb + goff[k] + CK * blk(c));
   };
   float sa = 1.0f;
   auto store_unit = [&](int buf, const float4 (&ra)[LP], int k) {
@@ -189,6 +196,8 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   // (the finished segment sits in accumulation registers -- the 256 arch VGPRs are taken by tot, the A ring and the loader --
   // and VALU cannot read those: two v_accvgpr_read + one v_pk_add_f32 per register pair, written out so that the compiler
   // keeps tot in arch VGPRs instead of shuttling it through the accumulation file around every add)
+  bool park_now = false;   // PARK: wave-uniform, true in the first chunk of the second K half
+  auto park_at = [&](int mb, int r) __attribute__((always_inline)) { return 2 * BUF + (((wave * MB + mb) * 8 + r) * 64 + lane) * 8; };
   auto flush = [&](int mb) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -196,6 +205,13 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
       asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t[0]) : "a"(acc[mb][2 * r]));
       asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t[1]) : "a"(acc[mb][2 * r + 1]));
       asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(tot[mb][r]) : "v"(t));
+    }
+    if (PARK && park_now) {   // p0 = the first half's total: parked, the second half starts from zero
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        *reinterpret_cast<f2v*>(&lds[park_at(mb, r)]) = tot[mb][r];
+        tot[mb][r] = f2v{0.f, 0.f};
+      }
     }
   };
 
@@ -231,7 +247,8 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
     int ab[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) ab[mb] = arow[mb] + (c & 1) * BUF;
-    const unsigned char* wcur = wp + (size_t)c * kChunkStride;
+    const unsigned char* wcur = wp + (size_t)blk(c) * kChunkStride;
+    const unsigned char* wnxt = wp + (size_t)blk(c + 1) * kChunkStride;   // (not dereferenced behind the last chunk)
     ch_h8 ah[NB], al[NB];
     auto rd = [&](int s) {
       const int t = s / MB, mb = s % MB;
@@ -285,7 +302,7 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
       for (int t = t0; t <= (s1 < S ? t1 : t0); ++t) {
         const int last = (t + 1) * MB - 1;
         if ((last == s0 || (last == s1 && s1 < S)) && (MORE || t + D < 9)) {
-          const unsigned char* wa = wcur + ((t + D) / 9) * kChunkStride + (size_t)((t + D) % 9) * 2048;
+          const unsigned char* wa = (t + D < 9 ? wcur : wnxt) + (size_t)((t + D) % 9) * 2048;
           qh[t % D] = *reinterpret_cast<const ch_h8*>(wa);
           ql[t % D] = *reinterpret_cast<const ch_h8*>(wa + 1024);
         }
@@ -310,19 +327,22 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
     constexpr std::false_type F{};
 #pragma unroll 1
     for (int c = 0; c + SEG < NC; c += SEG) {
+      if (PARK) park_now = 2 * c == NC;
       chunk(c, T, T);
       if constexpr (SEG >= 2) chunk(c + 1, T, F);
       if constexpr (SEG >= 4) { chunk(c + 2, T, F); chunk(c + 3, T, F); }
       if (c / SEG < 8) { CH2W_STAMP(4 + c / SEG); }
     }
     if constexpr (SEG == 1) chunk(NC - 1, F, T);
+    if (PARK) park_now = false;   // (NC >= 8: the second half starts inside the loop above)
     if constexpr (SEG == 2) { chunk(NC - 2, T, T); chunk(NC - 1, F, F); }
     if constexpr (SEG == 4) { chunk(NC - 4, T, T); chunk(NC - 3, T, F); chunk(NC - 2, T, F); chunk(NC - 1, F, F); }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const f2v t = tot[mb][r] + f2v{acc[mb][2 * r], acc[mb][2 * r + 1]};
+        f2v t = tot[mb][r] + f2v{acc[mb][2 * r], acc[mb][2 * r + 1]};
+        if (PARK) t = *reinterpret_cast<const f2v*>(&lds[park_at(mb, r)]) + t;   // p0 + p1
         acc[mb][2 * r] = t[0];
         acc[mb][2 * r + 1] = t[1];
       }
@@ -429,13 +449,14 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   CH2W_STAMP(14);
 }
 
-template <int MB, int MWV, int NWV, int WK, int TH, int TW, int OCC, int SEG = 0>
+template <int MB, int MWV, int NWV, int WK, int TH, int TW, int OCC, int SEG = 0, bool PARK = false>
 static hipError_t conv_h2w_go(ConvH2Dev d, hipStream_t st) {
   if (SEG > 0 && (d.Cin / (16 * WK)) % SEG != 0) return hipErrorInvalidValue;   // whole segments only
+  if (PARK && (d.Cin % 64 != 0 || d.Cin < 128)) return hipErrorInvalidValue;    // two halves of whole segments, the second one starting inside the loop
   d.tiles_x = (d.W + TW - 1) / TW;
   d.tiles_y = (d.H + TH - 1) / TH;
   const int grid = d.B * d.tiles_x * d.tiles_y * (d.Cout / (32 * NWV));
-  hipLaunchKernelGGL((conv_h2w_kernel<MB, MWV, NWV, WK, TH, TW, OCC, SEG>), dim3(grid), dim3(64 * MWV * NWV * WK), 0, st, d);
+  hipLaunchKernelGGL((conv_h2w_kernel<MB, MWV, NWV, WK, TH, TW, OCC, SEG, PARK>), dim3(grid), dim3(64 * MWV * NWV * WK), 0, st, d);
   return hipGetLastError();
 }
 
@@ -462,7 +483,13 @@ hipError_t conv_h2w_launch(ConvH2Dev d, hipStream_t st, int variant) {
   // take the SEGMENTED form -- chains of 54, the segments summed in fp32 -- whatever the batch; conv1_2 / conv2_1
   // (Cin = 64: chains of 108 as they are) the round-3 variants below.  variant -1 (the training step): round 3's
   // selection for every layer (chains of up to 432: faster at 4 .. 11 images per call, 1.7 x the error)
-  if (variant == 0 && d.Cin >= 128 && d.Cout % 128 == 0) variant = 6;
+  if (variant == 0 && d.Cin >= 128 && d.Cout % 128 == 0) {
+    // two K halves (even / odd k16 blocks), each in segments of two chunks, p0 + p1: as two k-waves over 64-channel
+    // workgroups (variant 7) while that is what fills the chip, as ONE k-wave that parks p0 in LDS (variant 6: four n-waves
+    // per halo, half the loader work per MFMA) from ~200 128-channel workgroups on -- the same bits
+    const long wg128 = (long)d.B * ((d.H + 7) / 8) * ((d.W + 27) / 28) * (d.Cout / 128);
+    variant = wg128 >= 200 ? 6 : 7;
+  }
   if (variant == 0 || variant == -1) {
     const int wk = conv_h2w_kwaves(d.H, d.W, d.Cin, d.Cout);
     if (wk == 1) {
@@ -482,7 +509,8 @@ hipError_t conv_h2w_launch(ConvH2Dev d, hipStream_t st, int variant) {
     case 3: return conv_h2w_go<7, 1, 2, 1, 8, 28, 2>(d, st);
     case 4: return conv_h2w_go<7, 1, 4, 2, 8, 28, 1>(d, st);
     case 5: return conv_h2w_go<7, 1, 2, 2, 8, 28, 1>(d, st);
-    case 6: return conv_h2w_go<7, 1, 4, 1, 8, 28, 1, 2>(d, st);
+    case 6: return conv_h2w_go<7, 1, 4, 1, 8, 28, 1, 2, true>(d, st);
+    case 7: return conv_h2w_go<7, 1, 2, 2, 8, 28, 1, 2>(d, st);
     default: return hipErrorInvalidValue;
   }
 }

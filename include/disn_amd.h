@@ -80,12 +80,15 @@ int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w
  * force variant 1..5 of the BATCHED form (conv_h2w.hip: waves own 32-channel n-blocks of 128..224-pixel patches and
  * walk K sequentially; variants 1..3 one k-wave, 4..5 two; H*W >= 784), 10 = the whole-image tiling of layers of at
  * most 14 x 14 pixels (one workgroup per image and 32-channel block, four k-waves), 11 = by shape, single-image form
- * whatever B (what disn_vgg_weights_t.strict_forms = 1 runs), 12 = the SEGMENTED batched variant (round 6: one k-wave whose
- * accumulators restart every two 16-channel chunks -- chains of 54 MFMAs -- the finished segments summed in fp32 VALU adds;
- * Cout % 128 == 0), 18 = round 3's batched selection by shape and batch (one or two k-waves, chains of up to 432: what the
- * training step runs), 19 = tiling 10 in segments of two 64-channel chunks (Cin % 128 == 0).
+ * whatever B (what disn_vgg_weights_t.strict_forms = 1 runs), 12 / 13 = the SEGMENTED batched variants (round 6: the k16
+ * blocks in two halves -- even, odd --, each half in segments of two 16-channel chunks -- chains of 54 MFMAs -- whose
+ * finished sums are added in fp32 VALU adds, p0 + p1 at the end; 13: two k-waves over 64-channel workgroups, 12: ONE k-wave
+ * that parks p0 in LDS, 128-channel workgroups, Cout % 128 == 0; the SAME bits; Cin % 64 == 0, Cin >= 128), 18 = round 3's
+ * batched selection by shape and batch (one or two k-waves, chains of up to 432: what the training step runs), 19 = tiling
+ * 10 in segments of two 64-channel chunks (Cin % 128 == 0).
  * SELECTION RULE of tiling 0 (also inside disn_vgg16_* / disn_encode*): calls of B >= 4 images take, by LAYER SHAPE only,
- *   - layers of 28 x 28 pixels and more with Cin >= 128 (conv2_2 .. conv4_3): the segmented batched variant (12);
+ *   - layers of 28 x 28 pixels and more with Cin >= 128 (conv2_2 .. conv4_3): the segmented batched variants (13 while
+ *     that is what fills the chip, 12 from ~200 128-channel workgroups on: the same bits);
  *   - layers of 28 x 28 pixels and more with Cin = 64 (conv1_2, conv2_1): the one-k-wave batched form (chains of 108);
  *   - the 14 x 14 layers: four k-waves in segments of two chunks (19 where B * Cout / 32 >= 200, two-row patches below:
  *     same bits);

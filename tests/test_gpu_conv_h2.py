@@ -151,12 +151,14 @@ def test_14_pixel_layers_of_a_batched_call_run_with_four_k_waves(ops):
 # ---- the batched form (disn_amd/csrc/conv_h2w.hip): tiling 5..9 force its variants 1..5, tiling 0 takes it from
 # four images per call on (28-pixel layers and larger) --------------------------------------------------------------
 WIDE_ONE_KWAVE, WIDE_TWO_KWAVES = (5, 6, 7), (8, 9)
-WIDE_SEGMENTED = 12   # one k-wave in segments of two chunks (round 6): what tiling 0 takes for Cin >= 128
+WIDE_SEGMENTED = (12, 13)   # two K halves in segments of two chunks (round 6; one k-wave + LDS park | two k-waves): what tiling 0 takes for Cin >= 128
 
 
-@pytest.mark.parametrize("tiling", WIDE_ONE_KWAVE + WIDE_TWO_KWAVES + (WIDE_SEGMENTED,))
+@pytest.mark.parametrize("tiling", WIDE_ONE_KWAVE + WIDE_TWO_KWAVES + WIDE_SEGMENTED)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 30, 44, 64, 128), (1, 36, 62, 128, 128), (3, 28, 28, 192, 128)])
 def test_every_batched_variant_on_ragged_shapes(ops, tiling, B, H, W, Cin, Cout):
+    if tiling in WIDE_SEGMENTED and Cin < 128:
+        pytest.skip("the segmented variants need two K halves of whole segments (Cin >= 128)")
     x, w, b = case(B, H, W, Cin, Cout, 100 * tiling + H, relu_input=False)
     ref = O.conv2d(x, w, b, "SAME", False, dtype=np.float64)
     out, pooled, amax = ops.conv3x3_h2(dev(x), ops.pack_conv_h2(dev(w)), dev(b), Cout, False, pool=True,
@@ -181,8 +183,9 @@ def test_batched_variants_with_the_same_k_waves_agree_bit_for_bit_and_runs_repea
         assert np.array_equal(o[t], host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=t)))
     # the segmented variant (tiling 0's choice for Cin >= 128): its own order -- segments of two chunks summed in fp32 --
     # closer to the float64 convolution than the 216-MFMA chain of the one-k-wave variants; runs repeat
-    seg = host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=WIDE_SEGMENTED))
-    assert np.array_equal(seg, host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=WIDE_SEGMENTED)))
+    seg = host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=12))
+    assert np.array_equal(seg, host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=12)))
+    assert np.array_equal(seg, host(ops.conv3x3_h2(xd, img, bd, 128, True, tiling=13))), "one k-wave + park vs two k-waves"
     assert np.array_equal(seg, host(ops.conv3x3_h2(dev(np.concatenate([x, x])), img, bd, 128, True, tiling=0))[:2])   # B = 4: tiling 0 takes it
     ref = O.conv2d(x, w, b, "SAME", True, dtype=np.float64)
     e_seg, e_one = np.sqrt(((seg - ref) ** 2).mean()), np.sqrt(((o[5] - ref) ** 2).mean())
@@ -211,6 +214,9 @@ def test_batched_form_on_the_vgg_layer_shapes(ops, hw, cin, cout):
         assert np.abs(got[k] - one[0]).max() <= 2e-6 * np.abs(one).max(), k
     assert np.array_equal(host(pooled), got.reshape(4, hw // 2, 2, hw // 2, 2, cout).max(axis=(2, 4)))
     assert float(amax) == float(np.abs(got).max())
+    if cin >= 128:   # tiling 0 = the segmented variants: one k-wave + LDS park (12) and two k-waves (13) -- the same bits
+        assert np.array_equal(host(ops.conv3x3_h2(dev(x), img, bd, cout, True, tiling=12)), got)
+        assert np.array_equal(host(ops.conv3x3_h2(dev(x), img, bd, cout, True, tiling=13)), got)
     # other companions, other position, other batch size (5): the same bits
     x2 = np.concatenate([x[3:4], x[3:4] * 0.5, x[0:1], x[1:2], x[2:3]], axis=0)
     got2 = host(ops.conv3x3_h2(dev(x2), img, bd, cout, True))
