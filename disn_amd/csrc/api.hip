@@ -1517,6 +1517,7 @@ int conv11_rt = 0;
 int tn_interleave = -1;
 int conv5_whole = 1;
 int fused_small = 1;
+int gemv_rows_cfg = 0;
 long long* ch2_stamps = nullptr;
 }
 }  // namespace disn
@@ -1526,16 +1527,16 @@ extern "C" int disn_tuning_set_ptr(int key, void* p) {
   return 0;
 }
 // tuning builds only (build.py --tuning -> libdisn_amd_tuning.so): 0 x3, 1 overlap, 2 bf_splits, 3 skip_pack,
-// 4 fused_safe, 5-7 gemm_force, 8 gemv_wgs, 9 dense_mb, 10 dense_nw, 11 dense_kpw, 12 conv_occ, 13 conv_occ_mask, 14 conv_occ_min, 15 aux_cu_mode, 16 conv_img_major, 17 conv_wide_min, 18 l4_ranges, 19 gather_l16, 20 densew_m64, 21 densew_c128, 22 conv11_wgs, 23 tn_interleave, 24 conv5_whole, 25 fused_small, 26 conv11_rt
+// 4 fused_safe, 5-7 gemm_force, 8 gemv_wgs, 9 dense_mb, 10 dense_nw, 11 dense_kpw, 12 conv_occ, 13 conv_occ_mask, 14 conv_occ_min, 15 aux_cu_mode, 16 conv_img_major, 17 conv_wide_min, 18 l4_ranges, 19 gather_l16, 20 densew_m64, 21 densew_c128, 22 conv11_wgs, 23 tn_interleave, 24 conv5_whole, 25 fused_small, 26 conv11_rt, 27 gemv_rows_cfg
 extern "C" int disn_tuning_set(int key, int value) {
-  int* k[27] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
+  int* k[28] = {&disn::tune::x3, &disn::tune::overlap, &disn::tune::bf_splits, &disn::tune::skip_pack,
                 &disn::tune::fused_safe, &disn::tune::gemm_force[0], &disn::tune::gemm_force[1],
                 &disn::tune::gemm_force[2], &disn::tune::gemv_wgs, &disn::tune::dense_mb,
                 &disn::tune::dense_nw, &disn::tune::dense_kpw, &disn::tune::conv_occ, &disn::tune::conv_occ_mask,
                 &disn::tune::conv_occ_min, &disn::tune::aux_cu_mode,
                 &disn::tune::conv_img_major, &disn::tune::conv_wide_min, &disn::tune::l4_ranges, &disn::tune::gather_l16, &disn::tune::densew_m64, &disn::tune::densew_c128,
-                &disn::tune::conv11_wgs, &disn::tune::tn_interleave, &disn::tune::conv5_whole, &disn::tune::fused_small, &disn::tune::conv11_rt};
-  if (key < 0 || key > 26) return DISN_E_ARG;
+                &disn::tune::conv11_wgs, &disn::tune::tn_interleave, &disn::tune::conv5_whole, &disn::tune::fused_small, &disn::tune::conv11_rt, &disn::tune::gemv_rows_cfg};
+  if (key < 0 || key > 27) return DISN_E_ARG;
   *k[key] = value;
   return 0;
 }

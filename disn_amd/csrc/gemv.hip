@@ -211,6 +211,22 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
 // wt_nk: [N][K] (the TF [K][N] matrix transposed); K % 4 == 0
 hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, const float* bias, int N, int relu,
                             float* out, hipStream_t st) {
+#ifdef DISN_TUNING
+  if (tune::gemv_rows_cfg > 0 && B == 1) {   // (R, U) experiments on the one-row form: the bits do not depend on them
+    const int c = tune::gemv_rows_cfg;
+    const int R = c == 2 || c == 5 ? 2 : (c == 4 ? 4 : 1);
+    const dim3 g(((N + R - 1) / R + 3) / 4);
+    switch (c) {
+      case 1: hipLaunchKernelGGL((gemv_rows_kernel<1, 1, 8>), g, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, 0); break;
+      case 2: hipLaunchKernelGGL((gemv_rows_kernel<1, 2, 8>), g, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, 0); break;
+      case 3: hipLaunchKernelGGL((gemv_rows_kernel<1, 1, 16>), g, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, 0); break;
+      case 4: hipLaunchKernelGGL((gemv_rows_kernel<1, 4, 4>), g, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, 0); break;
+      case 5: hipLaunchKernelGGL((gemv_rows_kernel<1, 2, 4>), g, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, 0); break;
+      default: hipLaunchKernelGGL((gemv_rows_kernel<1, 1, 4>), g, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, 0); break;
+    }
+    return hipGetLastError();
+  }
+#endif
   // two rows per wave when there are enough outputs to fill the chip that way (halves the x re-reads)
   const bool two = N >= 4096;
   const int waves = two ? (N + 1) / 2 : N;

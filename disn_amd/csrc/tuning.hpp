@@ -32,10 +32,11 @@ extern int conv5_whole;    // 0: never the whole-image tiling of 14 x 14 layers 
 extern int fused_small;    // 0: batched calls keep round 3's layer-by-layer point MLP (dense_h2w.hip) instead of the fused small-set kernels
 extern int conv11_wgs;     // > 0: workgroups of conv1_1_direct_kernel's persistent grid (default 512)
 extern int conv11_rt;      // > 0: row pairs per tile of conv1_1_direct_kernel in a batched call (1, 2, 4; default 4)
+extern int gemv_rows_cfg;   // one-row gemv_rows_kernel<1, R, U>: 0 by N (default), 1 <1,8>, 2 <2,8>, 3 <1,16>, 4 <4,4>, 5 <2,4>, 6 <1,4> (same bits: the k order of a lane is U-independent)
 extern int densew_m64, densew_c128;   // >= 0: force dense_h2w's 64-row tiles / forbid its 128-column chunks
 extern long long* ch2_stamps;  // conv_h2 kernels write 16 clock stamps per workgroup here (tools/conv_h2_stamps.py)
 #else
-constexpr int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0, gemv_wgs = 0, dense_mb = 0, dense_nw = 0, dense_kpw = 0, conv_occ = 0, conv_occ_mask = 7 /* 15 with the conv4 variant */, conv_occ_min = 384, conv_img_major = -1, conv_wide_min = 4, l4_ranges = 2, gather_l16 = 0, densew_m64 = -1, densew_c128 = -1, conv11_wgs = 0, conv11_rt = 0, conv5_whole = 1, tn_interleave = -1, fused_small = 1;
+constexpr int x3 = 1, overlap = 1, bf_splits = 0, skip_pack = 0, fused_safe = 0, gemv_wgs = 0, dense_mb = 0, dense_nw = 0, dense_kpw = 0, conv_occ = 0, conv_occ_mask = 7 /* 15 with the conv4 variant */, conv_occ_min = 384, conv_img_major = -1, conv_wide_min = 4, l4_ranges = 2, gather_l16 = 0, densew_m64 = -1, densew_c128 = -1, conv11_wgs = 0, conv11_rt = 0, conv5_whole = 1, tn_interleave = -1, fused_small = 1, gemv_rows_cfg = 0;
 constexpr int gemm_force[3] = {0, 0, 0};
 #endif
 }  // namespace tune
