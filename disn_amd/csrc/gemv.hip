@@ -227,10 +227,13 @@ hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, co
     return hipGetLastError();
   }
 #endif
-  // two rows per wave when there are enough outputs to fill the chip that way (halves the x re-reads)
-  const bool two = N >= 4096;
-  const int waves = two ? (N + 1) / 2 : N;
-  const dim3 grid((waves + 3) / 4);
+  // Round 6 (tools/fc_rows_time.py, cold weights, one row): ONE output row per wave for every layer -- fc7 26.2 -> 20.5 us
+  // (twice the waves streaming: 4096 instead of 2048 for 67 MB); row pieces in flight per lane by K: sixteen for the
+  // 4096-long rows of fc8 (16.8 -> 12.8 us), four for fc7 (enough waves already) and for the 1000-long rows of the bias
+  // fold (18.3 -> 11.9 us: the eight-deep form spent its time in masked tail pieces).  U does not change a lane's k order
+  // (the bits); going from two rows per wave to one changed fc7's (the compiler contracts the two-row body differently).
+  const dim3 grid((N + 3) / 4);
+  const int u = N >= 4096 ? 4 : (K >= 4096 ? 16 : 4);
   // up to eight batch rows per launch: the matrix is read once per launch, and a batch row's sum is the same
   // instruction sequence whatever NB (an eight-step call must not read fc7's 67 MB twice)
   for (int b0 = 0; b0 < B; b0 += 8) {
@@ -238,8 +241,8 @@ hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, co
     switch (nb) {
 #define DISN_GR_CASE(NB)                                                                                          \
   case NB:                                                                                                        \
-    if (two) hipLaunchKernelGGL((gemv_rows_kernel<NB, 2, 4>), grid, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, b0); \
-    else hipLaunchKernelGGL((gemv_rows_kernel<NB, 1, 8>), grid, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, b0);    \
+    if (u == 16) hipLaunchKernelGGL((gemv_rows_kernel<NB, 1, 16>), grid, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, b0); \
+    else hipLaunchKernelGGL((gemv_rows_kernel<NB, 1, 4>), grid, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, b0);    \
     break;
       DISN_GR_CASE(1) DISN_GR_CASE(2) DISN_GR_CASE(3) DISN_GR_CASE(4)
       DISN_GR_CASE(5) DISN_GR_CASE(6) DISN_GR_CASE(7) DISN_GR_CASE(8)
