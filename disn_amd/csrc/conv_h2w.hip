@@ -52,8 +52,8 @@ constexpr int w_row_bytes(int raw) {  // smallest size >= raw that is 128 (mod 2
 
 // MB row blocks per wave, MWV m-waves x NWV n-waves x WK k-waves per workgroup, patch TH x TW (= 32 MB MWV pixels),
 // OCC workgroups per CU the register budget is cut for
-// PARK (WK == 1, SEG == 2): the TWO-K-HALVES order of the two-k-wave segmented variant in ONE k-wave -- the even k16 blocks
-// first (p0: what k-wave 0 of <.., WK = 2, .., SEG = 2> sums), that total parked in LDS, then the odd blocks (p1), p0 + p1:
+// PARK (WK == 1, SEG == 2): the TWO-K-HALVES order of the two-k-wave segmented variant in ONE k-wave -- the lower half of the
+// k16 blocks first (p0: what k-wave 0 of <.., WK = 2, .., SEG = 2> sums), that total parked in LDS, then the upper half (p1), p0 + p1:
 // bit for bit the two-k-wave variant's result with four n-waves per halo instead of two (large calls), see conv_h2w_launch
 template <int MB, int MWV, int NWV, int WK, int TH, int TW, int OCC, int SEG = 0, bool PARK = false>
 __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4) void conv_h2w_kernel(const ConvH2Dev P) {
@@ -102,8 +102,13 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   const int H = P.H, W = P.W, Cin = P.Cin, Cout = P.Cout;
   const int NC = Cin / CK;
   const float* inb = P.in + (size_t)b * H * W * Cin;
-  // chunk i of the walk -> k16 block: i itself, or (PARK) the even blocks, then the odd ones
-  auto blk = [&](int i) __attribute__((always_inline)) { return PARK ? (i < (NC >> 1) ? 2 * i : 2 * (i - (NC >> 1)) + 1) : i; };
+  // HALVES (the two-k-wave SEGMENTED variant): k-wave 0 walks the LOWER half of the k16 blocks, k-wave 1 the upper half --
+  // chunk i holds blocks i and Cin / 32 + i (two 64-byte pieces of two cache lines per halo pixel; a line's other half is
+  // the next chunk's) -- so that the one-k-wave PARK variant, which walks all blocks in order and parks the lower half's
+  // total at the midpoint, sums the same things in the same order.  (A first version split even / odd blocks: the PARK
+  // walk then touched every 128-byte line of the input twice, a whole K half apart -- 2.6 x the input bytes from the
+  // memory side, profiles/r06r_pmc_traffic_even_odd.json.)
+  constexpr bool HALVES = WK == 2 && SEG > 0;
 
   // ---- halo loader: unit u = (halo pixel, float4 of the chunk's CK channels).  Every load is unconditional and
   // every loaded value is used (an out-of-image unit reads a valid address and is ANDed with 0): no exec-mask
@@ -118,13 +123,14 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
     const int hy = hp / RP, hx = hp - hy * RP;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = y >= 0 && y < H && x >= 0 && x < W;
-    goff[k] = ok ? (y * W + x) * Cin + 4 * c4 : 4 * c4;
+    const int coff_u = HALVES ? (c4 < 4 ? 4 * c4 : (Cin >> 1) + 4 * (c4 - 4)) : 4 * c4;
+    goff[k] = ok ? (y * W + x) * Cin + coff_u : coff_u;
     vbits |= ok ? (1u << k) : 0u;
     woff[k] = hy * ROWB + hx * KPIX + 8 * c4;
   }
   auto load_chunk = [&](int c, float4 (&ra)[LP]) {
 #pragma unroll
-    for (int k = 0; k < LP; ++k) ra[k] = *reinterpret_cast<const float4*>(inb + goff[k] + CK * blk(c));
+    for (int k = 0; k < LP; ++k) ra[k] = *reinterpret_cast<const float4*>(inb + goff[k] + (HALVES ? 16 : CK) * c);
   };
   float sa = 1.0f;
   auto store_unit = [&](int buf, const float4 (&ra)[LP], int k) {
@@ -165,8 +171,8 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
   }
 
   // ---- this wave's weight stream: k16 block WK c + wk in chunk c, nine contiguous 2-KiB pairs per chunk ---------
-  const unsigned char* wp = P.wimg + ((size_t)((n0 >> 5) * (Cin >> 4) + wk) * 9) * 2048 + lane * 16;
-  constexpr size_t kChunkStride = (size_t)WK * 9 * 2048;
+  const unsigned char* wp = P.wimg + ((size_t)((n0 >> 5) * (Cin >> 4) + (HALVES ? wk * (Cin >> 5) : wk)) * 9) * 2048 + lane * 16;
+  constexpr size_t kChunkStride = (size_t)(HALVES ? 1 : WK) * 9 * 2048;
   ch_h8 qh[D], ql[D];
 #pragma unroll
   for (int t = 0; t < D; ++t) {
@@ -247,8 +253,8 @@ __global__ __launch_bounds__(64 * MWV * NWV * WK, (OCC * MWV * NWV * WK + 3) / 4
     int ab[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) ab[mb] = arow[mb] + (c & 1) * BUF;
-    const unsigned char* wcur = wp + (size_t)blk(c) * kChunkStride;
-    const unsigned char* wnxt = wp + (size_t)blk(c + 1) * kChunkStride;   // (not dereferenced behind the last chunk)
+    const unsigned char* wcur = wp + (size_t)c * kChunkStride;
+    const unsigned char* wnxt = wcur + kChunkStride;   // (not dereferenced behind the last chunk)
     ch_h8 ah[NB], al[NB];
     auto rd = [&](int s) {
       const int t = s / MB, mb = s % MB;
@@ -484,7 +490,7 @@ hipError_t conv_h2w_launch(ConvH2Dev d, hipStream_t st, int variant) {
   // (Cin = 64: chains of 108 as they are) the round-3 variants below.  variant -1 (the training step): round 3's
   // selection for every layer (chains of up to 432: faster at 4 .. 11 images per call, 1.7 x the error)
   if (variant == 0 && d.Cin >= 128 && d.Cout % 128 == 0) {
-    // two K halves (even / odd k16 blocks), each in segments of two chunks, p0 + p1: as two k-waves over 64-channel
+    // two K halves (lower / upper k16 blocks), each in segments of two chunks, p0 + p1: as two k-waves over 64-channel
     // workgroups (variant 7) while that is what fills the chip, as ONE k-wave that parks p0 in LDS (variant 6: four n-waves
     // per halo, half the loader work per MFMA) from ~200 128-channel workgroups on -- the same bits
     const long wg128 = (long)d.B * ((d.H + 7) / 8) * ((d.W + 27) / 28) * (d.Cout / 128);

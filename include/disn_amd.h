@@ -81,7 +81,7 @@ int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w
  * walk K sequentially; variants 1..3 one k-wave, 4..5 two; H*W >= 784), 10 = the whole-image tiling of layers of at
  * most 14 x 14 pixels (one workgroup per image and 32-channel block, four k-waves), 11 = by shape, single-image form
  * whatever B (what disn_vgg_weights_t.strict_forms = 1 runs), 12 / 13 = the SEGMENTED batched variants (round 6: the k16
- * blocks in two halves -- even, odd --, each half in segments of two 16-channel chunks -- chains of 54 MFMAs -- whose
+ * blocks in two halves -- lower, upper --, each half in segments of two 16-channel chunks -- chains of 54 MFMAs -- whose
  * finished sums are added in fp32 VALU adds, p0 + p1 at the end; 13: two k-waves over 64-channel workgroups, 12: ONE k-wave
  * that parks p0 in LDS, 128-channel workgroups, Cout % 128 == 0; the SAME bits; Cin % 64 == 0, Cin >= 128), 18 = round 3's
  * batched selection by shape and batch (one or two k-waves, chains of up to 432: what the training step runs), 19 = tiling

@@ -15,8 +15,8 @@ else:
   LAYERS = [(64, 64, 224), (64, 128, 112), (128, 128, 112), (128, 256, 56), (256, 256, 56), (256, 512, 28), (512, 512, 28)]
 
 
-def ev_ms(fn, n=10):
-    for _ in range(2):
+def ev_ms(fn, n=30):
+    for _ in range(10):
         fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,11 +30,11 @@ def ev_ms(fn, n=10):
 
 def ref64(x, w, cin, cout):
     # x [B,H,W,Cin] fp32, w [9*cin, cout] rows ordered (ky, kx, ci) -> float64 output of the first 2 images
-    xb = x[:2].double().permute(0, 3, 1, 2)
+    xb = x[:2].double().permute(0, 3, 1, 2)   # (B = 1: one image)
     cols = torch.nn.functional.unfold(xb, 3, padding=1)            # [2, cin*9, HW] rows ordered (ci, ky, kx)
     w64 = w.double().view(3, 3, cin, cout).permute(2, 0, 1, 3).reshape(cin * 9, cout)
     o = torch.einsum("bkp,kn->bpn", cols, w64)
-    return torch.relu(o).view(2, x.shape[1], x.shape[2], cout)
+    return torch.relu(o).view(xb.shape[0], x.shape[1], x.shape[2], cout)
 
 
 torch.manual_seed(0)
@@ -50,7 +50,7 @@ for cin, cout, hw in LAYERS:
     for tiling in TILINGS:
         try:
             t = ev_ms(lambda: ops.conv3x3_h2(x, img, b, cout, True, tiling=tiling, out=o))
-            e = (o[:2].double() - r)
+            e = (o[:r.shape[0]].double() - r)
             res.append("%d: %.1f us rms %.2e max %.2e" % (tiling, t * 1e3, float(e.pow(2).mean().sqrt()) / scale, float(e.abs().max()) / scale))
         except Exception as ex:
             res.append("%d: -" % tiling)
