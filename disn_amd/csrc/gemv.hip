@@ -227,13 +227,16 @@ hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, co
     return hipGetLastError();
   }
 #endif
-  // Round 6 (tools/fc_rows_time.py, cold weights, one row): ONE output row per wave for every layer -- fc7 26.2 -> 20.5 us
-  // (twice the waves streaming: 4096 instead of 2048 for 67 MB); row pieces in flight per lane by K: sixteen for the
-  // 4096-long rows of fc8 (16.8 -> 12.8 us), four for fc7 (enough waves already) and for the 1000-long rows of the bias
-  // fold (18.3 -> 11.9 us: the eight-deep form spent its time in masked tail pieces).  U does not change a lane's k order
-  // (the bits); going from two rows per wave to one changed fc7's (the compiler contracts the two-row body differently).
-  const dim3 grid((N + 3) / 4);
-  const int u = N >= 4096 ? 4 : (K >= 4096 ? 16 : 4);
+  // two rows per wave when there are enough outputs to fill the chip that way (halves the x re-reads)
+  const bool two = N >= 4096;
+  const int waves = two ? (N + 1) / 2 : N;
+  const dim3 grid((waves + 3) / 4);
+  // Round 6 (tools/fc_rows_time.py, cold weights, one row): row pieces in flight per lane by K for the one-row-per-wave
+  // layers -- sixteen for the 4096-long rows of fc8 (16.8 -> 12.8 us), four for the 1000-long rows of the bias fold (18.3
+  // -> 11.9 us: the eight-deep form spent its time in masked tail pieces).  U does not change a lane's k order: the same
+  // bits.  (fc7 with ONE row per wave is 6 us faster too, but the compiler contracts that body differently: other bits
+  // for the single-image forms -- on the 48-set sweep their worst request moved from 8.8e-6 to 9.9e-6, r06t; not taken.)
+  const int u1 = K >= 4096 ? 16 : 4;
   // up to eight batch rows per launch: the matrix is read once per launch, and a batch row's sum is the same
   // instruction sequence whatever NB (an eight-step call must not read fc7's 67 MB twice)
   for (int b0 = 0; b0 < B; b0 += 8) {
@@ -241,7 +244,8 @@ hipError_t gemv_rows_launch(const float* x, int B, int K, const float* wt_nk, co
     switch (nb) {
 #define DISN_GR_CASE(NB)                                                                                          \
   case NB:                                                                                                        \
-    if (u == 16) hipLaunchKernelGGL((gemv_rows_kernel<NB, 1, 16>), grid, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, b0); \
+    if (two) hipLaunchKernelGGL((gemv_rows_kernel<NB, 2, 4>), grid, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, b0); \
+    else if (u1 == 16) hipLaunchKernelGGL((gemv_rows_kernel<NB, 1, 16>), grid, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, b0); \
     else hipLaunchKernelGGL((gemv_rows_kernel<NB, 1, 4>), grid, dim3(256), 0, st, x, K, wt_nk, N, bias, relu, out, b0);    \
     break;
       DISN_GR_CASE(1) DISN_GR_CASE(2) DISN_GR_CASE(3) DISN_GR_CASE(4)

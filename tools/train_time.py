@@ -15,6 +15,12 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 precision = sys.argv[4] if len(sys.argv) > 4 else "f32"   # f32 | f32_mfma | bf16
+if os.environ.get("KNOB"):   # tuning build: KNOB=wgrad_fork=0
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _tuning
+    for kv in os.environ["KNOB"].split(","):
+        k, v = kv.split("=")
+        _tuning.set_knob(k, int(v))
 rng = np.random.default_rng(0)
 tr = Trainer(WeightStore.random_init(seed=0, mode="he"), batch_size=B, precision=precision)
 dev = tr.params.device
