@@ -61,19 +61,22 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
 }
 
 // Four batch rows and more (a batched call): the same split-K stream with the products on the fp32 matrix pipe.
-// v_mfma_f32_16x16x1_4B_f32 is four independent 16 x 16 x 1 outer products: block q = lane / 16 multiplies
-// A[q][i = lane % 16] (here: batch row i's x[k], the same in the four blocks) by B[q][j = lane % 16] -- and a lane's
-// float4 of a 1-KiB weight row segment (columns 4 lane .. 4 lane + 3) IS such a B operand for each of its four
-// components: a weight row costs one 16-byte load and four MFMAs (128 matrix-pipe cycles per SIMD) whatever the number of
-// batch rows up to sixteen, against 4 NB FMAs + NB scalar loads of gemv_kernel<NB> (sixteen rows: 96 us for fc6's 411 MB
-// where one row takes 65).  acc[c][r] of lane l: batch row 4 (l / 16) + r % 4, column 64 (r / 4) + 4 (l % 16) + c of the
-// workgroup's 256.  A wave takes FOUR consecutive k rows per step (x as one float4 per lane), the workgroup's four waves
-// consecutive steps; partial slabs and reduce pass as before.  Summation order of one output: k ascending inside a wave
-// (one product per MFMA), (w0 + w1) + (w2 + w3), then splitk_reduce_kernel: fixed by (K, N, S) -- never by the batch.
+// Round 6: v_mfma_f32_16x16x4_f32 -- D[i][j] += sum_{k < 4} A[i][k] B[k][j], lane l holding A[i = l % 16][k = l / 16] and
+// B[k = l / 16][j = l % 16].  A wave takes FOUR consecutive k rows per step: lane (j, k) loads the float4 W[k0 + k][col0 +
+// 64 cb + 4 j ..] of each of the four 64-column blocks cb (16 lanes = 256 contiguous bytes of a row, four rows per
+// instruction) -- component c of that float4 is the B operand of the MFMA for columns 64 cb + 4 j + c -- and the ONE x
+// value x[row j][k0 + k] as the A operand: sixteen MFMAs per step as before (round 4: 16x16x1 in four blocks, one product
+// per MFMA), but the four products of a step are summed INSIDE the MFMA before they touch the accumulator -- a wave's chain
+// on one accumulator is a quarter as long (fc6: 25 instead of 98: the VALU kernels' length; profiles/r06o_sweep_diag2_set35.txt
+// had the one-product form at 2 x the VALU head's error).  acc[c][4 cb + r] of lane l: batch row 4 (l / 16) + r, column 64 cb
+// + 4 (l % 16) + c of the workgroup's 256 (the layout the epilogue always had).  The workgroup's four waves take
+// consecutive steps; partial slabs and reduce pass as before.  Summation order of one output: k quads ascending inside a wave,
+// (w0 + w1) + (w2 + w3), then splitk_reduce_kernel: fixed by (K, N, S) -- never by the batch.
 __global__ __launch_bounds__(256) void gemv_mfma_kernel(const float* __restrict__ x, int K,
                                                         const float* __restrict__ w, int N,
                                                         float* __restrict__ partial, int Btot, int b0) {
   typedef float v16f __attribute__((ext_vector_type(16)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
   __shared__ float red[4][8][4][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -81,33 +84,33 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const float* __restrict_
   const int K4 = K >> 2;
   const int kbeg = 4 * (int)(((long)K4 * z) / S), kend = 4 * (int)(((long)K4 * (z + 1)) / S);
   const int col0 = blockIdx.x * 256;
-  const int row = lane & 15;
+  const int row = lane & 15, kq = lane >> 4;
   const bool live = b0 + row < Btot;
-  const float* xr = x + (size_t)(live ? b0 + row : b0) * K;
-  const float* wp = w + col0 + lane * 4;
-  v16f acc[4];
+  const float* xr = x + (size_t)(live ? b0 + row : b0) * K + kq;
+  const float* wp = w + col0 + 4 * row + (size_t)kq * N;
+  v4f acc4[4][4];   // [c][cb]
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-  // two register sets: the four row segments (and the x float4) of step i + 1 are requested before the sixteen MFMAs of
+    for (int cb = 0; cb < 4; ++cb) acc4[c][cb] = v4f{0.f, 0.f, 0.f, 0.f};
+  // two register sets: the four row segments (and the x value) of step i + 1 are requested before the sixteen MFMAs of
   // step i are issued (left to itself the compiler waits for every load right behind its issue: one KiB in flight per wave)
-  float4 wv[2][4], xv[2];
-  auto load = [&](int k, float4 (&wq)[4], float4& xq) {
+  float4 wv[2][4];
+  float xv[2];
+  auto load = [&](int k, float4 (&wq)[4], float& xq) {
     const int kk = k < kend ? k : kbeg;            // past the end: a valid address, the values are not used
-    xq = *reinterpret_cast<const float4*>(xr + kk);
+    xq = xr[kk];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wq[e] = nt_load4(wp + (size_t)(kk + e) * N);
+    for (int cb = 0; cb < 4; ++cb) wq[cb] = nt_load4(wp + (size_t)kk * N + 64 * cb);
   };
-  auto mac = [&](const float4 (&wq)[4], float4 xq) {
-    if (!live) xq = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float xe[4] = {xq.x, xq.y, xq.z, xq.w};
+  auto mac = [&](const float4 (&wq)[4], float xq) {
+    if (!live) xq = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[e], wq[e].x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[e], wq[e].y, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[e], wq[e].z, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[e], wq[e].w, acc[3], 0, 0, 0);
+    for (int cb = 0; cb < 4; ++cb) {
+      acc4[0][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq, wq[cb].x, acc4[0][cb], 0, 0, 0);
+      acc4[1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq, wq[cb].y, acc4[1][cb], 0, 0, 0);
+      acc4[2][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq, wq[cb].z, acc4[2][cb], 0, 0, 0);
+      acc4[3][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq, wq[cb].w, acc4[3][cb], 0, 0, 0);
     }
   };
   const int k0 = kbeg + 4 * wave;
@@ -124,6 +127,13 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const float* __restrict_
     __builtin_amdgcn_sched_barrier(0);
   }
   if (n & 1) mac(wv[0], xv[0]);
+  v16f acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[c][4 * cb + r] = acc4[c][cb][r];
   // (w0 + w1) + (w2 + w3) through LDS, eight accumulator registers (two column blocks of 64) per round
   const int t = threadIdx.x;
 #pragma unroll
@@ -268,7 +278,11 @@ int gemv_splits(int K, int N, int B) {
   const int colblocks = N / 256;
   const int wgs = tune::gemv_wgs > 0 ? tune::gemv_wgs : (B >= tune::conv_wide_min ? 1024 : 2048);
   int s = (wgs + colblocks - 1) / colblocks;
-  const int smax = K / 32 > 0 ? K / 32 : 1;
+  // at least 32 k rows per split (a one-row call: 2048 workgroups want them short); a batched call: at least 128 -- its
+  // small layers otherwise write more partial bytes than they read weights (round 5: fc8 128 splits, the bias fold 31:
+  // 8 / 16 MB of slabs for 16 / 2 MB of weights, a 42 us reduce pass; round 6: 32 / 7)
+  const int per = B >= tune::conv_wide_min ? 128 : 32;
+  const int smax = K / per > 0 ? K / per : 1;
   if (s > smax) s = smax;
   if (s < 1) s = 1;
   return s;
