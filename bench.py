@@ -329,7 +329,7 @@ def dry_run(args, torch, dist, world, rank, launched):
 
 def _accuracy_of_the_timed_mode(strict: bool, sb: int):
     """north_star's tolerance for the kernel FORMS the main line times, from the committed full sweep of this round
-    (tests/test_gpu_sweep.py with DISN_SWEEP=full on a GPU box -> profiles/r06v_sweep_full.json: 48 trained-like weight
+    (tests/test_gpu_sweep.py with DISN_SWEEP=full on a GPU box -> profiles/r06w_sweep_full.json: 48 trained-like weight
     sets x 8 images, max |pred_sdf - float64 oracle| per request); the line's own three-set spot check of the same
     forms on this box is cpu_baseline.parity_trained_like.sweep"""
     out = {"bar": 1e-5, "on": "pred_sdf (the un-divided network output; the SDF value is pred_sdf / 10)",
@@ -337,15 +337,15 @@ def _accuracy_of_the_timed_mode(strict: bool, sb: int):
                            ("batched forms (calls of >= 4 requests): segmented convolutions, matrix-pipe fc head, fused small-set MLP"
                             if sb >= 4 else "single-image forms (calls of < 4 requests)"))}
     try:
-        sw = json.load(open(os.path.join(ROOT, "profiles", "r06v_sweep_full.json")))["summary"]
+        sw = json.load(open(os.path.join(ROOT, "profiles", "r06w_sweep_full.json")))["summary"]
         bf = sw["by_form"]
         forms = ("strict4", "strict16") if strict else (("batch4", "batch16") if sb >= 4 else ("single",))
         out.update({"sweep_worst_of_the_timed_forms": max(bf[f]["max"] for f in forms),
                     "sweep_requests": sum(bf[f]["n"] for f in forms), "sweep_sets": sw["sets"],
                     "sweep_worst_of_every_form": sw["worst"], "within_bar": max(bf[f]["max"] for f in forms) <= 1e-5,
-                    "source": "profiles/r06v_sweep_full.json (tests/test_gpu_sweep.py, DISN_SWEEP=full; asserts <= bar for every form)"})
+                    "source": "profiles/r06w_sweep_full.json (tests/test_gpu_sweep.py, DISN_SWEEP=full; asserts <= bar for every form)"})
     except Exception as e:   # the committed file is the evidence; its absence must not cost the line
-        out["sweep"] = "profiles/r06v_sweep_full.json not readable: %r" % (e,)
+        out["sweep"] = "profiles/r06w_sweep_full.json not readable: %r" % (e,)
     return out
 
 def main():
@@ -1076,7 +1076,7 @@ def main():
                                       "worst": max(errs["single"] + errs["batch16"]), "bar": 1e-5,
                                       "equalised_weights": True,
                                       "reference": "tests/golden/stress_sweep.npz (float64 oracle); the full sweep: "
-                                                   "tests/test_gpu_sweep.py, profiles/r06v_sweep_full.json"}
+                                                   "tests/test_gpu_sweep.py, profiles/r06w_sweep_full.json"}
                 parity_tl["worst"] = max(parity_tl["worst"], parity_tl["sweep"]["worst"])
             except Exception as e:
                 parity_tl = {"error": repr(e)} if parity_tl is None else dict(parity_tl, sweep_error=repr(e))

@@ -97,7 +97,7 @@ int disn_conv3x3_x3(const float* in, int B, int H, int W, int Cin, const void* w
  * which form ran it (B >= 4 or not), never on its companions, its position or the exact B.  Why segments: a chain of
  * L MFMAs on one fp32 accumulator carries ~0.3 sqrt(L) ulp of rounding noise (tools/ubench/mfma_round.hip: 6.2 ulp rms
  * at 432, 0.9-1.0 with a restart every 27-54); round 3's chains of 216-432 put 2.7 % of trained-like batched requests at
- * 1.0-1.46e-5 of the float64 oracle (profiles/r05k_sweep_full.json), the segmented forms none (profiles/r06v_sweep_full.json: worst 8.9e-6).
+ * 1.0-1.46e-5 of the float64 oracle (profiles/r05k_sweep_full.json), the segmented forms none (profiles/r06w_sweep_full.json: worst 9.5e-6).
  * ws: disn_conv3x3_h2_workspace_bytes(B). */
 size_t disn_pack_conv_h2_bytes(int Cin, int Cout);
 int disn_pack_conv_h2(const float* w_hwio, int Cin, int Cout, void* image, void* stream);

@@ -33,8 +33,8 @@ from oracle import disn_oracle as O
 pytestmark = pytest.mark.gpu
 BAR = 1e-5
 # What is asserted: every case of every form <= BAR (1e-5 on the UN-divided network output; the SDF value is pred_sdf / 10,
-# test/create_sdf.py:285).  Measured over all 48 sets (profiles/r06v_sweep_full.json: 1104 default-mode + 960 strict-mode
-# requests): single <= 6.2e-6, grid <= 8.4e-6, calls of 4 / 16 requests <= 8.7e-6 / 8.9e-6 (median 2.7e-6, p90 5.1e-6),
+# test/create_sdf.py:285).  Measured over all 48 sets (profiles/r06w_sweep_full.json: 1104 default-mode + 960 strict-mode
+# requests): single <= 6.2e-6, grid <= 8.4e-6, calls of 4 / 16 requests <= 7.9e-6 / 9.5e-6 (median 2.7e-6, p90 5.1e-6),
 # strict <= 8.8e-6; the float32 CPU oracle itself: median 8.6e-6, worst 1.87e-5.  Until round 5 the batched convolutions
 # summed K in chains of up to 432 MFMAs per accumulator and 2.7 % of the batched requests sat at 1.0-1.46e-5
 # (profiles/r05k_sweep_full.json); tools/ubench/mfma_round.hip measures what a chain costs (rms 6.2 ulp at 432 MFMAs,
