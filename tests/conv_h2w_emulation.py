@@ -13,7 +13,29 @@ from conv_h2_emulation import pack, pow2_scale, quad_row, sigma, split  # noqa: 
 
 # variant -> MB, MWV, NWV, WK, TH, TW   (conv_h2w_launch's switch)
 VARIANTS = {1: (4, 2, 2, 1, 8, 32), 2: (7, 1, 4, 1, 8, 28), 3: (7, 1, 2, 1, 8, 28), 4: (7, 1, 4, 2, 8, 28),
-            5: (7, 1, 2, 2, 8, 28)}
+            5: (7, 1, 2, 2, 8, 28), 6: (7, 1, 4, 1, 8, 28), 7: (7, 1, 2, 2, 8, 28)}
+# round 6, the SEGMENTED variants (SEG = 2): the k16 blocks in two halves (lower -> p0, upper -> p1), each half in segments
+# of two chunks whose sums are added in order, p0 + p1 at the end.  6 (PARK): ONE k-wave walks every block in order and
+# parks p0 at the midpoint; 7 (HALVES): k-wave 0 walks the lower half, k-wave 1 the upper half -- chunk i holds blocks i and
+# Cin / 32 + i.  Same (block, tap) sequence per accumulator and the same segment boundaries: the same bits on the GPU.
+SEGMENTED = {6: "park", 7: "halves"}
+
+
+def segment_plan(variant, cin):
+    """-> [p0, p1], each a list of segments, each segment the k16 blocks it sums (in order) -- per accumulator"""
+    kb = cin // 16
+    assert variant in SEGMENTED and kb % 4 == 0 and kb >= 8, "two halves of whole two-chunk segments"
+    halves = [list(range(0, kb // 2)), list(range(kb // 2, kb))]
+    return [[h[i:i + 2] for i in range(0, len(h), 2)] for h in halves]
+
+
+def chunk_blocks(variant, cin, c):
+    """k16 blocks that chunk c of the walk stages in LDS, per k-wave: {wk: block}"""
+    kb = cin // 16
+    if SEGMENTED.get(variant) == "halves":
+        return {0: c, 1: kb // 2 + c}
+    WK = VARIANTS[variant][3]
+    return {wk: WK * c + wk for wk in range(WK)}
 
 
 _r, _lane = np.meshgrid(np.arange(16), np.arange(64), indexing="ij")
@@ -62,6 +84,7 @@ def conv_tile(x, img, s_w, bias, variant, tile, relu=True):
     sa = pow2_scale(np.abs(x).max(), 14)
     descale = np.float32(1.0) / sa * (np.float32(1.0) / np.asarray(s_w, np.float32))     # [Cout]: per column
     acc = np.zeros((MWV, NWV, WK, MB, 16, 64), np.float64)
+    visited = {}
     for c in range(NC):
         # ---- the halo in byte-addressed LDS (one buffer; f16 element a at byte 2a), NaN = never written ----
         lds = np.full(BUF // 2, np.nan, np.float64)
@@ -73,7 +96,11 @@ def conv_tile(x, img, s_w, bias, variant, tile, relu=True):
                 hy, hx = divmod(hp, RP)
                 yy, xx = y0 - 1 + hy, x0 - 1 + hx
                 ok = 0 <= yy < H and 0 <= xx < W
-                v = (x[yy, xx, CK * c + 4 * c4:CK * c + 4 * c4 + 4] * sa).astype(np.float32) if ok else np.zeros(4, np.float32)
+                if SEGMENTED.get(variant) == "halves":   # two 64-byte pieces of two cache lines per halo pixel
+                    ch0 = 16 * c + 4 * c4 if c4 < 4 else Cin // 2 + 16 * c + 4 * (c4 - 4)
+                else:
+                    ch0 = CK * c + 4 * c4
+                v = (x[yy, xx, ch0:ch0 + 4] * sa).astype(np.float32) if ok else np.zeros(4, np.float32)
                 h, l = split(v)
                 woff = hy * ROWB + hx * KPIX + 8 * c4
                 for e in range(4):
@@ -87,7 +114,9 @@ def conv_tile(x, img, s_w, bias, variant, tile, relu=True):
                 n0 = (nt * NWV + wn) * 32
                 for wk in range(WK):
                     for t in range(9):
-                        f = ((n0 >> 5) * KB + c * WK + wk) * 9 + t
+                        blk = chunk_blocks(variant, Cin, c)[wk]
+                        visited.setdefault((wm, wn, wk), []).append(blk) if t == 0 else None
+                        f = ((n0 >> 5) * KB + blk) * 9 + t
                         bh, bl = img[f, 0].astype(np.float64), img[f, 1].astype(np.float64)
                         Bh = np.zeros((16, 32)); Bl = np.zeros((16, 32))
                         for lane in range(64):
@@ -105,6 +134,11 @@ def conv_tile(x, img, s_w, bias, variant, tile, relu=True):
                             assert not np.isnan(Ah).any() and not np.isnan(Al).any(), "a fragment read LDS bytes nobody wrote"
                             Dm = Al @ Bh + Ah @ Bl + Ah @ Bh
                             acc[wm, wn, wk, mb] += Dm[C_ROW, C_COL]      # C layout: lane (j, g), register r
+    if variant in SEGMENTED:   # every accumulator's walk is the plan's: PARK one k-wave (p0 then p1), HALVES k-wave w = half w
+        plan = segment_plan(variant, Cin)
+        for (wm, wn, wk), blocks in visited.items():
+            want = [b for seg in (plan[0] + plan[1] if SEGMENTED[variant] == "park" else plan[wk]) for b in seg]
+            assert blocks == want, (variant, wk, blocks, want)
     out, pooled, vmax = {}, {}, 0.0
     MBH = (MB + 1) // 2 if WK == 2 else MB
     for wm in range(MWV):

@@ -9,7 +9,8 @@ from test_conv_h2_emulation import case, ref_conv
 
 
 @pytest.mark.parametrize("variant,H,W,cin,cout", [(1, 10, 34, 64, 64), (2, 8, 28, 64, 128), (2, 12, 30, 64, 128),
-                                                  (3, 6, 28, 64, 64), (4, 10, 28, 64, 128), (5, 8, 30, 128, 64)])
+                                                  (3, 6, 28, 64, 64), (4, 10, 28, 64, 128), (5, 8, 30, 128, 64),
+                                                  (6, 8, 28, 128, 128), (7, 10, 30, 128, 64)])
 def test_every_variant_reproduces_the_convolution(variant, H, W, cin, cout):
     x, w, b = case(H, W, cin, cout, seed=variant)
     out, pooled, vmax = E.conv(x, w, b, variant)
@@ -42,8 +43,26 @@ def test_geometry_fits_the_hardware():
         assert (G["KPIX"] // 16) % 2 == 1
         lds = max(2 * G["BUF"], MWV * NWV * MB * 4096 if WK == 2 else 0)
         occ = 2 if WK == 1 else 1
+        if E.SEGMENTED.get(v) == "park":   # p0 of every wave parked BEHIND the halo buffers, one workgroup per CU
+            lds, occ = 2 * G["BUF"] + MWV * NWV * WK * MB * 4096, 1
+        elif v in E.SEGMENTED:
+            occ = 1
         assert lds * occ <= 160 * 1024
         # the largest tap offset is an immediate of ds_read (16 bits)
         assert 2 * G["ROWB"] + 2 * G["KPIX"] + G["CK"] * 2 < 65536
         # a thread's halo units fit the sub-steps that carry them
         assert -(-G["UNITS"] // G["NT"]) <= 5 * MB
+
+
+@pytest.mark.parametrize("cin", [128, 256, 512])
+def test_the_two_segmented_variants_sum_the_same_things_in_the_same_order(cin):
+    """variant 6 (one k-wave, p0 parked at the midpoint) and variant 7 (k-wave w = K half w): the same two halves, the
+    same two-chunk segments, every k16 block exactly once -- what makes tilings 12 and 13 bit-identical on the GPU"""
+    p6, p7 = E.segment_plan(6, cin), E.segment_plan(7, cin)
+    assert p6 == p7
+    blocks = [b for half in p6 for seg in half for b in seg]
+    assert sorted(blocks) == list(range(cin // 16)) and all(len(seg) == 2 for half in p6 for seg in half)
+    # the walks: PARK visits chunk c = block c; HALVES stages blocks c and cin / 32 + c in chunk c (k-wave 0 / 1)
+    assert [E.chunk_blocks(6, cin, c)[0] for c in range(cin // 16)] == blocks
+    assert [E.chunk_blocks(7, cin, c)[0] for c in range(cin // 32)] == [b for seg in p7[0] for b in seg]
+    assert [E.chunk_blocks(7, cin, c)[1] for c in range(cin // 32)] == [b for seg in p7[1] for b in seg]
