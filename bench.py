@@ -595,6 +595,7 @@ def main():
     if rank == 0:
         print("[bench] main line: %.4g points/s, %.4f ms/step" % (value, line["ms_per_step"]), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_extras:   # roofline / cpu legs: N=1 only (bench contract)
+        pmc = {}   # profiles/pmc_traffic.json (read in the roofline leg; the gather legs quote it too)
         # ---- one step at a time (the latency of a step; the main line overlaps S independent steps) ----------
         try:
             if S > 1 or SB > 1:
@@ -827,7 +828,8 @@ def main():
                 gb = nb * N_POINTS * GATHER_BYTES_PER_PT
                 line["roofline_gather"]["call_project_gather_taps_wave_%dx%d" % (nb, N_POINTS)] = {
                     "ms": ms_gather, "algorithmic_bytes": gb, "achieved": gb / ms_gather / 1e6, "frac": gb / ms_gather / 1e6 / PEAK_HBM_GBS,
-                    "traffic": None,
+                    "traffic": (((pmc.get("small_set_b16") or {}).get("gather_split") or {}).get("hbm_bytes")
+                                if nb == 16 and ((pmc.get("small_set_b16") or {}).get("gather_split") or {}).get("kernel") == "project_gather_taps_wave_kernel" else None),
                     "note": "the gather of the timed call in split form [h8 | l8] (project_gather_taps_wave_kernel: one wave per point, "
                             "duplicate tap rows / columns skipped by scalar branches; ~36 KB/point requested through L1 against the "
                             "thread-per-float4 kernel's 100 KB; the same bits); 29 440 B/point convention; A/B: profiles/r06j_gather_ab.txt"}

@@ -53,6 +53,7 @@ g_small = [i for i in gathers if int(fetch[i]["grid"]) < 1_000_000][-1]
 g_big = [i for i in gathers if int(fetch[i]["grid"]) >= 1_000_000][-1]
 cal = 262144 * 5888 / 1024.0 / write[g_big]["v"]
 g_taps = [i for i in ids if "project_gather_taps_kernel" in fetch[i]["name"]]
+g_wave = [i for i in ids if "project_gather_taps_wave_kernel" in fetch[i]["name"]]   # round 6: calls of >= 10 240 points
 g_fold = [i for i in ids if "gather_fold_kernel" in fetch[i]["name"]]
 fused = [i for i in ids if "mlp_fused_kernel" in fetch[i]["name"]]
 build = os.environ.get("PMC_BUILD", "")
@@ -94,8 +95,10 @@ out = {"build": build, "counter_files": os.environ.get("PMC_BUILD", ""), "source
                              "note": "per 65536 points: weights re-streamed per 128-point tile stay in L2; the local "
                                      "stream adds 8 KB/point of pmap rows (L2 / MALL resident)"} if fused else None),
        "small_set_b16": (lambda fe, gl, ga: {
-           "gather_split": dict(hbm(ga[-1:]), algorithmic_bytes=16 * 2048 * (16 * 5888 + 6144),
-                                note="16 x 2048 points: 94 208 B/point of (cached) tap pixels read, 6144 B/point of split rows written"),
+           "gather_split": dict(hbm((g_wave or ga)[-1:]), algorithmic_bytes=16 * 2048 * 29440,
+                                kernel="project_gather_taps_wave_kernel" if g_wave else "project_gather_taps_kernel",
+                                note="16 x 2048 points, split rows; algorithmic = the 29 440 B/point convention of roofline_gather "
+                                     "(the one-wave-per-point kernel requests ~36 KB/point of L2 / MALL-resident tap pixels and writes 6144 B/point)"),
            "local_feat": dict(hbm(fe[-1:]), algorithmic_bytes=16 * 2048 * 6144 + 5308416,
                               note="split rows read once + one pass over the 5.3 MB weight image (every workgroup re-reads it from L2)"),
            "global": hbm([i for i in gl if i > fe[-1]][:1])} if fe else None)(
