@@ -193,6 +193,34 @@ def test_split_form_gather_is_the_fp32_gather_split(eng_store):
     assert np.array_equal(got2[1], E.split_rows(feat[1], float(amax[1]) * 3.0))
 
 
+def test_one_wave_per_point_gather_equals_the_thread_per_float4_gather(eng_store):
+    """from 10 240 points per call on the gather from the taps runs one wave per point (round 6: wave-uniform geometry,
+    duplicate tap rows / columns skipped by scalar branches) -- the SAME BITS as the thread-per-float4 kernel that serves
+    smaller calls: 6 images x 2048 points in one call (wave kernel) against the same requests image by image (thread
+    kernel), fp32 rows and split rows; points far outside the image, on its border and NaN cameras included"""
+    from disn_amd import ops
+    eng, _ = eng_store
+    rng = np.random.default_rng(11)
+    B, N = 6, 2048
+    enc = eng.encode(rng.random((B, 137, 137, 3), dtype=np.float32))
+    pts = rng.uniform(-0.6, 0.6, (B, N, 3)).astype(np.float32)
+    pts[:, :16] *= 40.0                                   # far outside the image
+    tms = np.stack([O.DEMO_TRANS_MAT[0]] + [O.synth_trans_mat(30.0 + 50.0 * k, 25.0, 0.8) for k in range(B - 1)]).astype(np.float32)
+    tms[3, 3, 2] = np.nan                                 # a degenerate camera: every point of image 3 projects to NaN
+    pts_d, tms_d = torch.from_numpy(pts).cuda(), torch.from_numpy(tms).cuda()
+    amax = torch.stack([torch.stack([t[b].abs().max() for t in enc.taps]).max() for b in range(B)]).contiguous()
+    wave = ops.gather_taps(enc.taps, tms_d, pts_d)
+    wave_split = ops.gather_taps_split(enc.taps, tms_d, pts_d, amax)
+    assert bool(torch.isfinite(wave).all())
+    for b in range(B):
+        taps_b = [t[b:b + 1].contiguous() for t in enc.taps]
+        one = ops.gather_taps(taps_b, tms_d[b:b + 1].contiguous(), pts_d[b:b + 1].contiguous())
+        assert torch.equal(one[0], wave[b]), "fp32 rows, image %d" % b
+        one_s = ops.gather_taps_split(taps_b, tms_d[b:b + 1].contiguous(), pts_d[b:b + 1].contiguous(), amax[b:b + 1].contiguous())
+        assert torch.equal(one_s[0], wave_split[b]), "split rows, image %d" % b
+    assert float(wave[3].abs().max()) == 0.0              # NaN projection -> the resampler's zeros (sample4's `ok` test)
+
+
 def _oracle_taps(store, enc, pts, tms):
     fm = np.concatenate([O.resize_bilinear_legacy(t.cpu().numpy(), 137, 137) for t in enc.taps], axis=3)
     xy = O.get_img_points(pts, tms)
