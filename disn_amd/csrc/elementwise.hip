@@ -30,8 +30,8 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
                                                      float* __restrict__ zero, int nzero) {
   // side job of the encoder's first launch: clear the activation-maximum slots of the convolution stack
   // (api.hip vgg_features) -- saves a memset launch and the stream bubble around it
-  if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0.f;
+  // (spread over the launch: one workgroup clearing the 14 x 64 slots of SIXTEEN images alone was most of the launch's 14 us)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)nzero; i += (size_t)gridDim.x * blockDim.x) zero[i] = 0.f;
   const int cv = C / VEC;
   const size_t total = (size_t)B * Hout * Wout * cv;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
