@@ -15,7 +15,8 @@ segments summed in fp32 VALU adds -- and the fused small-set MLP) and STRICT (di
 SdfEngine(strict=True): the single-image forms for every call size; a request's taps, embedding and pred_sdf bit for bit
 those of the request alone).  EVERY request of EVERY form in EITHER mode: <= 1e-5.
 
-Default: 12 of the 48 weight sets (all of sigma = 2 for four seeds + one of every other (sigma, outlier) pair);
+Default: 18 of the 48 weight sets (all of sigma = 2 for four seeds + one of every other (sigma, outlier) pair + the seven
+sets that hold the full run's worst requests);
 DISN_SWEEP=full runs all 48 (profiles/r05*_sweep_full.json is that run).  The distribution is printed and, when
 gpurun_out/ exists, written there as JSON.
 """
@@ -50,7 +51,10 @@ def _chosen():
     pick = [i for i, (s, sg, og) in enumerate(MS.SETS) if sg == 2.0 and s in MS.SEEDS[:4]]
     pick += [MS.SETS.index((MS.SEEDS[4], 1.0, 1e3)), MS.SETS.index((MS.SEEDS[5], 1.0, 1e4)),
              MS.SETS.index((MS.SEEDS[6], 1.5, 1e3)), MS.SETS.index((MS.SEEDS[7], 1.5, 1e4))]
-    return sorted(pick)
+    # round 6: + every set that holds a request above 7.5e-6 in the committed full run (profiles/r06w_sweep_full.json), so
+    # that the run the driver makes sees the whole tail of the distribution, not a sample of it
+    pick += [20, 24, 25, 28, 29, 33, 35]
+    return sorted(set(pick))
 
 
 def _forms(eng, s, dev, strict_eng=None):
